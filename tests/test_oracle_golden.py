@@ -136,6 +136,15 @@ def _check_summary(got, ref, what, rtol=2e-3, scalar_rtol=2e-2):
     assert abs(got[1] - ref[1]) <= rtol * max(ref[1], 1e-12) + 1e-9, what
 
 
+def _check_par(got, ref, what, it, lr=2e-4):
+    """Parameters after Adam: iteration 0 tight; afterwards sign flips of near-zero grads move single
+    elements by up to 2*lr per step, so compare element samples with an absolute 3*lr budget."""
+    if it == 0:
+        _check_summary(got, ref, what, 1e-4, 1e-4)
+    else:
+        assert np.abs(got[3:] - ref[3:]).max() <= 3 * lr, what
+
+
 @pytest.mark.parametrize("name,content,area,l1w", [("step_l1", "none", 1, 100.0), ("step_nn", "block1_conv2", 5, 0.01)])
 def test_two_training_iterations(name, content, area, l1w):
     fix = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -162,13 +171,13 @@ def test_two_training_iterations(name, content, area, l1w):
         g_rtol, g_srtol, p_rtol = (2e-3, 2e-2, 1e-4) if it == 0 else (5e-2, None, 5e-3)
         for k in tr.dp:
             _check_summary(summarize(tr.last_disc_grads[k]), fix["it%d_dgrad_%s" % (it, k)], "dgrad " + k, g_rtol, g_srtol)
-            _check_summary(summarize(tr.dp[k]), fix["it%d_dpar_%s" % (it, k)], "dpar " + k, p_rtol, p_rtol)
+            _check_par(summarize(tr.dp[k]), fix["it%d_dpar_%s" % (it, k)], "dpar " + k, it)
         og, gl = tr.gen_update(bC[0], bC[1], bC[2], bC[3], dC)
         np.testing.assert_allclose(gl, fix["it%d_gen_losses" % it], rtol=1e-4 if it == 0 else 2e-3, atol=1e-6)
         assert np.abs(og.numpy() - fix["it%d_out_gen" % it]).max() < (1e-4 if it == 0 else 1e-3)
         for k in tr.gp:
             _check_summary(summarize(tr.last_gen_grads[k]), fix["it%d_ggrad_%s" % (it, k)], "ggrad " + k, g_rtol, g_srtol)
-            _check_summary(summarize(tr.gp[k]), fix["it%d_gpar_%s" % (it, k)], "gpar " + k, p_rtol, p_rtol)
+            _check_par(summarize(tr.gp[k]), fix["it%d_gpar_%s" % (it, k)], "gpar " + k, it)
 
 
 def test_baseline_step():
