@@ -1,0 +1,198 @@
+/*
+ * posegan_hip.h — C ABI of libposegan_hip.so: the MI355X (gfx950) kernels behind the
+ * Deformable-GAN training step.
+ *
+ * The reference (saurabhsharma1993/pose-transfer) has no FFI: its seam is the ATen op set its
+ * Python modules dispatch.  Each entry point below names the reference call site(s) it replaces
+ * (paths relative to /root/reference/src_deformable).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error (message: pg_last_error(), thread-local);
+ *   - all pointers are DEVICE pointers unless stated; buffers are borrowed (caller-owned, must outlive
+ *     the stream work); the library allocates nothing persistent;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is stream-ordered, no
+ *     host synchronisation happens inside any call;
+ *   - activations are fp32 NHWC ("pixel-major": [N][H][W][C]) unless a stride quadruple is given;
+ *   - conv / conv-transpose weights are fp32 packed [KH][KW][Cout][Cin] (host packs once from the
+ *     reference's OIHW / IOHW state_dict layouts).
+ */
+#ifndef POSEGAN_HIP_H
+#define POSEGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_MAX_SRC 4
+#define PG_ACT_NONE 0
+#define PG_ACT_RELU 1   /* nn.ReLU         models/networks.py:152 */
+#define PG_ACT_LEAKY 2  /* nn.LeakyReLU(0.2) models/networks.py:150 */
+#define PG_OUT_NONE 0
+#define PG_OUT_TANH 1   /* nn.Tanh         models/networks.py:232 */
+
+/* One K-operand source of a (virtually concatenated) convolution input: replaces torch.cat
+ * (models/networks.py:241,245,271,284,286; models/pose_gan.py:86,133,135) — never materialised.
+ * value(n,c,y,x) = act( (a_n * raw + b_n) * mask[n][c] ), zero outside the image.            */
+typedef struct {
+  const float* ptr;   /* raw tensor                                                          */
+  int32_t C;          /* channels of this source                                             */
+  int32_t _pad;
+  const float* aff;   /* [N][2] per-sample (a,b): the deferred per-sample norm; NULL = (1,0) */
+  const float* mask;  /* [N][C] channel-dropout multipliers (Dropout2d); NULL = none         */
+  int64_t sN, sC, sH, sW; /* element strides; used only when the conv is run in scalar mode  */
+} pg_src_t;
+
+/* One destination of a data-gradient epilogue (the gradient of the concat is split back):
+ * grad[n,y,x,c] (+)= g * mask[n][c] * act'( (a_n*fwd + b_n) * mask[n][c] )                   */
+typedef struct {
+  float* grad;        /* NHWC [N][Ho][Wo][C]                                                 */
+  const float* fwd;   /* raw forward tensor the activation derivative is evaluated on, or NULL */
+  const float* aff;   /* [N][2] or NULL                                                      */
+  const float* mask;  /* [N][C] or NULL                                                      */
+  int32_t C;
+  int32_t act;        /* PG_ACT_* of the consumer that read `fwd`                            */
+  int32_t accumulate; /* 1: grad += ...; 0: grad = ...                                       */
+  int32_t _pad;
+} pg_dst_t;
+
+/* Implicit-GEMM convolution, fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   mode 0 "down": out[n,oy,ox,:] = sum_{r,s} W[r][s] . in[n, oy*stride + r - pad, ox*stride + s - pad, :]
+ *                  = nn.Conv2d forward (models/networks.py:154,186,228,341) and the data-gradient of
+ *                    nn.ConvTranspose2d+Cropping2D(1) (models/networks.py:156-157).
+ *   mode 1 "up":   out[n,Y,X,:]   = sum_{r,s: (Y+pad-r)%stride==0} W[r][s] . in[n,(Y+pad-r)/stride,(X+pad-s)/stride,:]
+ *                  = nn.ConvTranspose2d(k4,s2)+crop forward (pad=1) and the data-gradient of nn.Conv2d.
+ *   w_transposed 0: GEMM-N runs over the packed weight's Cout, K over its Cin (forward passes);
+ *                1: GEMM-N over Cin, K over Cout (data-gradient passes); n_off/n_cnt select a sub-range of N.
+ *   epilogue 0: out (+bias)(tanh) stored through (oN,oC,oH,oW) strides;
+ *   epilogue 1: data-gradient split over `dst[]` with fused activation derivative / dropout mask.  */
+typedef struct {
+  pg_src_t src[PG_MAX_SRC];
+  int32_t nsrc, N, Hi, Wi;
+  int32_t act;              /* PG_ACT_* applied to the operand after affine+mask                   */
+  int32_t scalar_in;        /* 1: sources are small-C strided tensors (e.g. NCHW inputs)            */
+  int32_t mode, KH, KW, stride, pad, Ho, Wo;
+  int32_t w_transposed;
+  const float* W;           /* packed [KH][KW][wCout][wCin]                                        */
+  int32_t wCout, wCin;
+  int32_t n_off, n_cnt;     /* GEMM-N sub-range (0, full) in the common case                       */
+  int32_t epilogue;
+  int32_t out_act;          /* PG_OUT_*                                                            */
+  float* out;
+  const float* bias;        /* [n_cnt] or NULL                                                     */
+  int64_t oN, oC, oH, oW;   /* output element strides (NHWC: Ho*Wo*C, 1, Wo*C, C)                  */
+  pg_dst_t dst[PG_MAX_SRC];
+  int32_t ndst;
+  int32_t ksplit;           /* 0 = auto; >1 splits K across workgroups (atomic accumulate)         */
+} pg_conv_t;
+
+int pg_conv(const pg_conv_t* desc, void* stream);
+
+/* Weight gradient of the same relation (torch autograd of conv2d / conv_transpose2d wrt weight):
+ *   dW[r][s][co][ci] += sum_{n,qy,qx} dY_small/large[...,co] * X_large/small[...,ci]
+ * with small pixel (qy,qx) <-> large pixel (qy*stride + r - pad, qx*stride + s - pad).
+ *   x_is_large 1: X is the large tensor (nn.Conv2d); 0: X is the small one (nn.ConvTranspose2d+crop).
+ * X is a virtual concat of `src[]` with the same fused prologue as the forward; dW must be
+ * zero-initialised by the caller (it is accumulated, split-K uses float atomics).              */
+typedef struct {
+  pg_src_t src[PG_MAX_SRC];
+  int32_t nsrc, N;
+  int32_t act, scalar_x;
+  const float* dY;          /* NHWC [N][Hy][Wy][Cout] (or strided when scalar_y)                   */
+  int64_t yN, yC, yH, yW;   /* dY strides (used when scalar_y)                                     */
+  int32_t scalar_y;
+  int32_t x_is_large;
+  int32_t Hs, Ws, Hl, Wl;   /* small / large spatial sizes                                         */
+  int32_t KH, KW, stride, pad;
+  float* dW;                /* packed [KH][KW][Cout][Cin]                                          */
+  int32_t Cout, Cin;
+  int32_t ksplit;           /* 0 = auto                                                            */
+  int32_t _pad;
+} pg_wgrad_t;
+
+int pg_conv_wgrad(const pg_wgrad_t* desc, void* stream);
+
+/* db[c] += sum over rows of a strided [rows][C] view (bias gradient; torch autograd of conv bias). */
+int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,
+                 int64_t s_inner, int64_t sC, float* db, void* stream);
+
+/* ---- per-sample normalisation: nn.InstanceNorm3d(1, eps=1e-3, affine=True) on x.unsqueeze(1)
+ *      (models/networks.py:159,166-169) = LayerNorm over (C,H,W) with scalar gamma/beta.
+ * stats: per-sample sum / sum of squares (double, caller zero-initialises `sums` [N][2]).
+ * finalize: mr[N][2] = (mean, rstd);  aff[N][2] = (gamma*rstd, beta - gamma*mean*rstd).            */
+int pg_norm_stats(const float* y, int32_t N, int64_t L, double* sums, void* stream);
+int pg_norm_finalize(const double* sums, const float* gamma, const float* beta, int32_t N, int64_t L,
+                     float eps, float* mr, float* aff, void* stream);
+/* backward: bsums[N][2] += (sum dz, sum dz*zhat) (caller zero-initialises);
+ * apply: dz <- dy = gamma*rstd*(dz - mean(dz) - zhat*mean(dz*zhat)) in place; dgamma/dbeta accumulated. */
+int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t N, int64_t L,
+                       double* bsums, void* stream);
+int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
+                      int32_t N, int64_t L, float* dgamma, float* dbeta, void* stream);
+
+/* ---- deformable skip connection (utils/pose_transform.py:16-92)
+ * mask pyramid: cv2.resize(mask_HWT,(w,h)) INTER_LINEAR (pose_transform.py:84-87) on device.
+ *   masks [N][T][H0][W0] (float32, or float64 when is_f64) -> out [N][h][w][T] float32.            */
+int pg_mask_pyramid(const void* masks, int32_t is_f64, int32_t N, int32_t T, int32_t H0, int32_t W0,
+                    int32_t h, int32_t w, float* out, void* stream);
+/* fused affine_grid + grid_sample(bilinear, zeros) + mask multiply + max over T
+ * (pose_transform.py:20-46,69-92).  feat raw NHWC [N][h][w][C] with optional deferred-norm `aff`;
+ * warps [N][T][8]; lvl_masks [N][h][w][T]; out NHWC; argmax [N][h][w][C] uint8 (255 = a masked-out 0 won). */
+int pg_warp_mask_max_fwd(const float* feat, const float* aff, const float* warps, const float* lvl_masks,
+                         int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
+                         int32_t align_corners, float* out, uint8_t* argmax, void* stream);
+/* gradient wrt the (post-affine) features: dfeat += scatter(gout * mask[t*] * bilinear weights). */
+int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, const float* warps, const float* lvl_masks,
+                         int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
+                         int32_t align_corners, float* dfeat, void* stream);
+
+/* ---- losses (models/pose_gan.py)
+ * GAN log loss on D logits [rows][K] (sigmoid fused; pose_gan.py:90-98,140-160):
+ *   mode 0: -log(sigmoid(x)+1e-7) (real / generator), mode 1: -log(1-sigmoid(x)+1e-7) (fake);
+ *   *loss += scale * sum; dlogits = scale * d/dx (NULL to skip); sig = sigmoid(x) (NULL to skip).   */
+int pg_gan_logloss(const float* logits, int64_t count, int32_t mode, float scale, float* loss,
+                   float* dlogits, float* sig, void* stream);
+/* nn.L1Loss (pose_gan.py:66,105): *loss += scale*sum|p-t|; gout (+)= scale*sign(p-t).              */
+int pg_l1_loss(const float* pred, const float* target, int64_t count, float scale, float* loss,
+               float* gout, int32_t accumulate, void* stream);
+/* d(pre-tanh) = g * (1 - out^2), in place on g (autograd of nn.Tanh, models/networks.py:232).      */
+int pg_tanh_bwd(float* g, const float* out, int64_t count, void* stream);
+/* Feature_Extractor(vgg19,'block1_conv2') = ReLU(conv1_1(prep(x))) with the view-not-permute
+ * pre-process (utils/pose_utils.py:312-338).  x NCHW [N][3][H][W]; w [64][3][3][3]; feat NHWC [N][H][W][64]. */
+int pg_vgg_conv1_relu_fwd(const float* x, const float* w, const float* b, int32_t N, int32_t H, int32_t W,
+                          float* feat, void* stream);
+/* gout[N][3][H][W] += d/dx of the above given dfeat (already masked by feat>0). */
+int pg_vgg_conv1_dgrad(const float* dfeat, const float* w, int32_t N, int32_t H, int32_t W, float* gout,
+                       void* stream);
+/* nearest-neighbour L1 loss (pose_gan.py:173-199) on NHWC features [N][H][W][C], C%4==0, C<=256:
+ *   *loss += scale * sum_pixels min_{|dy|,|dx|<=area/2} sum_c |G[p+d]-P[p]|;
+ *   dP = scale * sign(P-G*) * (P>0 if relu_mask) at the arg-min offset.                             */
+int pg_nn_loss(const float* P, const float* G, int32_t N, int32_t H, int32_t W, int32_t C, int32_t area,
+               float scale, int32_t relu_mask, float* loss, float* dP, void* stream);
+
+/* ---- optimiser / misc
+ * torch.optim.Adam(betas=(b1,b2), eps) single fused step over a flat arena (pose_gan.py:50-51,111,167);
+ * step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) computed by the host in double.                  */
+int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float b1, float b2, float eps,
+            float step_size, float bc2_sqrt, float grad_scale, void* stream);
+/* channel-dropout multipliers in {0, 1/(1-p)} from a stateless counter hash (nn.Dropout2d, networks.py:161). */
+int pg_dropout_mask(float* out, int64_t n, uint64_t key, float p, void* stream);
+int pg_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int pg_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* y = act((a_n*x+b_n)*mask): materialise a deferred-norm tensor (module-level API / tests only).   */
+int pg_apply_affine_act(const float* x, const float* aff, const float* mask, int32_t act, int32_t N,
+                        int64_t HW, int32_t C, float* y, void* stream);
+
+const char* pg_last_error(void);
+int pg_version(void);
+/* timing helper for bench.py: HIP events on the caller's stream (torch.cuda.Event sees only torch's). */
+int pg_event_create(void** ev);
+int pg_event_record(void* ev, void* stream);
+int pg_event_elapsed_ms(void* start, void* stop, float* ms);  /* synchronises on `stop` */
+int pg_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEGAN_HIP_H */

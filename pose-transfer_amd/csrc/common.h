@@ -1,0 +1,74 @@
+// Shared helpers for libposegan_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "posegan_hip.h"
+
+namespace pg {
+
+char* err_buf();  // thread-local 512-byte message buffer (api.hip)
+
+#define PG_FAIL(code, ...)                          \
+  do {                                              \
+    snprintf(pg::err_buf(), 512, __VA_ARGS__);      \
+    return (code);                                  \
+  } while (0)
+
+#define PG_REQUIRE(cond, ...)                       \
+  do {                                              \
+    if (!(cond)) PG_FAIL(1, __VA_ARGS__);           \
+  } while (0)
+
+#define PG_LAUNCH_OK(what)                                                        \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) PG_FAIL(2, "%s: %s", what, hipGetErrorString(e__));    \
+  } while (0)
+
+#define PG_HIP(call)                                                              \
+  do {                                                                            \
+    hipError_t e__ = (call);                                                      \
+    if (e__ != hipSuccess) PG_FAIL(3, "%s: %s", #call, hipGetErrorString(e__));   \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// wave-level (64 lanes) sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-level sum of `v` over 256 threads; result valid in thread 0. `red` = 4-float LDS scratch.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == PG_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == PG_ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == PG_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == PG_ACT_LEAKY) return z > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+}  // namespace pg

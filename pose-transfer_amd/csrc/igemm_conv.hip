@@ -1,0 +1,499 @@
+// Implicit-GEMM convolution for gfx950, fp32 MFMA (v_mfma_f32_32x32x2_f32: exact f32, 157 TF peak).
+//
+// One kernel family covers every data-path contraction of the Deformable-GAN step:
+//   "down" : nn.Conv2d forward (reference models/networks.py:154,186,228,341) and the data-gradient of
+//            nn.ConvTranspose2d(k4,s2)+Cropping2D(1) (networks.py:156-157)
+//   "up"   : nn.ConvTranspose2d(k4,s2)+crop forward, as stride^2 sub-pixel phases (each a 2x2 conv), and the
+//            data-gradient of nn.Conv2d.
+// GEMM view: C[M = N*Gy*Gx pixels][Ngemm = channels out] = A[M][K = taps*channels in] * B[K][Ngemm].
+//   A is gathered on the fly from up to 4 NHWC sources (the reference's torch.cat is never materialised) with the
+//   producer's deferred per-sample norm (a_n*x+b_n), channel-dropout mask and activation fused into the load;
+//   B is the packed weight [KH][KW][Cout][Cin], read k-contiguous (forward) or n-contiguous (data-gradient).
+// Tiling: 256 threads = 4 waves; block tile BMxBNx32; each wave owns (BM/WGM)x(BN/WGN) as 32x32 MFMA tiles.
+//   LDS tiles are K-major ([k][m], [k][n]) so that an MFMA operand fetch is one conflict-free ds_read_b32 per lane.
+//   Global->register prefetch of tile t+1 overlaps the 16 MFMA k-steps of tile t (64 cycles each per SIMD).
+// Split-K (atomic accumulate) fills the 256 CUs on the deep, small-M layers.
+#include "common.h"
+
+namespace pg {
+
+constexpr int BK = 32;
+constexpr int MAXTAP = 16;
+enum { A_VEC = 0, A_SCALAR = 1 };
+enum { B_NT = 0, B_NN = 1, B_SCALAR = 2 };
+
+struct ConvK {
+  pg_src_t src[PG_MAX_SRC];
+  int nsrc, Ctot;
+  int cstart[PG_MAX_SRC + 1];
+  int N, Hi, Wi, act;
+  int Gy, Gx, so, si, Ho, Wo, M;
+  int nphase;
+  int phy[4], phx[4], ntap[4];
+  signed char dy[4][MAXTAP], dx[4][MAXTAP];
+  unsigned char wtap[4][MAXTAP];
+  const float* W;
+  int wCout, wCin, w_transposed, n_off, n_cnt;
+  int ksplit;
+  int epilogue, out_act;
+  float* out;
+  const float* bias;
+  long oN, oC, oH, oW;
+  pg_dst_t dst[PG_MAX_SRC];
+  int ndst;
+  int dstart[PG_MAX_SRC + 1];
+};
+
+struct RowInfo {   // per M-row of the block tile, built once in LDS
+  int n;           // sample index, -1 = row outside the problem
+  int iy, ix;      // input base coordinate (q*si)
+  int pix;         // n*Ho*Wo + oy*Wo + ox
+  long off;        // n*oN + oy*oH + ox*oW
+};
+
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int AS = BM + ((AMODE == A_VEC) ? 1 : 1);
+  constexpr int BS = BN + ((BMODE == B_NN) ? 4 : 1);
+  constexpr int A_ROWS = BM / 32;          // rows per thread in vec mode
+  constexpr int B_ROWS = BN / 32;          // NT: rows per thread
+  constexpr int NN_CPR = BN / 4;           // NN: float4 chunks per k-row
+  constexpr int NN_PASS = 32 / (256 / NN_CPR);
+  constexpr int AS_CNT = 32 / (256 / BM);  // scalar-A elements per thread
+  constexpr int BS_CNT = BN / 8;           // scalar-B elements per thread
+
+  __shared__ __attribute__((aligned(16))) float smem[BK * AS + BK * BS + BM * (sizeof(RowInfo) / 4)];
+  float* As = smem;
+  float* Bs = smem + BK * AS;
+  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + BK * AS + BK * BS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int phase = blockIdx.z / p.ksplit;
+  const int split = blockIdx.z - phase * p.ksplit;
+  const int m0 = blockIdx.x * BM;
+  const int nb0 = blockIdx.y * BN;
+  const int ntap = p.ntap[phase];
+
+  if (tid < BM) {
+    RowInfo ri;
+    const int m = m0 + tid;
+    ri.n = -1; ri.iy = 0; ri.ix = 0; ri.pix = 0; ri.off = 0;
+    if (m < p.M) {
+      const int gg = p.Gy * p.Gx;
+      const int n = m / gg;
+      const int rem = m - n * gg;
+      const int qy = rem / p.Gx;
+      const int qx = rem - qy * p.Gx;
+      const int oy = qy * p.so + p.phy[phase];
+      const int ox = qx * p.so + p.phx[phase];
+      if (oy < p.Ho && ox < p.Wo) {
+        ri.n = n;
+        ri.iy = qy * p.si;
+        ri.ix = qx * p.si;
+        ri.pix = (n * p.Ho + oy) * p.Wo + ox;
+        ri.off = (long)n * p.oN + (long)oy * p.oH + (long)ox * p.oW;
+      }
+    }
+    rows[tid] = ri;
+  }
+  __syncthreads();
+
+  // K range of this block
+  const int ktot = (AMODE == A_VEC) ? ntap * (p.Ctot / BK) : (ntap * p.Ctot + BK - 1) / BK;
+  const int kper = (ktot + p.ksplit - 1) / p.ksplit;
+  const int kt0 = split * kper;
+  const int kt1 = min(ktot, kt0 + kper);
+  const int cpt = p.Ctot / BK;  // chunks per tap (vec mode)
+
+  // ---- per-thread loader state
+  int a_n[A_ROWS], a_iy[A_ROWS], a_ix[A_ROWS];
+  if (AMODE == A_VEC) {
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const RowInfo& r = rows[(tid >> 3) + 32 * i];
+      a_n[i] = r.n; a_iy[i] = r.iy; a_ix[i] = r.ix;
+    }
+  }
+  const int s_row = tid % BM;       // scalar-A mapping
+  const int s_ksub = tid / BM;
+  int s_n = 0, s_iy = 0, s_ix = 0;
+  if (AMODE == A_SCALAR) { s_n = rows[s_row].n; s_iy = rows[s_row].iy; s_ix = rows[s_row].ix; }
+
+  // prefetch registers
+  float4 ra[A_ROWS];
+  float4 rmask[A_ROWS];
+  float raa[A_ROWS], rab[A_ROWS];
+  unsigned a_ok = 0;
+  bool a_has_mask = false;
+  float rs[AS_CNT];
+  float4 rb[(BMODE == B_NT) ? B_ROWS : (BMODE == B_NN ? NN_PASS : 1)];
+  float rbs[BS_CNT];
+
+  auto load_tile = [&](int kt) {
+    // ------------------------------------------------ A operand
+    if (AMODE == A_VEC) {
+      const int tap = kt / cpt;
+      const int cc = (kt - tap * cpt) * BK;
+      int j = 0;
+#pragma unroll
+      for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && cc >= p.cstart[q]) j = q;
+      const pg_src_t& s = p.src[j];
+      const int cl = cc - p.cstart[j] + (tid & 7) * 4;
+      const int dyv = p.dy[phase][tap], dxv = p.dx[phase][tap];
+      a_ok = 0;
+      a_has_mask = (s.mask != nullptr);
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
+        const bool ok = a_n[i] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        raa[i] = 1.f; rab[i] = 0.f;
+        rmask[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ok) {
+          a_ok |= (1u << i);
+          const long idx = (((long)a_n[i] * p.Hi + iy) * p.Wi + ix) * s.C + cl;
+          ra[i] = *reinterpret_cast<const float4*>(s.ptr + idx);
+          if (s.aff) { raa[i] = s.aff[2 * a_n[i]]; rab[i] = s.aff[2 * a_n[i] + 1]; }
+          if (s.mask) rmask[i] = *reinterpret_cast<const float4*>(s.mask + (long)a_n[i] * s.C + cl);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < AS_CNT; ++e) {
+        const int kk = s_ksub + e * (256 / BM);
+        const int k = kt * BK + kk;
+        float v = 0.f;
+        if (k < ntap * p.Ctot && s_n >= 0) {
+          const int tap = k / p.Ctot;
+          const int c = k - tap * p.Ctot;
+          int j = 0;
+#pragma unroll
+          for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && c >= p.cstart[q]) j = q;
+          const pg_src_t& s = p.src[j];
+          const int iy = s_iy + p.dy[phase][tap], ix = s_ix + p.dx[phase][tap];
+          if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+            v = s.ptr[(long)s_n * s.sN + (long)(c - p.cstart[j]) * s.sC + (long)iy * s.sH + (long)ix * s.sW];
+        }
+        rs[e] = v;
+      }
+    }
+    // ------------------------------------------------ B operand
+    if (BMODE == B_NT) {
+      const int tap = kt / cpt;
+      const int cc = (kt - tap * cpt) * BK + (tid & 7) * 4;
+      const long base = (long)p.wtap[phase][tap] * p.wCout;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int n = nb0 + (tid >> 3) + 32 * i;
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(p.W + (base + p.n_off + n) * p.wCin + cc);
+      }
+    } else if (BMODE == B_NN) {
+      const int tap = kt / cpt;
+      const int cc = (kt - tap * cpt) * BK;
+      const long base = (long)p.wtap[phase][tap] * p.wCout;
+#pragma unroll
+      for (int i = 0; i < NN_PASS; ++i) {
+        const int kr = tid / NN_CPR + i * (256 / NN_CPR);
+        const int n = nb0 + (tid % NN_CPR) * 4;
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(p.W + (base + cc + kr) * p.wCin + p.n_off + n);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < BS_CNT; ++e) {
+        int kk, nl;
+        if (p.w_transposed) { nl = tid % BN; kk = tid / BN + e * (256 / BN); }
+        else { kk = tid & 31; nl = (tid >> 5) + 8 * e; }
+        int tap, c; bool kval;
+        if (AMODE == A_VEC) { tap = kt / cpt; c = (kt - tap * cpt) * BK + kk; kval = true; }
+        else { const int k = kt * BK + kk; tap = k / p.Ctot; c = k - tap * p.Ctot; kval = k < ntap * p.Ctot; }
+        float v = 0.f;
+        const int n = nb0 + nl;
+        if (kval && n < p.n_cnt) {
+          const long base = (long)p.wtap[phase][tap] * p.wCout;
+          v = p.w_transposed ? p.W[(base + c) * p.wCin + p.n_off + n] : p.W[(base + p.n_off + n) * p.wCin + c];
+        }
+        rbs[e] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+    if (AMODE == A_VEC) {
+      const int kq = (tid & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        const float mk[4] = {rmask[i].x, rmask[i].y, rmask[i].z, rmask[i].w};
+        const bool ok = (a_ok >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = v[e] * raa[i] + rab[i];
+          if (a_has_mask) t *= mk[e];
+          t = apply_act(t, p.act);
+          As[(kq + e) * AS + (tid >> 3) + 32 * i] = ok ? t : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < AS_CNT; ++e) As[(s_ksub + e * (256 / BM)) * AS + s_row] = rs[e];
+    }
+    if (BMODE == B_NT) {
+      const int kq = (tid & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int nl = (tid >> 3) + 32 * i;
+        Bs[(kq + 0) * BS + nl] = rb[i].x;
+        Bs[(kq + 1) * BS + nl] = rb[i].y;
+        Bs[(kq + 2) * BS + nl] = rb[i].z;
+        Bs[(kq + 3) * BS + nl] = rb[i].w;
+      }
+    } else if (BMODE == B_NN) {
+#pragma unroll
+      for (int i = 0; i < NN_PASS; ++i) {
+        const int kr = tid / NN_CPR + i * (256 / NN_CPR);
+        *reinterpret_cast<float4*>(&Bs[kr * BS + (tid % NN_CPR) * 4]) = rb[i];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < BS_CNT; ++e) {
+        int kk, nl;
+        if (p.w_transposed) { nl = tid % BN; kk = tid / BN + e * (256 / BN); }
+        else { kk = tid & 31; nl = (tid >> 5) + 8 * e; }
+        Bs[kk * BS + nl] = rbs[e];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm0 = (wave / WGN) * (TM * 32);
+  const int wn0 = (wave % WGN) * (TN * 32);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  if (kt0 < kt1) load_tile(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt1) load_tile(kt + 1);
+#pragma unroll 4
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(kk + lhi) * AS + wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lhi) * BS + wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (kt0 >= kt1) return;   // empty split: contributes nothing
+
+  // ------------------------------------------------------------------ epilogue
+  const bool atomic = p.ksplit > 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const RowInfo ri = rows[row];
+      if (ri.n < 0) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ng = nb0 + wn0 + j * 32 + l31;
+        if (ng >= p.n_cnt) continue;
+        float g = acc[i][j][r];
+        if (p.epilogue == 0) {
+          if (p.bias && split == 0) g += p.bias[ng];
+          if (p.out_act == PG_OUT_TANH) g = tanhf(g);
+          float* o = p.out + ri.off + (long)ng * p.oC;
+          if (atomic) atomicAdd(o, g); else *o = g;
+        } else {
+          int d = 0;
+#pragma unroll
+          for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.ndst && ng >= p.dstart[q]) d = q;
+          const pg_dst_t& ds = p.dst[d];
+          const int c = ng - p.dstart[d];
+          const long idx = (long)ri.pix * ds.C + c;
+          const float mk = ds.mask ? ds.mask[(long)ri.n * ds.C + c] : 1.f;
+          if (ds.fwd) {
+            float z = ds.fwd[idx];
+            if (ds.aff) z = z * ds.aff[2 * ri.n] + ds.aff[2 * ri.n + 1];
+            g *= act_grad(z * mk, ds.act);
+          }
+          g *= mk;
+          if (atomic) atomicAdd(ds.grad + idx, g);
+          else if (ds.accumulate) ds.grad[idx] += g;
+          else ds.grad[idx] = g;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- host side
+template <int BM, int BN, int WGM, int WGN>
+static void launch_cfg(const ConvK& k, int amode, int bmode, dim3 grid, hipStream_t st) {
+#define PG_LAUNCH(A, B) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B>), grid, dim3(256), 0, st, k)
+  if (amode == A_VEC && bmode == B_NT) PG_LAUNCH(A_VEC, B_NT);
+  else if (amode == A_VEC && bmode == B_NN) PG_LAUNCH(A_VEC, B_NN);
+  else if (amode == A_VEC && bmode == B_SCALAR) PG_LAUNCH(A_VEC, B_SCALAR);
+  else PG_LAUNCH(A_SCALAR, B_SCALAR);
+#undef PG_LAUNCH
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PG_REQUIRE(d != nullptr, "pg_conv: null descriptor");
+  PG_REQUIRE(d->nsrc >= 1 && d->nsrc <= PG_MAX_SRC, "pg_conv: nsrc=%d", d->nsrc);
+  PG_REQUIRE(d->KH * d->KW <= MAXTAP && d->stride >= 1 && d->stride <= 2, "pg_conv: unsupported kernel %dx%d s%d",
+             d->KH, d->KW, d->stride);
+  ConvK k;
+  memset(&k, 0, sizeof(k));
+  k.nsrc = d->nsrc;
+  int ctot = 0;
+  for (int j = 0; j < d->nsrc; ++j) {
+    k.src[j] = d->src[j];
+    k.cstart[j] = ctot;
+    ctot += d->src[j].C;
+    PG_REQUIRE(d->src[j].ptr != nullptr, "pg_conv: src[%d] null", j);
+  }
+  for (int j = d->nsrc; j <= PG_MAX_SRC; ++j) k.cstart[j] = ctot;
+  k.Ctot = ctot;
+  k.N = d->N; k.Hi = d->Hi; k.Wi = d->Wi; k.act = d->act;
+  k.Ho = d->Ho; k.Wo = d->Wo;
+  k.W = d->W; k.wCout = d->wCout; k.wCin = d->wCin; k.w_transposed = d->w_transposed;
+  const int nfull = d->w_transposed ? d->wCin : d->wCout;
+  const int kfull = d->w_transposed ? d->wCout : d->wCin;
+  PG_REQUIRE(kfull == ctot, "pg_conv: operand channels %d != weight K dim %d", ctot, kfull);
+  k.n_off = d->n_off;
+  k.n_cnt = d->n_cnt > 0 ? d->n_cnt : nfull;
+  PG_REQUIRE(k.n_off >= 0 && k.n_off + k.n_cnt <= nfull, "pg_conv: bad N sub-range");
+  k.epilogue = d->epilogue; k.out_act = d->out_act; k.out = d->out; k.bias = d->bias;
+  k.oN = d->oN; k.oC = d->oC; k.oH = d->oH; k.oW = d->oW;
+  // ---- tap tables
+  if (d->mode == 0) {
+    k.nphase = 1; k.so = 1; k.si = d->stride; k.Gy = d->Ho; k.Gx = d->Wo;
+    int t = 0;
+    for (int r = 0; r < d->KH; ++r)
+      for (int s = 0; s < d->KW; ++s) {
+        k.dy[0][t] = (signed char)(r - d->pad); k.dx[0][t] = (signed char)(s - d->pad);
+        k.wtap[0][t] = (unsigned char)(r * d->KW + s); ++t;
+      }
+    k.ntap[0] = t;
+  } else {
+    const int S = d->stride;
+    k.nphase = S * S; k.so = S; k.si = 1;
+    k.Gy = (d->Ho + S - 1) / S; k.Gx = (d->Wo + S - 1) / S;
+    for (int py = 0; py < S; ++py)
+      for (int px = 0; px < S; ++px) {
+        const int ph = py * S + px;
+        k.phy[ph] = py; k.phx[ph] = px;
+        int t = 0;
+        for (int r = 0; r < d->KH; ++r) {
+          if ((((py + d->pad - r) % S) + S) % S != 0) continue;
+          for (int s = 0; s < d->KW; ++s) {
+            if ((((px + d->pad - s) % S) + S) % S != 0) continue;
+            k.dy[ph][t] = (signed char)((py + d->pad - r) / S); k.dx[ph][t] = (signed char)((px + d->pad - s) / S);
+            k.wtap[ph][t] = (unsigned char)(r * d->KW + s); ++t;
+          }
+        }
+        k.ntap[ph] = t;
+      }
+  }
+  k.M = d->N * k.Gy * k.Gx;
+  PG_REQUIRE(k.M > 0, "pg_conv: empty problem");
+  // ---- epilogue destinations
+  k.ndst = d->ndst;
+  if (d->epilogue == 1) {
+    PG_REQUIRE(d->ndst >= 1 && d->ndst <= PG_MAX_SRC, "pg_conv: ndst=%d", d->ndst);
+    int c = 0;
+    for (int j = 0; j < d->ndst; ++j) { k.dst[j] = d->dst[j]; k.dstart[j] = c; c += d->dst[j].C; }
+    for (int j = d->ndst; j <= PG_MAX_SRC; ++j) k.dstart[j] = c;
+    PG_REQUIRE(c == k.n_cnt, "pg_conv: dst channels %d != N %d", c, k.n_cnt);
+  } else {
+    PG_REQUIRE(d->out != nullptr, "pg_conv: out null");
+  }
+  // ---- loader modes
+  int amode = d->scalar_in ? A_SCALAR : A_VEC;
+  if (amode == A_VEC) {
+    for (int j = 0; j < d->nsrc; ++j)
+      PG_REQUIRE(d->src[j].C % BK == 0, "pg_conv: vec mode needs C%%32==0 (src %d has %d)", j, d->src[j].C);
+  }
+  int bmode;
+  const bool nvec_ok = (k.n_cnt % 4 == 0) && (k.n_off % 4 == 0);
+  if (amode == A_SCALAR) bmode = B_SCALAR;
+  else if (!d->w_transposed) bmode = B_NT;               // k contiguous: needs wCin%4 (true: Ctot%32==0)
+  else bmode = (nvec_ok && d->wCin % 4 == 0) ? B_NN : B_SCALAR;
+  // ---- tile config
+  int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
+  if (k.n_cnt <= 32) cfg = 3;
+  else if (k.M <= 64) cfg = 2;
+  else if (k.n_cnt % 128 == 0) cfg = 0;
+  else cfg = 1;
+  const int BMs[4] = {128, 128, 64, 128}, BNs[4] = {128, 64, 64, 32};
+  const int mt = cdiv(k.M, BMs[cfg]), nt = cdiv(k.n_cnt, BNs[cfg]);
+  // ---- split-K
+  int ktot_min = 1 << 30;
+  for (int ph = 0; ph < k.nphase; ++ph) {
+    const int kt = (amode == A_VEC) ? k.ntap[ph] * (ctot / BK) : cdiv((long)k.ntap[ph] * ctot, BK);
+    if (kt < ktot_min) ktot_min = kt;
+  }
+  int ks = d->ksplit;
+  if (ks <= 0) {
+    const long blocks = (long)mt * nt * k.nphase;
+    ks = 1;
+    if (blocks < 384) {
+      ks = (int)((512 + blocks - 1) / blocks);
+      const int kmax = ktot_min / 4 > 0 ? ktot_min / 4 : 1;
+      if (ks > kmax) ks = kmax;
+      if (ks > 64) ks = 64;
+    }
+  }
+  if (d->out_act != PG_OUT_NONE) ks = 1;
+  if (d->epilogue == 0) {   // split-K accumulates atomically into a zeroed, dense NHWC output only
+    const bool dense = d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
+                       d->oN == (long)d->Ho * d->Wo * k.n_cnt;
+    if (!dense) ks = 1;
+  }
+  if (ks < 1) ks = 1;
+  k.ksplit = ks;
+  if (ks > 1) {   // atomic accumulation needs zero-initialised destinations
+    if (d->epilogue == 0) {
+      PG_REQUIRE(d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
+                 d->oN == (long)d->Ho * d->Wo * k.n_cnt,
+                 "pg_conv: split-K needs a dense NHWC output");
+      PG_HIP(hipMemsetAsync(d->out, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * k.n_cnt, st));
+    } else {
+      for (int j = 0; j < d->ndst; ++j)
+        if (!d->dst[j].accumulate)
+          PG_HIP(hipMemsetAsync(d->dst[j].grad, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * d->dst[j].C, st));
+    }
+  }
+  dim3 grid(mt, nt, k.nphase * ks);
+  switch (cfg) {
+    case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, grid, st); break;
+    case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, grid, st); break;
+    case 2: launch_cfg<64, 64, 2, 2>(k, amode, bmode, grid, st); break;
+    default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, grid, st); break;
+  }
+  PG_LAUNCH_OK("pg_conv");
+  return 0;
+}

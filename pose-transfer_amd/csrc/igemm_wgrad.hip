@@ -1,0 +1,344 @@
+// Weight-gradient implicit GEMM for gfx950, fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   dW[r][s][co][ci] += sum_{n,qy,qx} dY[.., co] * X[.., ci]
+// where small pixel (qy,qx) pairs with large pixel (qy*stride + r - pad, qx*stride + s - pad): the same relation
+// as nn.Conv2d (X large, dY small; reference models/networks.py:154,186,228,341) and
+// nn.ConvTranspose2d(k4,s2)+Cropping2D(1) (X small, dY large; networks.py:156-157).
+// GEMM view per tap: C[M = Cout][N = Cin tile] = A^T[K = pixels][M] * B[K = pixels][N]; both operands are
+// pixel-major NHWC so a tile row is one contiguous float4 run (coalesced) and lands in the K-major LDS tile with a
+// single ds_write_b128.  X carries the forward prologue (deferred per-sample norm, dropout mask, activation) and
+// the virtual concat of up to 4 sources.  K is split across workgroups (float atomics into the zeroed dW).
+#include "common.h"
+
+namespace pg {
+
+constexpr int WBK = 32;
+
+struct WgradK {
+  pg_src_t src[PG_MAX_SRC];
+  int nsrc, Ctot;
+  int cstart[PG_MAX_SRC + 1];
+  int N, act;
+  const float* dY;
+  long yN, yC, yH, yW;
+  int Cout;
+  int x_is_large;
+  int Hs, Ws, Hl, Wl;
+  int KW, stride, pad;
+  float* dW;
+  int ksplit, Kpix, ntaps;
+};
+
+struct Pix { int n, sy, sx, ly, lx; bool lok; };
+
+__device__ __forceinline__ Pix decode_pix(const WgradK& p, int k, int r, int s) {
+  Pix q;
+  const int hw = p.Hs * p.Ws;
+  q.n = k / hw;
+  const int rem = k - q.n * hw;
+  q.sy = rem / p.Ws;
+  q.sx = rem - q.sy * p.Ws;
+  q.ly = q.sy * p.stride + r - p.pad;
+  q.lx = q.sx * p.stride + s - p.pad;
+  q.lok = q.ly >= 0 && q.ly < p.Hl && q.lx >= 0 && q.lx < p.Wl;
+  return q;
+}
+
+template <int BM, int BN, int WGM, int WGN, int WGK, int XS, int YS>
+__global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int AS = BM + (YS ? 1 : 4);
+  constexpr int BS = BN + (XS ? 1 : 4);
+  constexpr int A_CPR = BM / 4, A_PASS = (BM / 32 > 0) ? BM / 32 : 1;   // float4 chunks per pixel row / passes
+  constexpr int B_CPR = BN / 4, B_PASS = BN / 32;
+  constexpr int A_SC = BM / 8, B_SC = BN / 8;                            // scalar elements per thread
+  __shared__ __attribute__((aligned(16))) float smem[WBK * AS + WBK * BS];
+  float* As = smem;
+  float* Bs = smem + WBK * AS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tap = blockIdx.z / p.ksplit;
+  const int split = blockIdx.z - tap * p.ksplit;
+  const int r = tap / p.KW, s = tap - r * p.KW;
+  const int co0 = blockIdx.y * BM;
+  const int ci0 = blockIdx.x * BN;
+  const int nkt = (p.Kpix + WBK - 1) / WBK;
+  const int kper = (nkt + p.ksplit - 1) / p.ksplit;
+  const int kt0 = split * kper, kt1 = min(nkt, kt0 + kper);
+  if (kt0 >= kt1) return;
+
+  // source of this ci tile (vec mode: a tile never straddles sources)
+  int jsrc = 0;
+#pragma unroll
+  for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && ci0 >= p.cstart[q]) jsrc = q;
+
+  float4 ra[YS ? 1 : A_PASS];
+  float4 rb[XS ? 1 : B_PASS];
+  float4 rbm[XS ? 1 : B_PASS];
+  float rba[XS ? 1 : B_PASS], rbb[XS ? 1 : B_PASS];
+  unsigned b_ok = 0;
+  float ras[YS ? A_SC : 1];
+  float rbs[XS ? B_SC : 1];
+
+  auto load_tile = [&](int kt) {
+    // ---------------- A = dY  [pixel][co]
+    if (!YS) {
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) {
+        const int pr = tid / A_CPR + i * (256 / A_CPR);
+        const int k = kt * WBK + pr;
+        const int co = co0 + (tid % A_CPR) * 4;
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < p.Kpix && co < p.Cout) {
+          const Pix q = decode_pix(p, k, r, s);
+          if (p.x_is_large) ra[i] = *reinterpret_cast<const float4*>(p.dY + (((long)q.n * p.Hs + q.sy) * p.Ws + q.sx) * p.Cout + co);
+          else if (q.lok) ra[i] = *reinterpret_cast<const float4*>(p.dY + (((long)q.n * p.Hl + q.ly) * p.Wl + q.lx) * p.Cout + co);
+        }
+      }
+    } else {
+      const int pl = tid & 31;
+      const int k = kt * WBK + pl;
+      Pix q; q.n = -1;
+      if (k < p.Kpix) q = decode_pix(p, k, r, s);
+#pragma unroll
+      for (int e = 0; e < A_SC; ++e) {
+        const int co = co0 + (tid >> 5) + 8 * e;
+        float v = 0.f;
+        if (q.n >= 0 && co < p.Cout) {
+          if (p.x_is_large) v = p.dY[(long)q.n * p.yN + (long)co * p.yC + (long)q.sy * p.yH + (long)q.sx * p.yW];
+          else if (q.lok) v = p.dY[(long)q.n * p.yN + (long)co * p.yC + (long)q.ly * p.yH + (long)q.lx * p.yW];
+        }
+        ras[e] = v;
+      }
+    }
+    // ---------------- B = X  [pixel][ci]
+    if (!XS) {
+      const pg_src_t& sx = p.src[jsrc];
+      const int cl = ci0 - p.cstart[jsrc] + (tid % B_CPR) * 4;
+      b_ok = 0;
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) {
+        const int pr = tid / B_CPR + i * (256 / B_CPR);
+        const int k = kt * WBK + pr;
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rbm[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        rba[i] = 1.f; rbb[i] = 0.f;
+        if (k < p.Kpix) {
+          const Pix q = decode_pix(p, k, r, s);
+          const bool ok = p.x_is_large ? q.lok : true;
+          if (ok) {
+            b_ok |= 1u << i;
+            const long pixidx = p.x_is_large ? (((long)q.n * p.Hl + q.ly) * p.Wl + q.lx)
+                                             : (((long)q.n * p.Hs + q.sy) * p.Ws + q.sx);
+            rb[i] = *reinterpret_cast<const float4*>(sx.ptr + pixidx * sx.C + cl);
+            if (sx.aff) { rba[i] = sx.aff[2 * q.n]; rbb[i] = sx.aff[2 * q.n + 1]; }
+            if (sx.mask) rbm[i] = *reinterpret_cast<const float4*>(sx.mask + (long)q.n * sx.C + cl);
+          }
+        }
+      }
+    } else {
+      const int pl = tid & 31;
+      const int k = kt * WBK + pl;
+      Pix q; q.n = -1;
+      if (k < p.Kpix) q = decode_pix(p, k, r, s);
+#pragma unroll
+      for (int e = 0; e < B_SC; ++e) {
+        const int ci = ci0 + (tid >> 5) + 8 * e;
+        float v = 0.f;
+        if (q.n >= 0 && ci < p.Ctot) {
+          int j = 0;
+#pragma unroll
+          for (int t = 1; t < PG_MAX_SRC; ++t) if (t < p.nsrc && ci >= p.cstart[t]) j = t;
+          const pg_src_t& sx = p.src[j];
+          const long cbase = (long)q.n * sx.sN + (long)(ci - p.cstart[j]) * sx.sC;
+          if (p.x_is_large) { if (q.lok) v = sx.ptr[cbase + (long)q.ly * sx.sH + (long)q.lx * sx.sW]; }
+          else v = sx.ptr[cbase + (long)q.sy * sx.sH + (long)q.sx * sx.sW];
+        }
+        rbs[e] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+    if (!YS) {
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) {
+        const int pr = tid / A_CPR + i * (256 / A_CPR);
+        *reinterpret_cast<float4*>(&As[pr * AS + (tid % A_CPR) * 4]) = ra[i];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < A_SC; ++e) As[(tid & 31) * AS + (tid >> 5) + 8 * e] = ras[e];
+    }
+    if (!XS) {
+      const pg_src_t& sx = p.src[jsrc];
+      const bool hm = sx.mask != nullptr;
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) {
+        const int pr = tid / B_CPR + i * (256 / B_CPR);
+        const bool ok = (b_ok >> i) & 1u;
+        float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+        const float mk[4] = {rbm[i].x, rbm[i].y, rbm[i].z, rbm[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = v[e] * rba[i] + rbb[i];
+          if (hm) t *= mk[e];
+          t = apply_act(t, p.act);
+          v[e] = ok ? t : 0.f;
+        }
+        *reinterpret_cast<float4*>(&Bs[pr * BS + (tid % B_CPR) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < B_SC; ++e) Bs[(tid & 31) * BS + (tid >> 5) + 8 * e] = rbs[e];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const int wk = wave / (WGM * WGN);
+  const int wmn = wave - wk * (WGM * WGN);
+  const int wm0 = (wmn / WGN) * (TM * 32);
+  const int wn0 = (wmn % WGN) * (TN * 32);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  constexpr int KSPAN = WBK / WGK;
+
+  load_tile(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt1) load_tile(kt + 1);
+#pragma unroll 4
+    for (int kk = wk * KSPAN; kk < (wk + 1) * KSPAN; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(kk + lhi) * AS + wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lhi) * BS + wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const bool atomic = (p.ksplit > 1) || (WGK > 1);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = co0 + wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + wn0 + j * 32 + l31;
+        if (ci >= p.Ctot) continue;
+        float* o = p.dW + ((long)tap * p.Cout + co) * p.Ctot + ci;
+        if (atomic) atomicAdd(o, acc[i][j][q]); else *o += acc[i][j][q];
+      }
+    }
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PG_REQUIRE(d != nullptr, "pg_conv_wgrad: null descriptor");
+  PG_REQUIRE(d->nsrc >= 1 && d->nsrc <= PG_MAX_SRC, "pg_conv_wgrad: nsrc=%d", d->nsrc);
+  WgradK k;
+  memset(&k, 0, sizeof(k));
+  k.nsrc = d->nsrc;
+  int ctot = 0;
+  for (int j = 0; j < d->nsrc; ++j) { k.src[j] = d->src[j]; k.cstart[j] = ctot; ctot += d->src[j].C; }
+  for (int j = d->nsrc; j <= PG_MAX_SRC; ++j) k.cstart[j] = ctot;
+  k.Ctot = ctot;
+  PG_REQUIRE(ctot == d->Cin, "pg_conv_wgrad: sources have %d channels, Cin=%d", ctot, d->Cin);
+  k.N = d->N; k.act = d->act; k.dY = d->dY;
+  k.yN = d->yN; k.yC = d->yC; k.yH = d->yH; k.yW = d->yW;
+  k.Cout = d->Cout; k.x_is_large = d->x_is_large;
+  k.Hs = d->Hs; k.Ws = d->Ws; k.Hl = d->Hl; k.Wl = d->Wl;
+  k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dW = d->dW;
+  k.ntaps = d->KH * d->KW;
+  const long kp = (long)d->N * d->Hs * d->Ws;
+  PG_REQUIRE(kp > 0 && kp < (1L << 31), "pg_conv_wgrad: pixel count out of range");
+  k.Kpix = (int)kp;
+  const int xs = d->scalar_x ? 1 : 0, ys = d->scalar_y ? 1 : 0;
+  int cfg;  // 0: 128x64, 1: 64x64, 2: 32x64 (intra-block split-K)
+  if (ys || d->Cout <= 32) cfg = 2;
+  else if (d->Cout % 128 == 0) cfg = 0;
+  else cfg = 1;
+  if (!xs)
+    for (int j = 0; j < d->nsrc; ++j)
+      PG_REQUIRE(d->src[j].C % 64 == 0, "pg_conv_wgrad: vec X needs C%%64==0 (src %d has %d)", j, d->src[j].C);
+  if (!ys) PG_REQUIRE(d->Cout % 4 == 0, "pg_conv_wgrad: vec dY needs Cout%%4==0");
+  const int BMs[3] = {128, 64, 32};
+  const int mt = cdiv(d->Cout, BMs[cfg]), nt = cdiv(ctot, 64);
+  const int nkt = cdiv(kp, WBK);
+  int ks = d->ksplit;
+  if (ks <= 0) {
+    const long tiles = (long)mt * nt * k.ntaps;
+    ks = (int)((1024 + tiles - 1) / tiles);
+    const int kmax = nkt / 2 > 0 ? nkt / 2 : 1;
+    if (ks > kmax) ks = kmax;
+    if (ks > 512) ks = 512;
+    if (ks < 1) ks = 1;
+  }
+  k.ksplit = ks;
+  dim3 grid(nt, mt, k.ntaps * ks);
+#define PG_WG(BM, WGM, WGN, WGK, XS, YS) \
+  hipLaunchKernelGGL((wgrad_igemm_kernel<BM, 64, WGM, WGN, WGK, XS, YS>), grid, dim3(256), 0, st, k)
+  if (cfg == 0) {
+    PG_REQUIRE(!xs && !ys, "pg_conv_wgrad: scalar operands need Cout<=64");
+    PG_WG(128, 2, 2, 1, 0, 0);
+  } else if (cfg == 1) {
+    PG_REQUIRE(!ys, "pg_conv_wgrad: scalar dY needs Cout<=32");
+    if (xs) PG_WG(64, 2, 2, 1, 1, 0); else PG_WG(64, 2, 2, 1, 0, 0);
+  } else {
+    PG_REQUIRE(!xs, "pg_conv_wgrad: scalar X with Cout<=32 unsupported");
+    if (ys) PG_WG(32, 1, 2, 2, 0, 1); else PG_WG(32, 1, 2, 2, 0, 0);
+  }
+#undef PG_WG
+  PG_LAUNCH_OK("pg_conv_wgrad");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- bias gradient
+namespace pg {
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dY, long rows_outer, long rows_inner, int C,
+                                                        long s_outer, long s_inner, long sC, float* db) {
+  // grid.x = channel, grid.y = row slices; rows = rows_outer x rows_inner
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const long rows = rows_outer * rows_inner;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < rows; i += (long)gridDim.y * 256) {
+    const long o = i / rows_inner, in = i - o * rows_inner;
+    acc += dY[o * s_outer + in * s_inner + (long)c * sC];
+  }
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(db + c, t);
+}
+}  // namespace pg
+
+extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,
+                            int64_t s_inner, int64_t sC, float* db, void* stream) {
+  PG_REQUIRE(C > 0 && rows_outer > 0 && rows_inner > 0, "pg_bias_grad: empty");
+  const long rows = rows_outer * rows_inner;
+  int slices = (int)((rows + 256 * 16 - 1) / (256 * 16));
+  if (slices > 64) slices = 64;
+  if (slices < 1) slices = 1;
+  hipLaunchKernelGGL(pg::bias_grad_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, dY, (long)rows_outer,
+                     (long)rows_inner, C, (long)s_outer, (long)s_inner, (long)sC, db);
+  PG_LAUNCH_OK("pg_bias_grad");
+  return 0;
+}

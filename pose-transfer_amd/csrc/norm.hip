@@ -1,0 +1,155 @@
+// Per-sample normalisation kernels, gfx950.
+// Reference: nn.InstanceNorm3d(1, eps=1e-3, affine=True) applied on x.unsqueeze(1)
+// (models/networks.py:159,166-169) == LayerNorm over (C,H,W) per sample with ONE scalar gamma/beta.
+//
+// The normalisation itself is never materialised: `finalize` emits the per-sample affine (a_n, b_n) that consumers
+// (pg_conv / pg_conv_wgrad / pg_warp_mask_max_fwd prologues) apply on load.  These kernels are the HBM-bound
+// reductions around it: one read of the activation for the statistics; backward reads (dz, y) once for the two
+// per-sample sums and once more to rewrite dz -> dy in place.
+#include "common.h"
+
+namespace pg {
+
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* y, long L, double* sums) {
+  __shared__ double red[8];
+  const int n = blockIdx.y;
+  const float* b = y + (long)n * L;
+  float s = 0.f, q = 0.f;
+  const long L4 = L >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(b)[i];
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0)
+    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) { const float v = b[i]; s += v; q += v * v; }
+  double ds = wave_sum_d((double)s), dq = wave_sum_d((double)q);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[w] = ds; red[4 + w] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[2 * n], red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(&sums[2 * n + 1], red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+__global__ void norm_finalize_kernel(const double* sums, const float* gamma, const float* beta, int N, long L,
+                                     float eps, float* mr, float* aff) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double mean = sums[2 * n] / (double)L;
+  double var = sums[2 * n + 1] / (double)L - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double g = (double)gamma[0], b = (double)beta[0];
+  mr[2 * n] = (float)mean;
+  mr[2 * n + 1] = (float)rstd;
+  aff[2 * n] = (float)(g * rstd);
+  aff[2 * n + 1] = (float)(b - g * mean * rstd);
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* dz, const float* y, const float* mr, long L,
+                                                              double* bsums) {
+  __shared__ double red[8];
+  const int n = blockIdx.y;
+  const float mean = mr[2 * n], rstd = mr[2 * n + 1];
+  const float* bd = dz + (long)n * L;
+  const float* by = y + (long)n * L;
+  float s = 0.f, q = 0.f;
+  const long L4 = L >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L4; i += (long)gridDim.x * 256) {
+    const float4 d = reinterpret_cast<const float4*>(bd)[i];
+    const float4 v = reinterpret_cast<const float4*>(by)[i];
+    s += (d.x + d.y) + (d.z + d.w);
+    q += (d.x * ((v.x - mean) * rstd) + d.y * ((v.y - mean) * rstd)) +
+         (d.z * ((v.z - mean) * rstd) + d.w * ((v.w - mean) * rstd));
+  }
+  if (blockIdx.x == 0)
+    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) { s += bd[i]; q += bd[i] * ((by[i] - mean) * rstd); }
+  double ds = wave_sum_d((double)s), dq = wave_sum_d((double)q);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[w] = ds; red[4 + w] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&bsums[2 * n], red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(&bsums[2 * n + 1], red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* dz, const float* y, const float* mr,
+                                                             const double* bsums, const float* gamma, int N, long L,
+                                                             float* dgamma, float* dbeta) {
+  const int n = blockIdx.y;
+  const float mean = mr[2 * n], rstd = mr[2 * n + 1];
+  const float g = gamma[0];
+  const float m1 = (float)(bsums[2 * n] / (double)L);
+  const float m2 = (float)(bsums[2 * n + 1] / (double)L);
+  const float k = g * rstd;
+  float* bd = dz + (long)n * L;
+  const float* by = y + (long)n * L;
+  const long L4 = L >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L4; i += (long)gridDim.x * 256) {
+    float4 d = reinterpret_cast<float4*>(bd)[i];
+    const float4 v = reinterpret_cast<const float4*>(by)[i];
+    d.x = k * (d.x - m1 - ((v.x - mean) * rstd) * m2);
+    d.y = k * (d.y - m1 - ((v.y - mean) * rstd) * m2);
+    d.z = k * (d.z - m1 - ((v.z - mean) * rstd) * m2);
+    d.w = k * (d.w - m1 - ((v.w - mean) * rstd) * m2);
+    reinterpret_cast<float4*>(bd)[i] = d;
+  }
+  if (blockIdx.x == 0)
+    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256)
+      bd[i] = k * (bd[i] - m1 - ((by[i] - mean) * rstd) * m2);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    double sg = 0.0, sb = 0.0;
+    for (int i = 0; i < N; ++i) { sb += bsums[2 * i]; sg += bsums[2 * i + 1]; }
+    if (dgamma) atomicAdd(dgamma, (float)sg);
+    if (dbeta) atomicAdd(dbeta, (float)sb);
+  }
+}
+
+static int norm_blocks(long L) {
+  long b = (L / 4 + 256 * 8 - 1) / (256 * 8);
+  if (b < 1) b = 1;
+  if (b > 512) b = 512;
+  return (int)b;
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_norm_stats(const float* y, int32_t N, int64_t L, double* sums, void* stream) {
+  PG_REQUIRE(y && sums && N > 0 && L > 0, "pg_norm_stats: bad arguments");
+  PG_REQUIRE(L % 4 == 0, "pg_norm_stats: per-sample length must be a multiple of 4 (float4 path)");
+  hipLaunchKernelGGL(norm_stats_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, y, (long)L, sums);
+  PG_LAUNCH_OK("pg_norm_stats");
+  return 0;
+}
+
+extern "C" int pg_norm_finalize(const double* sums, const float* gamma, const float* beta, int32_t N, int64_t L,
+                                float eps, float* mr, float* aff, void* stream) {
+  PG_REQUIRE(sums && gamma && beta && mr && aff && N > 0, "pg_norm_finalize: bad arguments");
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, N,
+                     (long)L, eps, mr, aff);
+  PG_LAUNCH_OK("pg_norm_finalize");
+  return 0;
+}
+
+extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t N, int64_t L,
+                                  double* bsums, void* stream) {
+  PG_REQUIRE(dz && y && mr && bsums && N > 0 && L > 0 && L % 4 == 0, "pg_norm_bwd_reduce: bad arguments");
+  hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, dz, y, mr,
+                     (long)L, bsums);
+  PG_LAUNCH_OK("pg_norm_bwd_reduce");
+  return 0;
+}
+
+extern "C" int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
+                                 int32_t N, int64_t L, float* dgamma, float* dbeta, void* stream) {
+  PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0, "pg_norm_bwd_apply: bad arguments");
+  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, dz, y, mr,
+                     bsums, gamma, N, (long)L, dgamma, dbeta);
+  PG_LAUNCH_OK("pg_norm_bwd_apply");
+  return 0;
+}

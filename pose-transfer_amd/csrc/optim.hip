@@ -1,0 +1,139 @@
+// Optimiser and small utility kernels, gfx950 (all HBM-bound streaming kernels, float4 per lane).
+//  * adam: torch.optim.Adam(betas=(0.5,0.999), eps=1e-8) over a flat parameter arena (reference
+//    models/pose_gan.py:50-51,111,167): one launch for all 56 generator / 12 discriminator tensors.
+//    Algorithmic bytes: 7 streams x 4 B per parameter (read p,g,m,v; write p,m,v).
+//  * dropout_mask: channel-dropout multipliers (nn.Dropout2d, models/networks.py:161) from a stateless counter hash
+//    (same mixer as pose_transfer_amd/utils/synth.py, so the host can reproduce a mask bit-for-bit).
+#include "common.h"
+
+namespace pg {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float b1,
+                                                   float b2, float eps, float step_size, float bc2_sqrt,
+                                                   float grad_scale) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = ga[e] * grad_scale;
+      ma[e] = ma[e] * b1 + (1.f - b1) * gr;
+      va[e] = va[e] * b2 + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(va[e]) / bc2_sqrt + eps;
+      pa[e] = pa[e] - step_size * (ma[e] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+      const float gr = g[i] * grad_scale;
+      m[i] = m[i] * b1 + (1.f - b1) * gr;
+      v[i] = v[i] * b2 + (1.f - b2) * gr * gr;
+      p[i] = p[i] - step_size * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
+    }
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+
+__global__ void dropout_mask_kernel(float* out, long n, unsigned long long key, float p) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long bits = mix64((unsigned long long)i * 0xD1342543DE82EF95ULL + key);
+  const double u = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+  out[i] = ((float)u >= p) ? 1.f / (1.f - p) : 0.f;
+}
+
+// NCHW <-> NHWC through a 32x33 LDS tile: both sides coalesced.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* src, float* dst, int rows, int cols) {
+  // src: [batch][rows][cols] -> dst: [batch][cols][rows]
+  __shared__ float tile[32][33];
+  const long boff = (long)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < rows && c < cols) tile[k][tx] = src[boff + (long)r * cols + c];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (r < rows && c < cols) dst[boff + (long)c * rows + r] = tile[tx][k];
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* x, const float* aff, const float* mask, int act,
+                                                         long HW, int C, float* y) {
+  const int n = blockIdx.y;
+  const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
+  const long L = HW * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = x[(long)n * L + i] * a + b;
+    if (mask) v *= mask[(long)n * C + c];
+    y[(long)n * L + i] = apply_act(v, act);
+  }
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float b1, float b2, float eps,
+                       float step_size, float bc2_sqrt, float grad_scale, void* stream) {
+  PG_REQUIRE(p && g && m && v && n > 0, "pg_adam: bad arguments");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, b1, b2,
+                     eps, step_size, bc2_sqrt, grad_scale);
+  PG_LAUNCH_OK("pg_adam");
+  return 0;
+}
+
+extern "C" int pg_dropout_mask(float* out, int64_t n, uint64_t key, float p, void* stream) {
+  PG_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f, "pg_dropout_mask: bad arguments");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
+                     (unsigned long long)key, p);
+  PG_LAUNCH_OK("pg_dropout_mask");
+  return 0;
+}
+
+extern "C" int pg_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+  PG_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "pg_nchw_to_nhwc: bad arguments");
+  const int rows = C, cols = H * W;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, rows, cols);
+  PG_LAUNCH_OK("pg_nchw_to_nhwc");
+  return 0;
+}
+
+extern "C" int pg_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+  PG_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "pg_nhwc_to_nchw: bad arguments");
+  const int rows = H * W, cols = C;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, rows, cols);
+  PG_LAUNCH_OK("pg_nhwc_to_nchw");
+  return 0;
+}
+
+extern "C" int pg_apply_affine_act(const float* x, const float* aff, const float* mask, int32_t act, int32_t N,
+                                   int64_t HW, int32_t C, float* y, void* stream) {
+  PG_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "pg_apply_affine_act: bad arguments");
+  long blocks = (HW * C + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(affine_act_kernel, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
+                     (long)HW, C, y);
+  PG_LAUNCH_OK("pg_apply_affine_act");
+  return 0;
+}

@@ -1,0 +1,231 @@
+"""DeformablePose_GAN trainer with the reference's surface (reference src_deformable/models/pose_gan.py:11-220):
+``gen_update(input, target, other_inputs, opt) -> (out_gen, [], [total, ll, ad])`` and
+``dis_update(input, target, other_inputs, real_inp, real_target, opt) -> [total, true, fake]``.
+
+Differences from the reference, all result-preserving:
+  * ``dis_update`` does not back-propagate through the generator (bit-identical: those grads are zeroed
+    before use, pose_gan.py:70) and ``gen_update`` skips the discriminator's weight gradients;
+  * losses are reduced on the device; ``.item()`` happens once per call only when ``lazy_losses`` is off;
+  * data parallel: one process per GPU, gradients all-reduced (RCCL) in backward-ordered buckets while the
+    rest of the backward is still running (runtime/dp.py), then a single fused Adam launch per network.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from ..runtime import dp as DP
+from ..runtime import lib as L
+from ..utils import pose_utils, synth
+from .networks import Deformable_Generator, Discriminator, Generator, xavier_weights_init
+
+
+class FusedAdam:
+    """Stand-in for torch.optim.Adam(params, lr, betas=(0.5,0.999)) over a ParamArena (pose_gan.py:50-51)."""
+
+    def __init__(self, module, lr, betas=(0.5, 0.999), eps=1e-8):
+        self.module, self.lr, self.betas, self.eps = module, lr, betas, eps
+
+    def zero_grad(self):
+        self.module.arena.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        self.module.arena.adam_step(self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
+
+    def state_dict(self):
+        a = self.module.arena
+        return {"step": a.step, "exp_avg": a.m.clone(), "exp_avg_sq": a.v.clone()}
+
+
+class DeformablePose_GAN(nn.Module):
+    def __init__(self, opt, device="cuda", init_seed=0):
+        super().__init__()
+        # adding extra layers for larger image size — reference pose_gan.py:17-18
+        nfilters_encoder, nfilters_decoder = synth.nfilters(opt.image_size)
+        if not opt.use_input_pose:
+            raise Exception("use_input_pose=0 is not supported by the MI355X build")
+        input_nc = 3 + 2 * opt.pose_dim
+        self.batch_size = opt.batch_size
+        self.pose_dim = opt.pose_dim
+        self.image_size = tuple(opt.image_size)
+        self.device = device
+        self.deformable = getattr(opt, "warp_skip", "mask") == "mask"
+        if opt.gen_type == "baseline":
+            if self.deformable:
+                self.gen = Deformable_Generator(input_nc, self.pose_dim, opt.image_size, nfilters_encoder,
+                                                nfilters_decoder, "mask", use_input_pose=True,
+                                                align_corners=bool(getattr(opt, "align_corners", 0)), device=device)
+            else:   # src_baseline Pose_GAN (reference src_baseline/models/pose_gan.py:10-52)
+                self.gen = Generator(input_nc, nfilters_encoder, nfilters_decoder, pose_dim=self.pose_dim,
+                                     image_size=opt.image_size, device=device)
+        elif opt.gen_type == "stacked":
+            raise Exception("gen_type=stacked is out of scope for the MI355X build (SURVEY.md §8f #4)")
+        else:
+            raise Exception("Invalid gen_type")
+        self.disc = Discriminator(input_nc + 3, use_input_pose=True, image_size=opt.image_size, device=device)
+        # the reference loads a private pretrained discriminator unconditionally (pose_gan.py:40-42); here it is
+        # optional and the default is the reference's own init recipe (networks.py:26-31)
+        xavier_weights_init(self.gen, init_seed)
+        xavier_weights_init(self.disc, init_seed + 1)
+        pre = getattr(opt, "discriminator_checkpoint", None)
+        if pre:
+            self.disc.load_state_dict(torch.load(pre, map_location="cpu"))
+        pre = getattr(opt, "generator_checkpoint", None)
+        if pre:
+            self.gen.load_state_dict(torch.load(pre, map_location="cpu"))
+        lr = opt.learning_rate
+        self.disc_opt = FusedAdam(self.disc, lr)
+        self.gen_opt = FusedAdam(self.gen, lr)
+        self.content_loss_layer = opt.content_loss_layer
+        self.nn_loss_area_size = opt.nn_loss_area_size
+        self.vgg_w = self.vgg_b = None
+        if self.content_loss_layer != "none":
+            if pose_utils.get_layer_ind(self.content_loss_layer) != 1:
+                raise Exception("only content_loss_layer=block1_conv2 (vgg19.features[:2]) is implemented")
+            self.set_vgg_weights(*_default_vgg_conv1(getattr(opt, "vgg_weights", None)))
+        self.world = DP.world_size()
+        self.g_reducer = DP.GradReducer(self.gen.arena, self.world) if self.world > 1 else None
+        self.d_reducer = DP.GradReducer(self.disc.arena, self.world) if self.world > 1 else None
+        self._loss = torch.zeros(8, dtype=torch.float32, device=device)
+        self._bufs = {}
+
+    # ------------------------------------------------------------------------------------------
+    def set_vgg_weights(self, w, b):
+        self.vgg_w = w.to(self.device, torch.float32).contiguous()
+        self.vgg_b = b.to(self.device, torch.float32).contiguous()
+
+    def _buf(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        if key not in self._bufs:
+            self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.device)
+        return self._bufs[key]
+
+    def _gen_forward(self, input, other_inputs, drop_masks):
+        eng = self.gen.engine(input.shape[0])
+        eng.set_dropout(drop_masks, train=True, seed=int(os.environ.get("RANK", "0")))
+        if self.deformable:
+            return eng, eng.forward(input, other_inputs["warps"], other_inputs["masks"])
+        return eng, eng.forward(input)
+
+    def _losses(self, lo, lazy):
+        if lazy:
+            return self._loss[lo:lo + 3].clone()
+        return [float(v) for v in self._loss[lo:lo + 3].tolist()]
+
+    # ------------------------------------------------------------------------------------------
+    def gen_update(self, input, target, other_inputs, opt):
+        """reference pose_gan.py:69-115."""
+        n, (H, W) = input.shape[0], self.image_size
+        input, target = input.contiguous(), target.contiguous()
+        self.gen.zero_grad()
+        self._loss[0:3].zero_()
+        eng, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
+        # discriminator on [img, src_pose, out_gen, tgt_pose] — forward + data-gradient only
+        deng = self.disc.engine(n)
+        logits = deng.forward([(input, out_gen)])
+        dlog = self._buf("dlog_g", logits.shape)
+        K = logits.shape[1]
+        w_gan = float(opt["gan_penalty_weight"]) / self.batch_size
+        L.call("pg_gan_logloss", L.ptr(logits), logits.numel(), 0, w_gan / K, L.ptr(self._loss[2:]), L.ptr(dlog), None,
+               L.stream())
+        gout = self._buf("gout", out_gen.shape)
+        deng.backward(dlog, need_wgrad=False, image_grad=[gout])
+        l1w = float(opt["l1_penalty_weight"])
+        if self.content_loss_layer != "none":
+            fg = self._buf("feat_g", (n, H, W, 64))
+            ft = self._buf("feat_t", (n, H, W, 64))
+            L.call("pg_vgg_conv1_relu_fwd", L.ptr(out_gen), L.ptr(self.vgg_w), L.ptr(self.vgg_b), n, H, W, L.ptr(fg), L.stream())
+            L.call("pg_vgg_conv1_relu_fwd", L.ptr(target), L.ptr(self.vgg_w), L.ptr(self.vgg_b), n, H, W, L.ptr(ft), L.stream())
+            dfg = self._buf("dfeat_g", (n, H, W, 64))
+            L.call("pg_nn_loss", L.ptr(fg), L.ptr(ft), n, H, W, 64, int(self.nn_loss_area_size), l1w / (n * H * W), 1,
+                   L.ptr(self._loss[1:]), L.ptr(dfg), L.stream())
+            L.call("pg_vgg_conv1_dgrad", L.ptr(dfg), L.ptr(self.vgg_w), n, H, W, L.ptr(gout), L.stream())
+        else:
+            L.call("pg_l1_loss", L.ptr(out_gen), L.ptr(target), out_gen.numel(), l1w / out_gen.numel(),
+                   L.ptr(self._loss[1:]), L.ptr(gout), 1, L.stream())
+        L.call("pg_tanh_bwd", L.ptr(gout), L.ptr(out_gen), gout.numel(), L.stream())
+        if self.g_reducer is not None:
+            self.g_reducer.begin()
+            eng.grad_ready_cb = self.g_reducer.mark_ready
+        eng.backward(gout)
+        scale = 1.0
+        if self.g_reducer is not None:
+            self.g_reducer.finish()
+            scale = 1.0 / self.world
+        self.gen_opt.step(grad_scale=scale)
+        self._loss[0:1].copy_(self._loss[1:2] + self._loss[2:3])      # total = ll + ad  (pose_gan.py:109)
+        losses = self._losses(0, opt.get("lazy_losses", False))
+        return out_gen, [], losses
+
+    def dis_update(self, input, target, other_inputs, real_inp, real_target, opt):
+        """reference pose_gan.py:117-171 (out_gen detached: SURVEY App. A.7 (i))."""
+        n = input.shape[0]
+        input, real_inp, real_target = input.contiguous(), real_inp.contiguous(), real_target.contiguous()
+        self.disc.zero_grad()
+        self._loss[4:7].zero_()
+        eng, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
+        deng = self.disc.engine(2 * n)
+        logits = deng.forward([(real_inp, real_target), (input, out_gen)])     # cat((real, fake), 0) — pose_gan.py:136
+        K = logits.shape[1]
+        dlog = self._buf("dlog_d", logits.shape)
+        w_gan = float(opt["gan_penalty_weight"]) / self.batch_size
+        L.call("pg_gan_logloss", L.ptr(logits), n * K, 0, w_gan / K, L.ptr(self._loss[5:]), L.ptr(dlog), None, L.stream())
+        L.call("pg_gan_logloss", logits.data_ptr() + 4 * n * K, n * K, 1, w_gan / K, L.ptr(self._loss[6:]),
+               dlog.data_ptr() + 4 * n * K, None, L.stream())
+        if self.d_reducer is not None:
+            self.d_reducer.begin()
+            deng.grad_ready_cb = self.d_reducer.mark_ready
+        deng.backward(dlog, need_wgrad=True)
+        scale = 1.0
+        if self.d_reducer is not None:
+            self.d_reducer.finish()
+            scale = 1.0 / self.world
+        self.disc_opt.step(grad_scale=scale)
+        self._loss[4:5].copy_(self._loss[5:6] + self._loss[6:7])
+        return self._losses(4, opt.get("lazy_losses", False))
+
+    # ------------------------------------------------------------------------------------------
+    def nn_loss(self, predicted, ground_truth, nh=3, nw=3):
+        """reference pose_gan.py:173-199 on NCHW tensors (module-level API; value only)."""
+        assert nh == nw
+        n, c, h, w = predicted.shape
+        cp = 4
+        while cp < c:
+            cp *= 2
+        P = torch.zeros(n, h, w, cp, dtype=torch.float32, device=self.device)
+        G = torch.zeros(n, h, w, cp, dtype=torch.float32, device=self.device)
+        P[..., :c] = predicted.permute(0, 2, 3, 1)
+        G[..., :c] = ground_truth.permute(0, 2, 3, 1)
+        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        L.call("pg_nn_loss", L.ptr(P), L.ptr(G), n, h, w, cp, nh, 1.0 / (n * h * w), 0, L.ptr(loss), None, L.stream())
+        return loss[0]
+
+    def resume(self, save_dir):
+        """reference pose_gan.py:201-214."""
+        last = pose_utils.get_model_list(save_dir, "gen")
+        if last is None:
+            return 1
+        self.gen.load_state_dict(torch.load(last, map_location="cpu"))
+        epoch = int(last[-7:-4])
+        last = pose_utils.get_model_list(save_dir, "dis")
+        if last is None:
+            return 1
+        epoch = int(last[-7:-4])
+        self.disc.load_state_dict(torch.load(last, map_location="cpu"))
+        return epoch
+
+    def save(self, save_dir, epoch):
+        """reference pose_gan.py:216-220: gen_%03d.pkl / disc_%03d.pkl = torch.save(state_dict) in reference layout."""
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save({k: v.cpu() for k, v in self.gen.state_dict().items()}, os.path.join(save_dir, "gen_{0:03d}.pkl".format(epoch)))
+        torch.save({k: v.cpu() for k, v in self.disc.state_dict().items()}, os.path.join(save_dir, "disc_{0:03d}.pkl".format(epoch)))
+
+
+def _default_vgg_conv1(path=None):
+    """conv1_1 of VGG-19.  The ImageNet weights (`vgg19-dcbb9e9d.pth`) are not available offline: load them from
+    `path` (a torchvision state_dict) when given, else use seeded synthetic weights (trained values unpinned)."""
+    if path and os.path.exists(path):
+        sd = torch.load(path, map_location="cpu")
+        return sd["features.0.weight"], sd["features.0.bias"]
+    return (torch.from_numpy(synth.xavier_uniform(14, "vgg/w", (64, 3, 3, 3))),
+            torch.from_numpy(synth.uniform(14, "vgg/b", (64,), -0.1, 0.1)))

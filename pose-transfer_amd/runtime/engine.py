@@ -1,0 +1,584 @@
+"""Execution engines: the explicit forward/backward kernel schedules of the generator and the
+discriminator on top of libposegan_hip (no autograd tape, no torch compute ops).
+
+Data layout: every activation is fp32 NHWC and is stored RAW (the output of its
+convolution).  The reference's per-sample norm (models/networks.py:159,166-169), dropout (:161),
+pre-activation (:150,152) and torch.cat (:241,245,271,284,286) are never materialised: each tensor
+carries a per-sample affine ``aff`` [N,2] and an optional channel mask [N,C] that consumers apply on
+load.  Parameters live in flat arenas (params / grads / Adam m / Adam v) in packed kernel layout.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+from ..utils import synth
+
+T_WARPS = 10
+NORM_EPS = 1e-3   # reference models/networks.py:159
+
+
+# ------------------------------------------------------------------------------------------ arenas
+def _pack(key, w):
+    """reference state_dict tensor -> packed kernel layout [KH][KW][Cout][Cin]."""
+    if w.dim() != 4:
+        return w.contiguous()
+    if _is_convT(key):
+        return w.permute(2, 3, 1, 0).contiguous()      # (Cin,Cout,KH,KW) ConvTranspose2d
+    return w.permute(2, 3, 0, 1).contiguous()          # (Cout,Cin,KH,KW) Conv2d
+
+
+def _unpack(key, w):
+    if w.dim() != 4:
+        return w.clone()
+    if _is_convT(key):
+        return w.permute(3, 2, 0, 1).contiguous()
+    return w.permute(2, 3, 0, 1).contiguous()
+
+
+def _is_convT(key):
+    # decoder up-blocks hold nn.ConvTranspose2d at `.net.1` (reference models/networks.py:156)
+    return key.startswith("decoder.net.") and key.endswith(".net.1.weight")
+
+
+def _packed_shape(key, shape):
+    if len(shape) != 4:
+        return tuple(shape)
+    if _is_convT(key):
+        return (shape[2], shape[3], shape[1], shape[0])
+    return (shape[2], shape[3], shape[0], shape[1])
+
+
+class ParamArena:
+    """Flat fp32 device buffers holding every parameter of one network in packed layout, plus the
+    matching gradient and Adam-moment buffers.  `order` lists keys in backward-completion order so
+    that DP gradient buckets are contiguous ranges."""
+
+    ALIGN = 64
+
+    def __init__(self, spec, order, device):
+        shapes = dict(spec)
+        self.spec = list(spec)
+        self.keys = list(order)
+        assert sorted(self.keys) == sorted(shapes)
+        self.ref_shape = shapes
+        self.off, self.numel, self.pshape = {}, {}, {}
+        o = 0
+        for k in self.keys:
+            n = int(np.prod(shapes[k]))
+            self.off[k], self.numel[k] = o, n
+            self.pshape[k] = _packed_shape(k, shapes[k])
+            o += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = o
+        self.params = torch.zeros(o, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(o, dtype=torch.float32, device=device)
+        self.m = torch.zeros(o, dtype=torch.float32, device=device)
+        self.v = torch.zeros(o, dtype=torch.float32, device=device)
+        self.step = 0
+
+    def p(self, key):
+        return self.params[self.off[key]:self.off[key] + self.numel[key]].view(self.pshape[key])
+
+    def g(self, key):
+        return self.grads[self.off[key]:self.off[key] + self.numel[key]].view(self.pshape[key])
+
+    def load_state_dict(self, sd):
+        for k in self.keys:
+            w = sd[k]
+            if not torch.is_tensor(w):
+                w = torch.from_numpy(np.ascontiguousarray(w))
+            assert tuple(w.shape) == tuple(self.ref_shape[k]), (k, tuple(w.shape), self.ref_shape[k])
+            self.p(k).copy_(_pack(k, w.to(torch.float32)).to(self.params.device))
+
+    def state_dict(self):
+        return {k: _unpack(k, self.p(k)) for k, _ in self.spec}
+
+    def grad_dict(self):
+        return {k: _unpack(k, self.g(k)) for k, _ in self.spec}
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def adam_step(self, lr, b1=0.5, b2=0.999, eps=1e-8, grad_scale=1.0):
+        """torch.optim.Adam semantics (reference models/pose_gan.py:50-51); bias corrections in double."""
+        self.step += 1
+        bc1 = 1.0 - b1 ** self.step
+        bc2 = 1.0 - b2 ** self.step
+        L.call("pg_adam", L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.total,
+               b1, b2, eps, lr / bc1, math.sqrt(bc2), grad_scale, L.stream())
+
+
+# ------------------------------------------------------------------------------------------ activation handle
+class Act:
+    """A raw NHWC activation with its deferred per-sample affine / channel mask."""
+
+    def __init__(self, t, C, aff=None, mask=None, mr=None, strides=None, base_ptr=None):
+        self.t, self.C, self.aff, self.mask, self.mr = t, C, aff, mask, mr
+        self.strides = strides        # (sN,sC,sH,sW) for small-C strided sources
+        self.base_ptr = base_ptr      # explicit device pointer (channel slice of a bigger tensor)
+        self.dz = None                # gradient buffer wrt the post-norm value
+
+    def src(self, with_prologue=True):
+        s = L.Src()
+        s.ptr = self.base_ptr if self.base_ptr is not None else L.ptr(self.t)
+        s.C = self.C
+        if with_prologue:
+            s.aff = L.ptr(self.aff)
+            s.mask = L.ptr(self.mask)
+        if self.strides is not None:
+            s.sN, s.sC, s.sH, s.sW = self.strides
+        return s
+
+
+def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, transposed=False, scalar_in=False,
+          out=None, out_strides=None, bias=None, out_act=L.OUT_NONE, dsts=None, n_off=0, n_cnt=0, ksplit=0):
+    d = L.ConvDesc()
+    for i, s in enumerate(srcs):
+        d.src[i] = s
+    d.nsrc, d.N, d.Hi, d.Wi = len(srcs), N, Hi, Wi
+    d.act, d.scalar_in = act, 1 if scalar_in else 0
+    d.mode, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = mode, K, K, stride, pad, Ho, Wo
+    d.w_transposed = 1 if transposed else 0
+    d.W, d.wCout, d.wCin = L.ptr(W), wCout, wCin
+    d.n_off, d.n_cnt = n_off, n_cnt
+    if dsts is None:
+        ncnt = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
+        d.epilogue = 0
+        d.out = out if isinstance(out, int) else L.ptr(out)
+        d.bias = L.ptr(bias)
+        d.out_act = out_act
+        if out_strides is None:
+            out_strides = (Ho * Wo * ncnt, 1, Wo * ncnt, ncnt)
+        d.oN, d.oC, d.oH, d.oW = out_strides
+    else:
+        d.epilogue = 1
+        for i, t in enumerate(dsts):
+            d.dst[i] = t
+        d.ndst = len(dsts)
+    d.ksplit = ksplit
+    L.check(L.load().pg_conv(d, L.stream()), "pg_conv")
+
+
+def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
+           y_strides=None, ksplit=0):
+    d = L.WgradDesc()
+    for i, s in enumerate(srcs):
+        d.src[i] = s
+    d.nsrc, d.N, d.act, d.scalar_x = len(srcs), N, act, 1 if scalar_x else 0
+    d.dY = dY if isinstance(dY, int) else L.ptr(dY)
+    if y_strides is not None:
+        d.scalar_y = 1
+        d.yN, d.yC, d.yH, d.yW = y_strides
+    d.x_is_large = 1 if x_is_large else 0
+    d.Hs, d.Ws, d.Hl, d.Wl = Hs, Ws, Hl, Wl
+    d.KH, d.KW, d.stride, d.pad = K, K, stride, pad
+    d.dW, d.Cout, d.Cin = L.ptr(dW), Cout, Cin
+    d.ksplit = ksplit
+    L.check(L.load().pg_conv_wgrad(d, L.stream()), "pg_conv_wgrad")
+
+
+class NormState:
+    """Scratch for one per-sample norm: stats (double), mean/rstd, the emitted affine, backward sums."""
+
+    def __init__(self, N, device):
+        self.sums = torch.zeros(N, 2, dtype=torch.float64, device=device)
+        self.bsums = torch.zeros(N, 2, dtype=torch.float64, device=device)
+        self.mr = torch.zeros(N, 2, dtype=torch.float32, device=device)
+        self.aff = torch.zeros(N, 2, dtype=torch.float32, device=device)
+
+    def forward(self, y, N, Lr, gamma, beta):
+        self.sums.zero_()
+        L.call("pg_norm_stats", L.ptr(y), N, Lr, L.ptr(self.sums), L.stream())
+        L.call("pg_norm_finalize", L.ptr(self.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(self.mr),
+               L.ptr(self.aff), L.stream())
+
+    def backward(self, dz, y, N, Lr, gamma, dgamma, dbeta):
+        self.bsums.zero_()
+        L.call("pg_norm_bwd_reduce", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), L.stream())
+        L.call("pg_norm_bwd_apply", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
+               L.ptr(dgamma), L.ptr(dbeta), L.stream())
+
+
+def generator_param_order(spec, nlev, ndec, deformable=True):
+    """Backward-completion order of the generator's parameters (decoder tail first, encoder level 0 last)."""
+    keys = [k for k, _ in spec]
+    order = []
+
+    def take(prefix):
+        for k in keys:
+            if k.startswith(prefix) and k not in order:
+                order.append(k)
+
+    take("decoder.net.%d." % ndec)           # final conv (module index ndec = len(nfilters_dec))
+    for i in range(ndec - 2, -1, -1):
+        take("decoder.net.%d." % i)
+    encs = ("encoder_app", "encoder_pose") if deformable else ("encoder",)
+    for l in range(nlev - 1, -1, -1):
+        for e in encs:
+            take("%s.net.%d." % (e, l))
+    assert len(order) == len(keys), (len(order), len(keys))
+    return order
+
+
+# ------------------------------------------------------------------------------------------ generator
+class GeneratorEngine:
+    """Deformable_Generator (reference models/networks.py:252-288) / src_baseline Generator
+    (src_baseline/models/networks.py:238-253) forward + backward for a fixed (N,H,W)."""
+
+    def __init__(self, arena, N, H, W, pose_dim, nfilters_enc, nfilters_dec, deformable=True, align_corners=False,
+                 device="cuda"):
+        self.A, self.N, self.H, self.W, self.P = arena, N, H, W, pose_dim
+        self.enc, self.dec = tuple(nfilters_enc), tuple(nfilters_dec)
+        self.nlev, self.ndec = len(self.enc), len(self.dec)
+        self.deformable, self.align = deformable, 1 if align_corners else 0
+        self.dev = device
+        self.encs = ("encoder_app", "encoder_pose") if deformable else ("encoder",)
+        assert self.ndec == self.nlev
+        f32 = dict(dtype=torch.float32, device=device)
+        hw = [(H >> l, W >> l) for l in range(self.nlev)]
+        assert all(h << l == H and w << l == W for l, (h, w) in enumerate(hw)), "H,W must be divisible by 2^(levels-1)"
+        self.hw = hw
+        # encoder activations (raw), grads, norm state
+        self.e_raw = {e: [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nlev)] for e in self.encs}
+        self.e_dz = {e: [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nlev)] for e in self.encs}
+        self.e_norm = {e: [NormState(N, device) if 0 < l < self.nlev - 1 else None for l in range(self.nlev)] for e in self.encs}
+        # warped appearance skips (levels 0..3)
+        self.nwarp = min(4, self.nlev) if deformable else 0
+        self.w_out = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nwarp)]
+        self.w_g = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nwarp)]
+        self.w_arg = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], dtype=torch.uint8, device=device) for l in range(self.nwarp)]
+        self.lvl_masks = [torch.empty(N, hw[l][0], hw[l][1], T_WARPS, **f32) for l in range(self.nwarp)]
+        # decoder up-block outputs: block i lives at level nlev-2-i
+        self.d_raw, self.d_dz, self.d_norm = [], [], []
+        for i in range(self.ndec - 1):
+            h, w = hw[self.nlev - 2 - i]
+            self.d_raw.append(torch.empty(N, h, w, self.dec[i], **f32))
+            self.d_dz.append(torch.empty(N, h, w, self.dec[i], **f32))
+            self.d_norm.append(NormState(N, device))
+        self.drop = [torch.ones(N, self.dec[i], **f32) for i in range(min(3, self.ndec - 1))]
+        self.out = torch.empty(N, 3, H, W, **f32)
+        self.warps = torch.empty(N, T_WARPS, 8, **f32)
+        self.input = None
+        self._drop_counter = 0
+        self.grad_ready_cb = None      # DP hook: called with the parameter keys whose gradients are complete
+
+    # -------------------------------------------------------------------------------- helpers
+    def _ready(self, *prefixes):
+        if self.grad_ready_cb is not None:
+            self.grad_ready_cb([k for k in self.A.keys if k.startswith(prefixes)])
+
+    def _enc_in_src(self, e, inp):
+        """NCHW channel slice of `input` feeding encoder level 0 (get_imgpose, utils/pose_utils.py:227-233)."""
+        C = inp.shape[1]
+        HW = self.H * self.W
+        strides = (C * HW, HW, self.W, 1)
+        if e == "encoder_app":
+            return Act(inp, 3 + self.P, strides=strides)
+        if e == "encoder_pose":
+            return Act(inp, self.P, strides=strides, base_ptr=inp.data_ptr() + 4 * (3 + self.P) * HW)
+        return Act(inp, C, strides=strides)
+
+    def _enc_act(self, e, l):
+        st = self.e_norm[e][l]
+        return Act(self.e_raw[e][l], self.enc[l], aff=st.aff if st is not None else None)
+
+    def _dec_sources(self, i):
+        """K-sources of decoder block i (the reference's cat([out, skip]), networks.py:241,245), level nlev-1-i."""
+        l = self.nlev - 1 - i
+        srcs = []
+        if i > 0:
+            srcs.append(("dec", i - 1, Act(self.d_raw[i - 1], self.dec[i - 1], aff=self.d_norm[i - 1].aff,
+                                           mask=self.drop[i - 1] if (i - 1) < len(self.drop) and self.use_drop else None)))
+        if self.deformable:
+            if l < self.nwarp:
+                srcs.append(("warp", l, Act(self.w_out[l], self.enc[l])))
+            else:
+                srcs.append(("app", l, self._enc_act("encoder_app", l)))
+            srcs.append(("pose", l, self._enc_act("encoder_pose", l)))
+        else:
+            srcs.append(("enc", l, self._enc_act("encoder", l)))
+        return srcs
+
+    # -------------------------------------------------------------------------------- forward
+    def set_dropout(self, masks=None, train=True, seed=0):
+        """masks: list of (N,C) multiplier tensors (parity tests) | None -> device RNG (train) / identity (eval)."""
+        self.use_drop = bool(train) or masks is not None
+        if masks is not None:
+            for d, m in zip(self.drop, masks):
+                d.copy_(m)
+        elif train:
+            for i, d in enumerate(self.drop):
+                self._drop_counter += 1
+                key = int(synth._stream_key(seed, "drop/%d/%d" % (self._drop_counter, i)))
+                L.call("pg_dropout_mask", L.ptr(d), d.numel(), key, 0.5, L.stream())
+
+    def forward(self, inp, warps=None, masks=None):
+        """inp (N,3+2P,H,W) NCHW fp32; warps (N,10,8); masks (N,10,H,W) fp32|fp64.  Returns out_gen NCHW."""
+        A, N, H, W = self.A, self.N, self.H, self.W
+        assert tuple(inp.shape) == (N, 3 + 2 * self.P, H, W) and inp.is_contiguous() and inp.dtype == torch.float32
+        self.input = inp
+        if not hasattr(self, "use_drop"):
+            self.set_dropout(None, train=True)
+        if self.deformable:
+            self.warps.copy_(warps.reshape(N, T_WARPS, 8))
+            assert masks.is_contiguous()
+            for l in range(self.nwarp):
+                L.call("pg_mask_pyramid", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T_WARPS, H, W,
+                       self.hw[l][0], self.hw[l][1], L.ptr(self.lvl_masks[l]), L.stream())
+        # ---- encoders (reference networks.py:193-202)
+        for e in self.encs:
+            s0 = self._enc_in_src(e, inp)
+            _conv([s0.src()], N, H, W, L.ACT_NONE, 0, 3, 1, 1, H, W, A.p(e + ".net.0.weight"), self.enc[0], s0.C,
+                  scalar_in=True, out=self.e_raw[e][0], bias=A.p(e + ".net.0.bias"))
+            for l in range(1, self.nlev):
+                hi, wi = self.hw[l - 1]
+                ho, wo = self.hw[l]
+                _conv([self._enc_act(e, l - 1).src()], N, hi, wi, L.ACT_LEAKY, 0, 4, 2, 1, ho, wo,
+                      A.p("%s.net.%d.net.1.weight" % (e, l)), self.enc[l], self.enc[l - 1], out=self.e_raw[e][l])
+                if l < self.nlev - 1:
+                    self.e_norm[e][l].forward(self.e_raw[e][l], N, ho * wo * self.enc[l],
+                                              A.p("%s.net.%d.net.2.weight" % (e, l)), A.p("%s.net.%d.net.2.bias" % (e, l)))
+        # ---- deformable skips (reference networks.py:279-288, utils/pose_transform.py:69-92)
+        for l in range(self.nwarp):
+            a = self._enc_act("encoder_app", l)
+            L.call("pg_warp_mask_max_fwd", L.ptr(a.t), L.ptr(a.aff), L.ptr(self.warps), L.ptr(self.lvl_masks[l]), N,
+                   T_WARPS, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.w_out[l]),
+                   L.ptr(self.w_arg[l]), L.stream())
+        # ---- decoder (reference networks.py:236-250)
+        for i in range(self.ndec - 1):
+            srcs = self._dec_sources(i)
+            hi, wi = self.hw[self.nlev - 1 - i]
+            ho, wo = 2 * hi, 2 * wi
+            cin = sum(a.C for _, _, a in srcs)
+            _conv([a.src() for _, _, a in srcs], N, hi, wi, L.ACT_RELU, 1, 4, 2, 1, ho, wo,
+                  A.p("decoder.net.%d.net.1.weight" % i), self.dec[i], cin, out=self.d_raw[i])
+            self.d_norm[i].forward(self.d_raw[i], N, ho * wo * self.dec[i], A.p("decoder.net.%d.net.3.weight" % i),
+                                   A.p("decoder.net.%d.net.3.bias" % i))
+        i = self.ndec - 1
+        srcs = self._dec_sources(i)
+        cin = sum(a.C for _, _, a in srcs)
+        _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 3, 1, 1, H, W,
+              A.p("decoder.net.%d.weight" % (i + 1)), 3, cin, out=self.out, out_strides=(3 * H * W, H * W, W, 1),
+              bias=A.p("decoder.net.%d.bias" % (i + 1)), out_act=L.OUT_TANH)
+        return self.out
+
+    # -------------------------------------------------------------------------------- backward
+    def _dsts_for(self, srcs, first_write):
+        """Epilogue destinations of a data-gradient wrt the concat `srcs` (consumer activation = ReLU)."""
+        dsts = []
+        for kind, idx, a in srcs:
+            if kind == "dec":
+                dsts.append(L.make_dst(self.d_dz[idx], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=L.ACT_RELU))
+            elif kind == "warp":
+                dsts.append(L.make_dst(self.w_g[idx], a.C, fwd=a.t, act=L.ACT_RELU))
+            else:
+                e = {"app": "encoder_app", "pose": "encoder_pose", "enc": "encoder"}[kind]
+                dsts.append(L.make_dst(self.e_dz[e][idx], a.C, fwd=a.t, aff=a.aff, act=L.ACT_RELU,
+                                       accumulate=not first_write))
+        return dsts
+
+    def backward(self, dpre):
+        """dpre: gradient wrt the pre-tanh output, NCHW (N,3,H,W), contiguous.  Accumulates into arena.grads."""
+        A, N, H, W = self.A, self.N, self.H, self.W
+        assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
+        ystr = (3 * H * W, H * W, W, 1)
+        for l in range(self.nwarp):
+            self.e_dz["encoder_app"][l].zero_()
+        # ---- final conv k3s1p1 (+bias, tanh handled by the caller)
+        i = self.ndec - 1
+        srcs = self._dec_sources(i)
+        cin = sum(a.C for _, _, a in srcs)
+        wkey = "decoder.net.%d.weight" % (i + 1)
+        L.call("pg_bias_grad", L.ptr(dpre), N, H * W, 3, 3 * H * W, 1, H * W, L.ptr(A.g("decoder.net.%d.bias" % (i + 1))),
+               L.stream())
+        _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, dpre, 3, cin, True, H, W, H, W, 3, 1, 1, A.g(wkey),
+               y_strides=ystr)
+        self._ready("decoder.net.%d." % (i + 1))
+        dsrc = Act(dpre, 3, strides=ystr)
+        _conv([dsrc.src()], N, H, W, L.ACT_NONE, 1, 3, 1, 1, H, W, A.p(wkey), 3, cin, transposed=True, scalar_in=True,
+              dsts=self._dsts_for(srcs, True))
+        # ---- up blocks
+        for i in range(self.ndec - 2, -1, -1):
+            srcs = self._dec_sources(i)
+            cin = sum(a.C for _, _, a in srcs)
+            hi, wi = self.hw[self.nlev - 1 - i]
+            ho, wo = 2 * hi, 2 * wi
+            wkey = "decoder.net.%d.net.1.weight" % i
+            self.d_norm[i].backward(self.d_dz[i], self.d_raw[i], N, ho * wo * self.dec[i],
+                                    A.p("decoder.net.%d.net.3.weight" % i), A.g("decoder.net.%d.net.3.weight" % i),
+                                    A.g("decoder.net.%d.net.3.bias" % i))
+            dy = self.d_dz[i]
+            _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, dy, self.dec[i], cin, False, hi, wi, ho, wo, 4, 2, 1,
+                   A.g(wkey))
+            self._ready("decoder.net.%d." % i)
+            _conv([Act(dy, self.dec[i]).src()], N, ho, wo, L.ACT_NONE, 0, 4, 2, 1, hi, wi, A.p(wkey), self.dec[i], cin,
+                  transposed=True, dsts=self._dsts_for(srcs, True))
+        # ---- deformable skips
+        for l in range(self.nwarp):
+            L.call("pg_warp_mask_max_bwd", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
+                   L.ptr(self.lvl_masks[l]), N, T_WARPS, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align,
+                   L.ptr(self.e_dz["encoder_app"][l]), L.stream())
+        # ---- encoders
+        for l in range(self.nlev - 1, 0, -1):
+            for e in self.encs:
+                hi, wi = self.hw[l - 1]
+                ho, wo = self.hw[l]
+                wkey = "%s.net.%d.net.1.weight" % (e, l)
+                dz = self.e_dz[e][l]
+                if l < self.nlev - 1:
+                    self.e_norm[e][l].backward(dz, self.e_raw[e][l], N, ho * wo * self.enc[l],
+                                               A.p("%s.net.%d.net.2.weight" % (e, l)), A.g("%s.net.%d.net.2.weight" % (e, l)),
+                                               A.g("%s.net.%d.net.2.bias" % (e, l)))
+                xin = self._enc_act(e, l - 1)
+                _wgrad([xin.src()], N, L.ACT_LEAKY, dz, self.enc[l], self.enc[l - 1], True, ho, wo, hi, wi, 4, 2, 1,
+                       A.g(wkey))
+                self._ready("%s.net.%d." % (e, l))
+                _conv([Act(dz, self.enc[l]).src()], N, ho, wo, L.ACT_NONE, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
+                      self.enc[l - 1], transposed=True,
+                      dsts=[L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
+                                       accumulate=True)])
+        for e in self.encs:
+            dz = self.e_dz[e][0]
+            s0 = self._enc_in_src(e, self.input)
+            L.call("pg_bias_grad", L.ptr(dz), N * H * W, 1, self.enc[0], self.enc[0], 0, 1,
+                   L.ptr(A.g(e + ".net.0.bias")), L.stream())
+            _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
+                   A.g(e + ".net.0.weight"), scalar_x=True)
+            self._ready(e + ".net.0.")
+
+
+# ------------------------------------------------------------------------------------------ discriminator
+def discriminator_param_order(spec):
+    keys = [k for k, _ in spec]
+    idx = sorted({int(k.split(".")[1]) for k in keys}, reverse=True)
+    order = []
+    for i in idx:
+        order += [k for k in keys if k.startswith("net.%d." % i)]
+    return order
+
+
+class DiscriminatorEngine:
+    """Discriminator (reference models/networks.py:329-357) forward + backward for a fixed batch M."""
+
+    def __init__(self, arena, M, H, W, pose_dim, device="cuda"):
+        self.A, self.M, self.H, self.W, self.P = arena, M, H, W, pose_dim
+        self.chans = [64]
+        j = 1
+        while ("net.%d.net.1.weight" % j) in arena.off:
+            self.chans.append(arena.ref_shape["net.%d.net.1.weight" % j][0])
+            j += 1
+        self.nblk = len(self.chans)            # stem + blocks; last block has Cout=1 and no norm
+        f32 = dict(dtype=torch.float32, device=device)
+        hs, ws = [(H - 4) // 2 + 1], [(W - 4) // 2 + 1]
+        for j in range(1, self.nblk):
+            hs.append((hs[-1] + 2 - 4) // 2 + 1)
+            ws.append((ws[-1] + 2 - 4) // 2 + 1)
+        assert hs[-1] >= 1 and ws[-1] >= 1
+        self.hs, self.ws = hs, ws
+        self.raw = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
+        self.dz = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
+        self.norm = [NormState(M, device) if 0 < j < self.nblk - 1 else None for j in range(self.nblk)]
+        self.K = hs[-1] * ws[-1]               # outputs per image (49 at 256^2)
+        self.inputs = None
+        self.grad_ready_cb = None
+
+    def _ready(self, *prefixes):
+        if self.grad_ready_cb is not None:
+            self.grad_ready_cb([k for k in self.A.keys if k.startswith(prefixes)])
+
+    def _stem_srcs(self, pair):
+        """[img(3), src_pose(P), image_to_judge(3), tgt_pose(P)] without the cat (pose_gan.py:86,133,135).
+        pair = (input NCHW (n,3+2P,H,W), judged NCHW (n,3,H,W))  or  (x,) with x the already-concatenated
+        (n,3+2P+3,H,W) tensor (module-level Discriminator.forward API)."""
+        P, HW = self.P, self.H * self.W
+        if len(pair) == 1:
+            x = pair[0]
+            sX = (x.shape[1] * HW, HW, self.W, 1)
+            return [Act(x, 3 + P, strides=sX), Act(x, 3, strides=sX, base_ptr=x.data_ptr() + 4 * (3 + P) * HW),
+                    Act(x, P, strides=sX, base_ptr=x.data_ptr() + 4 * (6 + P) * HW)]
+        inp, judged = pair
+        C = inp.shape[1]
+        sI = (C * HW, HW, self.W, 1)
+        sJ = (3 * HW, HW, self.W, 1)
+        return [Act(inp, 3 + P, strides=sI), Act(judged, 3, strides=sJ),
+                Act(inp, P, strides=sI, base_ptr=inp.data_ptr() + 4 * (3 + P) * HW)]
+
+    def _act(self, j):
+        st = self.norm[j]
+        return Act(self.raw[j], self.chans[j], aff=st.aff if st is not None else None)
+
+    def forward(self, pairs):
+        """pairs: list of (input NCHW (n,3+2P,H,W), judged NCHW (n,3,H,W)); sum n == M.  Returns logits (M,K)."""
+        A, H, W = self.A, self.H, self.W
+        self.inputs = pairs
+        off = 0
+        for pair in pairs:
+            n = pair[0].shape[0]
+            assert all(t.is_contiguous() and t.dtype == torch.float32 for t in pair)
+            srcs = self._stem_srcs(pair)
+            out_ptr = self.raw[0].data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
+            _conv([a.src() for a in srcs], n, H, W, L.ACT_NONE, 0, 4, 2, 0, self.hs[0], self.ws[0], A.p("net.0.weight"),
+                  64, 3 + 2 * self.P + 3, scalar_in=True, out=out_ptr, bias=A.p("net.0.bias"))
+            off += n
+        assert off == self.M
+        for j in range(1, self.nblk):
+            _conv([self._act(j - 1).src()], self.M, self.hs[j - 1], self.ws[j - 1], L.ACT_LEAKY, 0, 4, 2, 1, self.hs[j],
+                  self.ws[j], A.p("net.%d.net.1.weight" % j), self.chans[j], self.chans[j - 1], out=self.raw[j])
+            if j < self.nblk - 1:
+                self.norm[j].forward(self.raw[j], self.M, self.hs[j] * self.ws[j] * self.chans[j],
+                                     A.p("net.%d.net.2.weight" % j), A.p("net.%d.net.2.bias" % j))
+        return self.raw[-1].view(self.M, self.K)
+
+    def backward(self, dlogits, need_wgrad=True, image_grad=None):
+        """dlogits (M,K).  need_wgrad: accumulate weight grads (dis_update).  image_grad: list of NCHW (n,3,H,W)
+        buffers (one per forward pair, or None) receiving d/d(judged image) (gen_update)."""
+        A, M, H, W = self.A, self.M, self.H, self.W
+        j = self.nblk - 1
+        ystr = (self.K, 1, self.ws[j], 1)
+        wkey = "net.%d.net.1.weight" % j
+        xin = self._act(j - 1)
+        if need_wgrad:
+            _wgrad([xin.src()], M, L.ACT_LEAKY, dlogits, 1, self.chans[j - 1], True, self.hs[j], self.ws[j],
+                   self.hs[j - 1], self.ws[j - 1], 4, 2, 1, A.g(wkey), y_strides=ystr)
+            self._ready("net.%d." % j)
+        _conv([Act(dlogits, 1, strides=ystr).src()], M, self.hs[j], self.ws[j], L.ACT_NONE, 1, 4, 2, 1, self.hs[j - 1],
+              self.ws[j - 1], A.p(wkey), 1, self.chans[j - 1], transposed=True, scalar_in=True,
+              dsts=[L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)])
+        for j in range(self.nblk - 2, 0, -1):
+            wkey = "net.%d.net.1.weight" % j
+            dz = self.dz[j]
+            self.norm[j].backward(dz, self.raw[j], M, self.hs[j] * self.ws[j] * self.chans[j],
+                                  A.p("net.%d.net.2.weight" % j),
+                                  A.g("net.%d.net.2.weight" % j) if need_wgrad else None,
+                                  A.g("net.%d.net.2.bias" % j) if need_wgrad else None)
+            xin = self._act(j - 1)
+            if need_wgrad:
+                _wgrad([xin.src()], M, L.ACT_LEAKY, dz, self.chans[j], self.chans[j - 1], True, self.hs[j], self.ws[j],
+                       self.hs[j - 1], self.ws[j - 1], 4, 2, 1, A.g(wkey))
+                self._ready("net.%d." % j)
+            _conv([Act(dz, self.chans[j]).src()], M, self.hs[j], self.ws[j], L.ACT_NONE, 1, 4, 2, 1, self.hs[j - 1],
+                  self.ws[j - 1], A.p(wkey), self.chans[j], self.chans[j - 1], transposed=True,
+                  dsts=[L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)])
+        # stem
+        dz0 = self.dz[0]
+        cin = 3 + 2 * self.P + 3
+        if need_wgrad:
+            L.call("pg_bias_grad", L.ptr(dz0), M * self.hs[0] * self.ws[0], 1, 64, 64, 0, 1, L.ptr(A.g("net.0.bias")),
+                   L.stream())
+        off = 0
+        for pi, pair in enumerate(self.inputs):
+            n = pair[0].shape[0]
+            dptr = dz0.data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
+            if need_wgrad:
+                _wgrad([a.src() for a in self._stem_srcs(pair)], n, L.ACT_NONE, dptr, 64, cin, True, self.hs[0],
+                       self.ws[0], H, W, 4, 2, 0, A.g("net.0.weight"), scalar_x=True)
+            if image_grad is not None and image_grad[pi] is not None:
+                g = image_grad[pi]
+                s = L.Src()
+                s.ptr, s.C = dptr, 64
+                _conv([s], n, self.hs[0], self.ws[0], L.ACT_NONE, 1, 4, 2, 0, H, W, A.p("net.0.weight"), 64, cin,
+                      transposed=True, out=g, out_strides=(3 * H * W, H * W, W, 1), n_off=3 + self.P, n_cnt=3)
+            off += n
+        if need_wgrad:
+            self._ready("net.0.")

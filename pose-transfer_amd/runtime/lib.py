@@ -1,0 +1,157 @@
+"""ctypes binding of libposegan_hip.so (include/posegan_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  PyTorch tensors are used only as device storage: every call passes raw ``data_ptr()``s and
+the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+PG_MAX_SRC = 4
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+OUT_NONE, OUT_TANH = 0, 1
+
+_f32p = C.c_void_p
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("_pad", C.c_int32), ("aff", C.c_void_p),
+                ("mask", C.c_void_p), ("sN", C.c_int64), ("sC", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64)]
+
+
+class Dst(C.Structure):
+    _fields_ = [("grad", C.c_void_p), ("fwd", C.c_void_p), ("aff", C.c_void_p), ("mask", C.c_void_p),
+                ("C", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("src", Src * PG_MAX_SRC),
+                ("nsrc", C.c_int32), ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32),
+                ("act", C.c_int32), ("scalar_in", C.c_int32),
+                ("mode", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("w_transposed", C.c_int32),
+                ("W", C.c_void_p), ("wCout", C.c_int32), ("wCin", C.c_int32),
+                ("n_off", C.c_int32), ("n_cnt", C.c_int32),
+                ("epilogue", C.c_int32), ("out_act", C.c_int32),
+                ("out", C.c_void_p), ("bias", C.c_void_p),
+                ("oN", C.c_int64), ("oC", C.c_int64), ("oH", C.c_int64), ("oW", C.c_int64),
+                ("dst", Dst * PG_MAX_SRC),
+                ("ndst", C.c_int32), ("ksplit", C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("src", Src * PG_MAX_SRC),
+                ("nsrc", C.c_int32), ("N", C.c_int32), ("act", C.c_int32), ("scalar_x", C.c_int32),
+                ("dY", C.c_void_p),
+                ("yN", C.c_int64), ("yC", C.c_int64), ("yH", C.c_int64), ("yW", C.c_int64),
+                ("scalar_y", C.c_int32), ("x_is_large", C.c_int32),
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hl", C.c_int32), ("Wl", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("dW", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("ksplit", C.c_int32), ("_pad", C.c_int32)]
+
+
+_i32, _i64, _u64, _f32, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+_PROTOS = {
+    "pg_conv": [C.POINTER(ConvDesc), _vp],
+    "pg_conv_wgrad": [C.POINTER(WgradDesc), _vp],
+    "pg_bias_grad": [_vp, _i64, _i64, _i32, _i64, _i64, _i64, _vp, _vp],
+    "pg_norm_stats": [_vp, _i32, _i64, _vp, _vp],
+    "pg_norm_finalize": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
+    "pg_norm_bwd_reduce": [_vp, _vp, _vp, _i32, _i64, _vp, _vp],
+    "pg_norm_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp],
+    "pg_mask_pyramid": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pg_warp_mask_max_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "pg_warp_mask_max_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pg_gan_logloss": [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp],
+    "pg_l1_loss": [_vp, _vp, _i64, _f32, _vp, _vp, _i32, _vp],
+    "pg_tanh_bwd": [_vp, _vp, _i64, _vp],
+    "pg_vgg_conv1_relu_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pg_vgg_conv1_dgrad": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pg_nn_loss": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp],
+    "pg_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
+    "pg_dropout_mask": [_vp, _i64, _u64, _f32, _vp],
+    "pg_nchw_to_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "pg_nhwc_to_nchw": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "pg_apply_affine_act": [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
+    "pg_event_create": [C.POINTER(_vp)],
+    "pg_event_record": [_vp, _vp],
+    "pg_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
+    "pg_event_destroy": [_vp],
+    "pg_version": [],
+}
+EXPORTS = sorted(list(_PROTOS) + ["pg_last_error"])
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen the in-tree library; fail loudly if it is not there (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("libposegan_hip.so not found at %s — run `python __graft_entry__.py` "
+                           "(build()) first; this package has no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.pg_last_error.argtypes = []
+    lib.pg_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().pg_last_error().decode()))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def make_src(t, C_, aff=None, mask=None, strides=None):
+    s = Src()
+    s.ptr = ptr(t)
+    s.C = C_
+    s.aff = ptr(aff)
+    s.mask = ptr(mask)
+    if strides is not None:
+        s.sN, s.sC, s.sH, s.sW = strides
+    return s
+
+
+def make_dst(grad, C_, fwd=None, aff=None, mask=None, act=ACT_NONE, accumulate=False):
+    d = Dst()
+    d.grad = ptr(grad)
+    d.fwd = ptr(fwd)
+    d.aff = ptr(aff)
+    d.mask = ptr(mask)
+    d.C = C_
+    d.act = act
+    d.accumulate = 1 if accumulate else 0
+    return d

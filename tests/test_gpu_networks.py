@@ -1,0 +1,228 @@
+"""GPU parity tests, whole networks and whole training steps: HIP engines vs golden fixtures captured from the
+reference and vs the CPU oracle.  Tolerance (BASELINE.json north_star): generator outputs within 1e-3 max-abs
+(fp32); losses 1e-4 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpu_util import DEV, E, L, R, maxdiff, synth, t
+    from pose_transfer_amd.models.networks import Deformable_Generator, Discriminator
+    from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
+from conftest import GOLDEN
+from types import SimpleNamespace
+
+P = 18
+
+
+def tp(d):
+    return {k: t(v) for k, v in d.items()}
+
+
+def dev(*xs):
+    return [x.to(DEV) for x in xs]
+
+
+@pytest.mark.parametrize("name,size", [("g64", (64, 64)), ("g64x32", (64, 32))])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_generator_forward_vs_golden(name, size, mode):
+    g = np.load(os.path.join(GOLDEN, "generator.npz"))
+    enc, dec = synth.nfilters(size)
+    gen = Deformable_Generator(3 + 2 * P, P, size, enc, dec, "mask")
+    gen.load_state_dict(tp(synth.init_params(21, name, synth.generator_spec(P, enc, dec), norm_jitter=0.2)))
+    inp, tgt, wr, mk = synth.batch(21, name, 2, P, *size)
+    drops = [t(m).to(DEV) for m in synth.dropout_masks(21, name, 2)] if mode == "train" else None
+    gen.training_dropout = mode == "train"
+    with torch.no_grad():
+        out = gen(t(inp).to(DEV), t(wr).to(DEV), t(mk).double().to(DEV), drop_masks=drops)
+    assert maxdiff(out, t(g["%s_%s_out" % (name, mode)])) < 1e-3
+    assert maxdiff(out, t(g["%s_%s_out" % (name, mode)])) < 2e-4      # actual fp32 head-room
+
+
+def test_generator_7level_vs_golden():
+    g = np.load(os.path.join(GOLDEN, "generator.npz"))
+    enc, dec = synth.nfilters((256, 256))
+    gen = Deformable_Generator(3 + 2 * P, P, (128, 128), enc, dec, "mask")
+    gen.load_state_dict(tp(synth.init_params(22, "g128", synth.generator_spec(P, enc, dec), norm_jitter=0.2)))
+    inp, tgt, wr, mk = synth.batch(22, "g128", 2, P, 128, 128)
+    drops = [t(m).to(DEV) for m in synth.dropout_masks(22, "g128", 2)]
+    with torch.no_grad():
+        out = gen(t(inp).to(DEV), t(wr).to(DEV), t(mk).to(DEV), drop_masks=drops)
+    assert maxdiff(out[0], t(g["g128_train_out_n0"])) < 1e-3
+
+
+def test_state_dict_roundtrip_reference_layout():
+    enc, dec = synth.nfilters((64, 64))
+    spec = synth.generator_spec(P, enc, dec)
+    par = tp(synth.init_params(3, "rt", spec, 0.1))
+    gen = Deformable_Generator(3 + 2 * P, P, (64, 64), enc, dec, "mask")
+    gen.load_state_dict(par)
+    sd = gen.state_dict()
+    assert list(sd.keys()) == [k for k, _ in spec]
+    for k, shape in spec:
+        assert tuple(sd[k].shape) == tuple(shape)
+        assert torch.equal(sd[k].cpu(), par[k])
+
+
+def test_generator_backward_vs_oracle():
+    """d(loss)/d(every parameter) through the whole generator, loss = <out, G> (+ autograd module surface)."""
+    size = (64, 64)
+    enc, dec = synth.nfilters(size)
+    spec = synth.generator_spec(P, enc, dec)
+    par = tp(synth.init_params(23, "gb", spec, norm_jitter=0.2))
+    inp, tgt, wr, mk = [t(a) for a in synth.batch(23, "gb", 2, P, *size)]
+    drops = [t(m) for m in synth.dropout_masks(23, "gb", 2)]
+    go = t(synth.normal(23, "gb/go", (2, 3, 64, 64)))
+    pr = {k: v.clone().requires_grad_(True) for k, v in par.items()}
+    out_ref = R.generator_forward(inp, wr, mk, pr, P, enc, dec, size, drops)
+    gref = dict(zip(pr.keys(), torch.autograd.grad((out_ref * go).sum(), list(pr.values()))))
+    gen = Deformable_Generator(3 + 2 * P, P, size, enc, dec, "mask")
+    gen.load_state_dict(par)
+    gen.zero_grad()
+    out = gen(inp.to(DEV), wr.to(DEV), mk.to(DEV), drop_masks=[d.to(DEV) for d in drops])
+    (out * go.to(DEV)).sum().backward()
+    assert maxdiff(out, out_ref) < 2e-4
+    got = gen.arena.grad_dict()
+    bad = []
+    for k in gref:
+        scale = max(float(gref[k].abs().max()), 1e-8)
+        d = (got[k].cpu() - gref[k]).abs()
+        if k.endswith("weight") and gref[k].dim() == 4:
+            ok = float(d.max()) / scale < 2e-3 or (d > 2e-3 * scale).float().mean() < 1e-4   # arg-max tie flips
+        else:
+            ok = float(d.max()) / scale < 2e-2        # scalar gamma/beta + biases: cancelling sums
+        if not ok:
+            bad.append((k, float(d.max()) / scale))
+    assert not bad, bad
+
+
+def test_discriminator_forward_backward():
+    ops = np.load(os.path.join(GOLDEN, "ops.npz"))
+    par = tp(synth.init_params(15, "disc", synth.discriminator_spec(42), norm_jitter=0.2))
+    for key, shape, tag in (("disc_out", (3, 42, 64, 64), "disc/x"), ("disc_out_96x80", (2, 42, 96, 80), "disc/x2")):
+        disc = Discriminator(42, image_size=shape[2:])
+        disc.load_state_dict(par)
+        x = t(synth.uniform(15, tag, shape, -1, 1))
+        xd = x.to(DEV).requires_grad_(True)
+        o = disc(xd)
+        assert maxdiff(o, t(ops[key])) < 2e-5
+        # backward: every parameter + the judged-image slice of the input
+        go = t(synth.normal(15, tag + "/go", tuple(o.shape)))
+        pr = {k: v.clone().requires_grad_(True) for k, v in par.items()}
+        xr = x.clone().requires_grad_(True)
+        oref = R.discriminator_forward(xr, pr)
+        grads = torch.autograd.grad((oref * go).sum(), list(pr.values()) + [xr])
+        disc.zero_grad()
+        (o * go.to(DEV)).sum().backward()
+        got = disc.arena.grad_dict()
+        for (k, _), gr in zip(pr.items(), grads[:-1]):
+            scale = max(float(gr.abs().max()), 1e-8)
+            assert maxdiff(got[k], gr) / scale < (2e-2 if gr.numel() <= 64 else 2e-3), k
+        gx = grads[-1][:, 21:24]
+        assert maxdiff(xd.grad[:, 21:24], gx) / float(gx.abs().max()) < 2e-3
+
+
+def _summ(x):
+    f = x.detach().reshape(-1).double().cpu()
+    idx = torch.linspace(0, f.numel() - 1, 32).long()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item(), f.abs().max().item()], f[idx].numpy()])
+
+
+def _opt(size, content="none", area=1, l1w=100.0, warp_skip="mask", N=2):
+    return SimpleNamespace(image_size=size, use_input_pose=True, pose_dim=P, batch_size=N, num_stacks=4,
+                           gen_type="baseline", dataset="fasion", warp_skip=warp_skip, learning_rate=2e-4,
+                           content_loss_layer=content, nn_loss_area_size=area, gan_penalty_weight=1.0,
+                           l1_penalty_weight=l1w)
+
+
+@pytest.mark.parametrize("name,content,area,l1w", [("step_l1", "none", 1, 100.0), ("step_nn", "block1_conv2", 5, 0.01)])
+def test_two_training_iterations_vs_golden(name, content, area, l1w):
+    """The whole hot path: dis_update + gen_update x2 against tensors captured from the reference."""
+    fix = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H = W = 64
+    N = 2
+    enc, dec = synth.nfilters((H, W))
+    opt = _opt((H, W), content, area, l1w)
+    model = DeformablePose_GAN(opt, device=DEV)
+    model.gen.load_state_dict(tp(synth.init_params(31, name + "/gen", synth.generator_spec(P, enc, dec), 0.1)))
+    model.disc.load_state_dict(tp(synth.init_params(31, name + "/disc", synth.discriminator_spec(42), 0.1)))
+    if content != "none":
+        model.set_vgg_weights(t(synth.xavier_uniform(14, "vgg/w", (64, 3, 3, 3))), t(synth.uniform(14, "vgg/b", (64,), -0.1, 0.1)))
+    od = vars(opt)
+    for it in range(2):
+        bA = dev(*[t(a) for a in synth.batch(31, "%s/it%d/A" % (name, it), N, P, H, W)])
+        bB = dev(*[t(a) for a in synth.batch(31, "%s/it%d/B" % (name, it), N, P, H, W)])
+        bC = dev(*[t(a) for a in synth.batch(31, "%s/it%d/C" % (name, it), N, P, H, W)])
+        dA = dev(*[t(m) for m in synth.dropout_masks(31, "%s/it%d/dA" % (name, it), N)])
+        dC = dev(*[t(m) for m in synth.dropout_masks(31, "%s/it%d/dC" % (name, it), N)])
+        dl = model.dis_update(bA[0], bA[1], {"warps": bA[2], "masks": bA[3], "drop_masks": dA}, bB[0], bB[1], od)
+        np.testing.assert_allclose(dl, fix["it%d_dis_losses" % it], rtol=1e-4 if it == 0 else 2e-3, atol=1e-6)
+        dgrads = model.disc.arena.grad_dict()
+        for k in dgrads:
+            ref = fix["it%d_dgrad_%s" % (it, k)]
+            if it == 0 and not np.all(ref[3:] == ref[3]):
+                assert np.abs(_summ(dgrads[k])[2:] - ref[2:]).max() <= 2e-3 * max(ref[2], 1e-12), k
+        og, _, gl = model.gen_update(bC[0], bC[1], {"warps": bC[2], "masks": bC[3], "drop_masks": dC}, od)
+        np.testing.assert_allclose(gl, fix["it%d_gen_losses" % it], rtol=1e-4 if it == 0 else 2e-3, atol=1e-6)
+        assert maxdiff(og, t(fix["it%d_out_gen" % it])) < 1e-3
+        ggrads = model.gen.arena.grad_dict()
+        gpars = model.gen.state_dict()
+        for k in ggrads:
+            ref = fix["it%d_ggrad_%s" % (it, k)]
+            if it == 0 and not np.all(ref[3:] == ref[3]):
+                assert np.abs(_summ(ggrads[k])[2:] - ref[2:]).max() <= 2e-3 * max(ref[2], 1e-12), k
+            refp = fix["it%d_gpar_%s" % (it, k)]
+            assert np.abs(_summ(gpars[k])[3:] - refp[3:]).max() <= 3 * 2e-4 + 1e-7, k   # Adam moves <= lr per step
+
+
+def test_baseline_step_vs_golden():
+    """BASELINE.json configs[0]: src_baseline Pose_GAN (no warps, one encoder) at 128x64, batch 2."""
+    fix = np.load(os.path.join(GOLDEN, "baseline_step.npz"))
+    H, W, N = 128, 64, 2
+    enc, dec = synth.nfilters((H, W))
+    opt = _opt((H, W), warp_skip="none")
+    model = DeformablePose_GAN(opt, device=DEV)
+    gspec = synth.generator_spec(P, enc, dec, num_skips=1, deformable=False)
+    model.gen.load_state_dict(tp(synth.init_params(41, "base/gen", gspec, 0.1)))
+    model.disc.load_state_dict(tp(synth.init_params(41, "base/disc", synth.discriminator_spec(42), 0.1)))
+    od = vars(opt)
+    bA = dev(*[t(a) for a in synth.batch(41, "base/A", N, P, H, W)])
+    bB = dev(*[t(a) for a in synth.batch(41, "base/B", N, P, H, W)])
+    bC = dev(*[t(a) for a in synth.batch(41, "base/C", N, P, H, W)])
+    dA = dev(*[t(m) for m in synth.dropout_masks(41, "base/dA", N)])
+    dC = dev(*[t(m) for m in synth.dropout_masks(41, "base/dC", N)])
+    dl = model.dis_update(bA[0], bA[1], {"drop_masks": dA}, bB[0], bB[1], od)
+    np.testing.assert_allclose(dl, fix["dis_losses"], rtol=1e-4)
+    og, _, gl = model.gen_update(bC[0], bC[1], {"drop_masks": dC}, od)
+    np.testing.assert_allclose(gl, fix["gen_losses"], rtol=1e-4)
+    assert maxdiff(og, t(fix["out_gen"])) < 1e-3
+
+
+def test_full_size_properties_256():
+    """BASELINE.json configs[1] shape (256x256, P=18, batch 4): too big for the CPU oracle in a test, so check
+    size-independent properties: finite losses, tanh range, determinism of the forward, loss decreases when the
+    same batch is replayed, and the masked-out region of the warp output is >= 0."""
+    H = W = 256
+    N = 4
+    opt = _opt((H, W), N=N)
+    model = DeformablePose_GAN(opt, device=DEV)
+    od = vars(opt)
+    b = dev(*[t(a) for a in synth.batch(77, "full", N, P, H, W)])
+    d = dev(*[t(m) for m in synth.dropout_masks(77, "full", N)])
+    eng = model.gen.engine(N)
+    eng.set_dropout(d)
+    o1 = eng.forward(b[0], b[2], b[3]).clone()
+    o2 = eng.forward(b[0], b[2], b[3]).clone()
+    assert torch.equal(o1, o2) and torch.isfinite(o1).all() and float(o1.abs().max()) <= 1.0
+    assert all(float(w.min()) >= 0.0 for w in eng.w_out)          # masked transforms inject 0 into the max
+    losses = []
+    for _ in range(3):
+        model.dis_update(b[0], b[1], {"warps": b[2], "masks": b[3], "drop_masks": d}, b[0], b[1], od)
+        _, _, gl = model.gen_update(b[0], b[1], {"warps": b[2], "masks": b[3], "drop_masks": d}, od)
+        assert all(np.isfinite(gl))
+        losses.append(gl[1])
+    assert losses[-1] < losses[0]
