@@ -1,0 +1,194 @@
+"""bench.py — GAN train images/sec (one iteration = dis_update + gen_update on 3 independent batches;
+reference src_deformable/main.py:77-108) on synthetic 256x256 data, BASELINE.json configs[1]:
+src_deformable warp_skip=mask, fasion 256x256, 18 key-points, batch 4 per GPU, fp32.
+
+    python bench.py                       # 1 GPU, defaults finish in ~1-2 minutes incl. the CPU baseline
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = global images / second with inputs resident in HBM.
+`roofline`: the dominant contraction kernel family timed per launch with HIP events on the launch stream
+(a separate, un-timed profiled iteration) against the fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+`cpu_baseline`: the CPU oracle (oracle/ref_cpu.py, torch-CPU restatement of the reference) timed on this
+box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import pta_bootstrap  # noqa: E402
+
+pta_bootstrap.load()
+from pose_transfer_amd.models.pose_gan import DeformablePose_GAN  # noqa: E402
+from pose_transfer_amd.runtime import dp  # noqa: E402
+from pose_transfer_amd.runtime import engine as E  # noqa: E402
+from pose_transfer_amd.utils import synth  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+P = 18
+
+
+def make_opt(args):
+    return SimpleNamespace(image_size=(args.size, args.size), use_input_pose=True, pose_dim=P, batch_size=args.batch,
+                           num_stacks=4, gen_type="baseline", dataset="fasion", warp_skip="mask", learning_rate=2e-4,
+                           content_loss_layer=args.content_loss_layer, nn_loss_area_size=args.nn_loss_area_size,
+                           gan_penalty_weight=1.0, l1_penalty_weight=args.l1_penalty_weight)
+
+
+def iteration(model, batches, od):
+    a, b, c = batches
+    model.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3]}, b[0], b[1], od)
+    model.gen_update(c[0], c[1], {"warps": c[2], "masks": c[3]}, od)
+
+
+def step_flops(size, pose_dim):
+    """Algorithmic conv FLOPs per image-iteration = 4 F_G + 8 F_D."""
+    enc, dec = synth.nfilters((size, size))
+    H = size
+    fg = 0.0
+    hw = [(H >> l) ** 2 for l in range(len(enc))]
+    for cin0 in (3 + pose_dim, pose_dim):
+        fg += 2 * enc[0] * hw[0] * cin0 * 9
+        for l in range(1, len(enc)):
+            fg += 2 * enc[l] * hw[l] * enc[l - 1] * 16
+    for i in range(len(dec) - 1):
+        l = len(enc) - 1 - i
+        cin = 2 * enc[l] + (dec[i - 1] if i > 0 else 0)
+        fg += 2 * cin * hw[l] * dec[i] * 16
+    fg += 2 * 3 * hw[0] * (2 * enc[0] + dec[-2]) * 9
+    fd, h, cin = 0.0, size, 3 + 2 * pose_dim + 3
+    for j, co in enumerate((64, 128, 256, 512, 1)):
+        h = (h - 4) // 2 + 1 if j == 0 else (h + 2 - 4) // 2 + 1
+        fd += 2 * co * h * h * cin * 16
+        cin = co
+    return 4 * fg + 8 * fd, fg, fd
+
+
+def cpu_baseline(args):
+    """Oracle (kind 'port') on the host cores: one dis_update + gen_update at the bench resolution, batch 2."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu as R
+    n = 2
+    size = args.size
+    enc, dec = synth.nfilters((size, size))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    cfg = dict(pose_dim=P, image_size=(size, size), batch_size=n, gan_penalty_weight=1.0,
+               l1_penalty_weight=args.l1_penalty_weight, learning_rate=2e-4,
+               content_loss_layer=args.content_loss_layer, nn_loss_area_size=args.nn_loss_area_size,
+               nfilters_enc=enc, nfilters_dec=dec, aten_warp=True)
+    gp = {k: t(v) for k, v in synth.init_params(1, "cpu/gen", synth.generator_spec(P, enc, dec)).items()}
+    dpar = {k: t(v) for k, v in synth.init_params(1, "cpu/disc", synth.discriminator_spec(3 + 2 * P + 3)).items()}
+    vgg = (t(synth.xavier_uniform(14, "vgg/w", (64, 3, 3, 3))), t(synth.uniform(14, "vgg/b", (64,), -0.1, 0.1)))
+    tr = R.Trainer(cfg, gp, dpar, vgg)
+    b = [[t(a) for a in synth.batch(1, "cpu/%s" % s, n, P, size, size)] for s in "ABC"]
+    d = [t(m) for m in synth.dropout_masks(1, "cpu/d", n)]
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    tr.dis_update(b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], d)
+    tr.gen_update(b[2][0], b[2][1], b[2][2], b[2][3], d)
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 iteration (dis_update+gen_update), %dx%d, batch %d, fp32, oracle/ref_cpu.py on torch-CPU "
+                      "(%d threads), %.1f s" % (size, size, n, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE.json configs[1]: 4)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--content_loss_layer", default="none")
+    ap.add_argument("--nn_loss_area_size", type=int, default=1)
+    ap.add_argument("--l1_penalty_weight", type=float, default=100.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = dp.init_from_env()
+    rank = dp.rank()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = "cuda:%d" % local
+    torch.cuda.set_device(device)
+
+    opt = make_opt(args)
+    model = DeformablePose_GAN(opt, device=device, init_seed=0)
+    od = dict(vars(opt), lazy_losses=True)
+    dev = lambda arrs: [torch.from_numpy(a).to(device) for a in arrs]
+    batches = [dev(synth.batch(1234 + rank, "bench/%s" % s, args.batch, P, args.size, args.size)) for s in "ABC"]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        iteration(model, batches, od)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration(model, batches, od)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    global_batch = args.batch * world
+    ips = global_batch * args.steps / elapsed
+
+    # ---- roofline leg: one extra profiled iteration, HIP events around every contraction launch
+    roof = None
+    if not args.no_kernel_profile:
+        E.PROFILER = E.KernelProfiler()
+        iteration(model, batches, od)
+        torch.cuda.synchronize()
+        fam = E.PROFILER.summary()
+        E.PROFILER = None
+        if fam:
+            name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                    "flops_per_launch_avg": d["flops"] / d["launches"],
+                    "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                     "tflops": round(v["flops"] / max(v["ms"], 1e-9) * 1e-9, 2)}
+                                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        sf, fg, fd = step_flops(args.size, P)
+        out = {
+            "metric": "GAN train images/sec (gen+disc step) at %dx%d" % (args.size, args.size),
+            "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "src_deformable warp_skip=mask gen_type=baseline, fasion %dx%d, 18 kpts, batch %d/GPU, "
+                                   "fp32 (BASELINE.json configs[1])" % (args.size, args.size, args.batch),
+                       "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size},
+            "step_tflops": round(sf * ips / 1e12, 2),
+            "step_frac_of_f32_mfma_peak": round(sf * ips / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

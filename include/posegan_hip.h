@@ -186,6 +186,8 @@ int pg_apply_affine_act(const float* x, const float* aff, const float* mask, int
 
 const char* pg_last_error(void);
 int pg_version(void);
+/* diagnostics: tile config | loader modes << 4/8 | split-K << 16 of this thread's last pg_conv / pg_conv_wgrad */
+int pg_last_launch_info(void);
 /* timing helper for bench.py: HIP events on the caller's stream (torch.cuda.Event sees only torch's). */
 int pg_event_create(void** ev);
 int pg_event_record(void* ev, void* stream);

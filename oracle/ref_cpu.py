@@ -190,12 +190,27 @@ def affine_sample(feat, warps, init_size, align_corners=False):
     return out
 
 
+def affine_sample_aten(feat, warps, init_size, align_corners=False):
+    """Same as affine_sample but through the very ATen calls the reference makes (F.affine_grid +
+    F.grid_sample, utils/pose_transform.py:37-39).  Used for the timed CPU baseline (bench.py) so that the
+    baseline pays the reference's cost profile; agrees with the closed form to ~1e-4 (tests/test_oracle_golden.py)."""
+    n, c, h, w = feat.shape
+    t = warps.shape[1]
+    mul = torch.tensor([1, 1, init_size[0] / h, 1, 1, init_size[1] / w, 1, 1], dtype=feat.dtype)
+    wr = (warps.to(feat.dtype) / mul)[..., :6]
+    t00, t01, t02, t10, t11, t12 = normalize_transforms(wr, h, w)
+    theta = torch.stack([t00, t01, t02, t10, t11, t12], -1).view(n * t, 2, 3)
+    x = feat.unsqueeze(1).expand(n, t, c, h, w).reshape(n * t, c, h, w)
+    grid = F.affine_grid(theta, (n * t, c, h, w), align_corners=align_corners)
+    return F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=align_corners).view(n, t, c, h, w)
+
+
 # --------------------------------------------------------------------------------------------- a6
-def warp_mask_max(feat, warps, masks, init_size, align_corners=False):
+def warp_mask_max(feat, warps, masks, init_size, align_corners=False, aten=False):
     """AffineTransformLayer.forward at warp_skip='mask': warp T copies, multiply by the resized masks,
     max over T.  reference utils/pose_transform.py:69-92.  masks: (N,T,H0,W0) at full resolution."""
     n, c, h, w = feat.shape
-    warped = affine_sample(feat, warps, init_size, align_corners)
+    warped = (affine_sample_aten if aten else affine_sample)(feat, warps, init_size, align_corners)
     m = mask_pyramid(masks, h, w).view(n, -1, 1, h, w)
     return (warped * m).max(dim=1)[0]
 
@@ -207,7 +222,7 @@ def split_input(x, pose_dim):
 
 
 def generator_forward(inp, warps, masks, p, pose_dim, nfilters_enc, nfilters_dec, init_size,
-                      drops=None, align_corners=False, return_skips=False):
+                      drops=None, align_corners=False, return_skips=False, aten_warp=False):
     """Deformable_Generator.forward + concatenate_skips: reference models/networks.py:269-288."""
     img, src_pose, tgt_pose = split_input(inp, pose_dim)
     nlev = len(nfilters_enc)
@@ -216,7 +231,7 @@ def generator_forward(inp, warps, masks, p, pose_dim, nfilters_enc, nfilters_dec
     skips = []
     for i, (a, q) in enumerate(zip(sk_app, sk_pose)):
         if i < 4:                                                                  # networks.py:282
-            a = warp_mask_max(a, warps, masks, init_size, align_corners)
+            a = warp_mask_max(a, warps, masks, init_size, align_corners, aten_warp)
         skips.append(torch.cat([a, q], 1))
     out = decoder_forward(skips, p, len(nfilters_dec), drops)
     return (out, sk_app, sk_pose, skips) if return_skips else out
@@ -335,7 +350,8 @@ class Trainer:
         c = self.cfg
         if c.get("deformable", True):
             return generator_forward(inp, warps, masks, gp, c["pose_dim"], self.enc, self.dec,
-                                     c["image_size"], drops, c.get("align_corners", False))
+                                     c["image_size"], drops, c.get("align_corners", False),
+                                     aten_warp=c.get("aten_warp", False))
         return baseline_generator_forward(inp, gp, self.enc, self.dec, drops)
 
     def dis_update(self, inp, target, warps, masks, real_inp, real_target, drops=None, average_fn=None):

@@ -6,8 +6,13 @@ char* err_buf() {
   static thread_local char buf[512] = {0};
   return buf;
 }
+int& last_info() {
+  static thread_local int v = 0;
+  return v;
+}
 }  // namespace pg
 
+extern "C" int pg_last_launch_info(void) { return pg::last_info(); }
 extern "C" const char* pg_last_error(void) { return pg::err_buf(); }
 extern "C" int pg_version(void) { return 100; }
 

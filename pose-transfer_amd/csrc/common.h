@@ -9,6 +9,7 @@
 namespace pg {
 
 char* err_buf();  // thread-local 512-byte message buffer (api.hip)
+int& last_info();  // thread-local: tile config / loader modes / split-K of the last pg_conv / pg_conv_wgrad launch
 
 #define PG_FAIL(code, ...)                          \
   do {                                              \

@@ -495,5 +495,6 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
     default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
+  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16);
   return 0;
 }

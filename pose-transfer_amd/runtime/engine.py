@@ -19,6 +19,52 @@ T_WARPS = 10
 NORM_EPS = 1e-3   # reference models/networks.py:159
 
 
+class KernelProfiler:
+    """Per-launch timing of the contraction kernels with HIP events recorded on the launch stream
+    (bench.py's `roofline` leg).  Not active inside the timed region."""
+
+    CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32"}
+    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64"}
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, kind, flops, fn):
+        import ctypes
+        lib = L.load()
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        L.check(lib.pg_event_create(ctypes.byref(e0)), "pg_event_create")
+        L.check(lib.pg_event_create(ctypes.byref(e1)), "pg_event_create")
+        L.check(lib.pg_event_record(e0, L.stream()), "pg_event_record")
+        fn()
+        L.check(lib.pg_event_record(e1, L.stream()), "pg_event_record")
+        info = lib.pg_last_launch_info()
+        if info & (1 << 30):
+            name = "wgrad_igemm<%s,xs%d,ys%d>" % (self.WGRAD_TILES[info & 15], (info >> 4) & 15, (info >> 8) & 15)
+        else:
+            name = "conv_igemm<%s,A%d,B%d>" % (self.CONV_TILES[info & 15], (info >> 4) & 15, (info >> 8) & 15)
+        self.records.append((name, kind, flops, (info >> 16) & 0x3FFF, e0, e1))
+
+    def summary(self):
+        import ctypes
+        lib = L.load()
+        out = {}
+        for name, kind, flops, ks, e0, e1 in self.records:
+            ms = ctypes.c_float()
+            L.check(lib.pg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "pg_event_elapsed_ms")
+            lib.pg_event_destroy(e0)
+            lib.pg_event_destroy(e1)
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += ms.value
+            d["flops"] += flops
+        self.records = []
+        return out
+
+
+PROFILER = None       # set to a KernelProfiler to time every contraction launch
+
+
 # ------------------------------------------------------------------------------------------ arenas
 def _pack(key, w):
     """reference state_dict tensor -> packed kernel layout [KH][KW][Cout][Cin]."""
@@ -157,6 +203,13 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
             d.dst[i] = t
         d.ndst = len(dsts)
     d.ksplit = ksplit
+    if PROFILER is not None:
+        sp = (Ho * Wo) if mode == 0 else (Hi * Wi)
+        ncnt_ = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
+        kdim = wCout if transposed else wCin
+        PROFILER.launch("conv", 2.0 * N * sp * K * K * kdim * ncnt_,
+                        lambda: L.check(L.load().pg_conv(d, L.stream()), "pg_conv"))
+        return
     L.check(L.load().pg_conv(d, L.stream()), "pg_conv")
 
 
@@ -175,6 +228,10 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
     d.KH, d.KW, d.stride, d.pad = K, K, stride, pad
     d.dW, d.Cout, d.Cin = L.ptr(dW), Cout, Cin
     d.ksplit = ksplit
+    if PROFILER is not None:
+        PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout,
+                        lambda: L.check(L.load().pg_conv_wgrad(d, L.stream()), "pg_conv_wgrad"))
+        return
     L.check(L.load().pg_conv_wgrad(d, L.stream()), "pg_conv_wgrad")
 
 

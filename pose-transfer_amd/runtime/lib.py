@@ -84,6 +84,7 @@ _PROTOS = {
     "pg_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
     "pg_event_destroy": [_vp],
     "pg_version": [],
+    "pg_last_launch_info": [],
 }
 EXPORTS = sorted(list(_PROTOS) + ["pg_last_error"])
 

@@ -27,10 +27,11 @@ def _mix(x):
 
 
 def _stream_key(seed, stream):
-    h = np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x100000001B3)
-    for ch in str(stream).encode():
-        h = ((h ^ np.uint64(ch)) * np.uint64(0x100000001B3)) & _M64
-    return _mix(np.array([h], dtype=np.uint64))[0]
+    with np.errstate(over="ignore"):
+        h = np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x100000001B3)
+        for ch in str(stream).encode():
+            h = ((h ^ np.uint64(ch)) * np.uint64(0x100000001B3)) & _M64
+        return _mix(np.array([h], dtype=np.uint64))[0]
 
 
 def uniform(seed, stream, shape, lo=0.0, hi=1.0, dtype=np.float32):

