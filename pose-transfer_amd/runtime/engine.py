@@ -143,6 +143,12 @@ class ParamArena:
     def grad_dict(self):
         return {k: _unpack(k, self.g(k)) for k, _ in self.spec}
 
+    def moment_dicts(self):
+        """Adam first/second moments in reference layout (tests / checkpointing of optimizer state)."""
+        mv = lambda buf, k: buf[self.off[k]:self.off[k] + self.numel[k]].view(self.pshape[k])
+        return ({k: _unpack(k, mv(self.m, k)) for k, _ in self.spec},
+                {k: _unpack(k, mv(self.v, k)) for k, _ in self.spec})
+
     def zero_grad(self):
         self.grads.zero_()
 
