@@ -66,6 +66,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == PG_ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
   return v;
 }
+// branch-free forms: slope = 0 (ReLU), 0.2 (LeakyReLU), 1 (identity); exact for every finite input
+__device__ __forceinline__ float act_slope(int act) { return act == PG_ACT_RELU ? 0.f : (act == PG_ACT_LEAKY ? 0.2f : 1.f); }
+__device__ __forceinline__ float apply_act_s(float v, float slope) { return fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)); }
+__device__ __forceinline__ float act_grad_s(float z, float slope) { return z > 0.f ? 1.f : slope; }
 __device__ __forceinline__ float act_grad(float z, int act) {
   if (act == PG_ACT_RELU) return z > 0.f ? 1.f : 0.f;
   if (act == PG_ACT_LEAKY) return z > 0.f ? 1.f : 0.2f;

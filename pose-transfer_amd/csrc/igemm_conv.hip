@@ -54,19 +54,25 @@ struct RowInfo {   // per M-row of the block tile, built once in LDS
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-  constexpr int AS = BM + ((AMODE == A_VEC) ? 1 : 1);
-  constexpr int BS = BN + ((BMODE == B_NN) ? 4 : 1);
-  constexpr int A_ROWS = BM / 32;          // rows per thread in vec mode
-  constexpr int B_ROWS = BN / 32;          // NT: rows per thread
-  constexpr int NN_CPR = BN / 4;           // NN: float4 chunks per k-row
+  // LDS layouts: A is [m][k] (row = 32 k's + 4 pad floats): the K-contiguous global float4 lands with ONE ds_write_b128
+  // and an MFMA operand fetch is ONE ds_read_b128 per lane per 4 k-steps (lanes<32 take k..k+3, lanes>=32 k+4..k+7;
+  // row stride 36 floats makes both conflict-free).  B is [n][k] likewise for K-contiguous weights (forward) and
+  // [k][n] for N-contiguous weights (data-gradient: float4 along n, ds_read_b32 per k-step).
+  constexpr int AS = BK + 4;
+  constexpr int BSK = BK + 4;               // [n][k] row stride
+  constexpr int BS = BN + 4;                // [k][n] row stride (B_NN)
+  constexpr bool B_KN = (BMODE == B_NN);
+  constexpr int A_ROWS = BM / 32;           // rows per thread in vec mode
+  constexpr int B_ROWS = BN / 32;           // NT: rows per thread
+  constexpr int NN_CPR = BN / 4;            // NN: float4 chunks per k-row
   constexpr int NN_PASS = 32 / (256 / NN_CPR);
-  constexpr int AS_CNT = 32 / (256 / BM);  // scalar-A elements per thread
-  constexpr int BS_CNT = BN / 8;           // scalar-B elements per thread
+  constexpr int AS_CNT = 32 / (256 / BM);   // scalar-A elements per thread
+  constexpr int BS_CNT = BN / 8;            // scalar-B elements per thread
 
-  __shared__ __attribute__((aligned(16))) float smem[BK * AS + BK * BS + BM * (sizeof(RowInfo) / 4)];
+  __shared__ __attribute__((aligned(16))) float smem[BM * AS + BN * BSK + BM * (sizeof(RowInfo) / 4)];
   float* As = smem;
-  float* Bs = smem + BK * AS;
-  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + BK * AS + BK * BS);
+  float* Bs = smem + BM * AS;
+  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + BM * AS + BN * BSK);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -75,6 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int m0 = blockIdx.x * BM;
   const int nb0 = blockIdx.y * BN;
   const int ntap = p.ntap[phase];
+  const float slope = act_slope(p.act);
 
   if (tid < BM) {
     RowInfo ri;
@@ -130,6 +137,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   float rs[AS_CNT];
   float4 rb[(BMODE == B_NT) ? B_ROWS : (BMODE == B_NN ? NN_PASS : 1)];
   float rbs[BS_CNT];
+  const float* aptr[A_ROWS];
+  const float* mptr[A_ROWS];
+  const float* bptr[(BMODE == B_NT) ? B_ROWS : (BMODE == B_NN ? NN_PASS : 1)];
+  int a_tap = -1, a_src = -1, b_tap = -1;
 
   auto load_tile = [&](int kt) {
     // ------------------------------------------------ A operand
@@ -139,24 +150,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       int j = 0;
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && cc >= p.cstart[q]) j = q;
-      const pg_src_t& s = p.src[j];
-      const int cl = cc - p.cstart[j] + (tid & 7) * 4;
-      const int dyv = p.dy[phase][tap], dxv = p.dx[phase][tap];
-      a_ok = 0;
-      a_has_mask = (s.mask != nullptr);
+      if (tap != a_tap || j != a_src) {
+        // (tap, source) changed: rebuild the per-row pointers / bounds; otherwise they just advance by one K tile
+        const pg_src_t& s = p.src[j];
+        const int cl = cc - p.cstart[j] + (tid & 7) * 4;
+        const int dyv = p.dy[phase][tap], dxv = p.dx[phase][tap];
+        a_ok = 0;
+        a_has_mask = (s.mask != nullptr);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+          const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
+          const bool ok = a_n[i] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+          raa[i] = 1.f; rab[i] = 0.f;
+          aptr[i] = s.ptr; mptr[i] = s.ptr;
+          if (ok) {
+            a_ok |= (1u << i);
+            aptr[i] = s.ptr + ((((long)a_n[i] * p.Hi + iy) * p.Wi + ix) * s.C + cl);
+            if (s.aff) { raa[i] = s.aff[2 * a_n[i]]; rab[i] = s.aff[2 * a_n[i] + 1]; }
+            if (s.mask) mptr[i] = s.mask + ((long)a_n[i] * s.C + cl);
+          }
+        }
+        a_tap = tap; a_src = j;
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) { aptr[i] += BK; mptr[i] += BK; }
+      }
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
-        const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
-        const bool ok = a_n[i] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        raa[i] = 1.f; rab[i] = 0.f;
         rmask[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (ok) {
-          a_ok |= (1u << i);
-          const long idx = (((long)a_n[i] * p.Hi + iy) * p.Wi + ix) * s.C + cl;
-          ra[i] = *reinterpret_cast<const float4*>(s.ptr + idx);
-          if (s.aff) { raa[i] = s.aff[2 * a_n[i]]; rab[i] = s.aff[2 * a_n[i] + 1]; }
-          if (s.mask) rmask[i] = *reinterpret_cast<const float4*>(s.mask + (long)a_n[i] * s.C + cl);
+        if ((a_ok >> i) & 1u) {
+          ra[i] = *reinterpret_cast<const float4*>(aptr[i]);
+          if (a_has_mask) rmask[i] = *reinterpret_cast<const float4*>(mptr[i]);
         }
       }
     } else {
@@ -182,24 +207,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     // ------------------------------------------------ B operand
     if (BMODE == B_NT) {
       const int tap = kt / cpt;
-      const int cc = (kt - tap * cpt) * BK + (tid & 7) * 4;
-      const long base = (long)p.wtap[phase][tap] * p.wCout;
+      if (tap != b_tap) {
+        const int cc = (kt - tap * cpt) * BK + (tid & 7) * 4;
+        const long base = (long)p.wtap[phase][tap] * p.wCout;
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+          const int n = nb0 + (tid >> 3) + 32 * i;
+          bptr[i] = p.W + (base + p.n_off + (n < p.n_cnt ? n : 0)) * p.wCin + cc;
+        }
+        b_tap = tap;
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) bptr[i] += BK;
+      }
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i) {
         const int n = nb0 + (tid >> 3) + 32 * i;
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(p.W + (base + p.n_off + n) * p.wCin + cc);
+        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);
       }
     } else if (BMODE == B_NN) {
       const int tap = kt / cpt;
-      const int cc = (kt - tap * cpt) * BK;
-      const long base = (long)p.wtap[phase][tap] * p.wCout;
+      const int n = nb0 + (tid % NN_CPR) * 4;
+      if (tap != b_tap) {
+        const int cc = (kt - tap * cpt) * BK;
+        const long base = (long)p.wtap[phase][tap] * p.wCout;
+#pragma unroll
+        for (int i = 0; i < NN_PASS; ++i) {
+          const int kr = tid / NN_CPR + i * (256 / NN_CPR);
+          bptr[i] = p.W + (base + cc + kr) * p.wCin + p.n_off + (n < p.n_cnt ? n : 0);
+        }
+        b_tap = tap;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NN_PASS; ++i) bptr[i] += (long)BK * p.wCin;
+      }
 #pragma unroll
       for (int i = 0; i < NN_PASS; ++i) {
-        const int kr = tid / NN_CPR + i * (256 / NN_CPR);
-        const int n = nb0 + (tid % NN_CPR) * 4;
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(p.W + (base + cc + kr) * p.wCin + p.n_off + n);
+        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);
       }
     } else {
 #pragma unroll
@@ -223,7 +269,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   auto store_tile = [&]() {
     if (AMODE == A_VEC) {
-      const int kq = (tid & 7) * 4;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
         float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
@@ -231,26 +276,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         const bool ok = (a_ok >> i) & 1u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = v[e] * raa[i] + rab[i];
-          if (a_has_mask) t *= mk[e];
-          t = apply_act(t, p.act);
-          As[(kq + e) * AS + (tid >> 3) + 32 * i] = ok ? t : 0.f;
+          const float t = apply_act_s((v[e] * raa[i] + rab[i]) * mk[e], slope);
+          v[e] = ok ? t : 0.f;
         }
+        *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * AS + (tid & 7) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < AS_CNT; ++e) As[(s_ksub + e * (256 / BM)) * AS + s_row] = rs[e];
+      for (int e = 0; e < AS_CNT; ++e) As[s_row * AS + s_ksub + e * (256 / BM)] = rs[e];
     }
     if (BMODE == B_NT) {
-      const int kq = (tid & 7) * 4;
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const int nl = (tid >> 3) + 32 * i;
-        Bs[(kq + 0) * BS + nl] = rb[i].x;
-        Bs[(kq + 1) * BS + nl] = rb[i].y;
-        Bs[(kq + 2) * BS + nl] = rb[i].z;
-        Bs[(kq + 3) * BS + nl] = rb[i].w;
-      }
+      for (int i = 0; i < B_ROWS; ++i)
+        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * BSK + (tid & 7) * 4]) = rb[i];
     } else if (BMODE == B_NN) {
 #pragma unroll
       for (int i = 0; i < NN_PASS; ++i) {
@@ -263,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         int kk, nl;
         if (p.w_transposed) { nl = tid % BN; kk = tid / BN + e * (256 / BN); }
         else { kk = tid & 31; nl = (tid >> 5) + 8 * e; }
-        Bs[kk * BS + nl] = rbs[e];
+        Bs[nl * BSK + kk] = rbs[e];
       }
     }
   };
@@ -280,23 +318,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int wn0 = (wave % WGN) * (TN * 32);
   const int l31 = lane & 31, lhi = lane >> 5;
 
+  // operand fetch for k-group g (8 k's): element e pairs k = 8g+e (lanes<32) with k = 8g+4+e (lanes>=32)
+  auto fetch = [&](int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + l31) * AS + g * 8 + lhi * 4]);
+      fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (B_KN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fb[j][e] = Bs[(g * 8 + lhi * 4 + e) * BS + wn0 + j * 32 + l31];
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + j * 32 + l31) * BSK + g * 8 + lhi * 4]);
+        fb[j][0] = v.x; fb[j][1] = v.y; fb[j][2] = v.z; fb[j][3] = v.w;
+      }
+    }
+  };
+
   if (kt0 < kt1) load_tile(kt0);
   for (int kt = kt0; kt < kt1; ++kt) {
     store_tile();
     __syncthreads();
     if (kt + 1 < kt1) load_tile(kt + 1);
-#pragma unroll 4
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
+    float fa[2][TM][4], fb[2][TN][4];
+    fetch(0, fa[0], fb[0]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[(kk + lhi) * AS + wm0 + i * 32 + l31];
+    for (int g = 0; g < BK / 8; ++g) {
+      if (g + 1 < BK / 8) fetch(g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lhi) * BS + wn0 + j * 32 + l31];
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -307,37 +364,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const RowInfo ri = rows[row];
-      if (ri.n < 0) continue;
+    for (int j = 0; j < TN; ++j) {
+      const int ng = nb0 + wn0 + j * 32 + l31;
+      const bool nval = ng < p.n_cnt;
+      if (p.epilogue == 0) {
+        const float bv = (p.bias && split == 0 && nval) ? p.bias[ng] : 0.f;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int ng = nb0 + wn0 + j * 32 + l31;
-        if (ng >= p.n_cnt) continue;
-        float g = acc[i][j][r];
-        if (p.epilogue == 0) {
-          if (p.bias && split == 0) g += p.bias[ng];
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const RowInfo ri = rows[row];
+          if (ri.n < 0 || !nval) continue;
+          float g = acc[i][j][r] + bv;
           if (p.out_act == PG_OUT_TANH) g = tanhf(g);
           float* o = p.out + ri.off + (long)ng * p.oC;
           if (atomic) atomicAdd(o, g); else *o = g;
-        } else {
-          int d = 0;
+        }
+      } else {
+        int d = 0;
 #pragma unroll
-          for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.ndst && ng >= p.dstart[q]) d = q;
-          const pg_dst_t& ds = p.dst[d];
-          const int c = ng - p.dstart[d];
-          const long idx = (long)ri.pix * ds.C + c;
-          const float mk = ds.mask ? ds.mask[(long)ri.n * ds.C + c] : 1.f;
-          if (ds.fwd) {
-            float z = ds.fwd[idx];
-            if (ds.aff) z = z * ds.aff[2 * ri.n] + ds.aff[2 * ri.n + 1];
-            g *= act_grad(z * mk, ds.act);
+        for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.ndst && ng >= p.dstart[q]) d = q;
+        const pg_dst_t& ds = p.dst[d];
+        const int c = ng - p.dstart[d];
+        const float dslope = act_slope(ds.act);
+        // batch the forward-tensor loads of the 16 rows before any dependent store (latency, not bandwidth, bound)
+        float fz[16], mk[16];
+        long idx[16];
+        int rn[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const RowInfo ri = rows[row];
+          rn[r] = nval ? ri.n : -1;
+          idx[r] = (long)ri.pix * ds.C + c;
+          fz[r] = 0.f; mk[r] = 1.f;
+          if (rn[r] >= 0) {
+            if (ds.fwd) {
+              fz[r] = ds.fwd[idx[r]];
+              if (ds.aff) fz[r] = fz[r] * ds.aff[2 * rn[r]] + ds.aff[2 * rn[r] + 1];
+            }
+            if (ds.mask) mk[r] = ds.mask[(long)rn[r] * ds.C + c];
           }
-          g *= mk;
-          if (atomic) atomicAdd(ds.grad + idx, g);
-          else if (ds.accumulate) ds.grad[idx] += g;
-          else ds.grad[idx] = g;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (rn[r] < 0) continue;
+          float g = acc[i][j][r];
+          if (ds.fwd) g *= act_grad_s(fz[r] * mk[r], dslope);
+          g *= mk[r];
+          if (atomic) atomicAdd(ds.grad + idx[r], g);
+          else if (ds.accumulate) ds.grad[idx[r]] += g;
+          else ds.grad[idx[r]] = g;
         }
       }
     }

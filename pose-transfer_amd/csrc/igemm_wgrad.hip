@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   const int kper = (nkt + p.ksplit - 1) / p.ksplit;
   const int kt0 = split * kper, kt1 = min(nkt, kt0 + kper);
   if (kt0 >= kt1) return;
+  const float slope = act_slope(p.act);
 
   // source of this ci tile (vec mode: a tile never straddles sources)
   int jsrc = 0;
@@ -181,9 +182,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
         const float mk[4] = {rbm[i].x, rbm[i].y, rbm[i].z, rbm[i].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = v[e] * rba[i] + rbb[i];
-          if (hm) t *= mk[e];
-          t = apply_act(t, p.act);
+          const float t = apply_act_s((v[e] * rba[i] + rbb[i]) * mk[e], slope);
           v[e] = ok ? t : 0.f;
         }
         *reinterpret_cast<float4*>(&Bs[pr * BS + (tid % B_CPR) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
@@ -209,23 +208,36 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   const int l31 = lane & 31, lhi = lane >> 5;
   constexpr int KSPAN = WBK / WGK;
 
+  // operand fetch for k-group g (8 pixels of this wave's K span), register double-buffered against the MFMAs
+  constexpr int NG = KSPAN / 8;
+  auto fetch = [&](int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = wk * KSPAN + g * 8 + lhi * 4 + e;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i][e] = As[kk * AS + wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j][e] = Bs[kk * BS + wn0 + j * 32 + l31];
+    }
+  };
+
   load_tile(kt0);
   for (int kt = kt0; kt < kt1; ++kt) {
     store_tile();
     __syncthreads();
     if (kt + 1 < kt1) load_tile(kt + 1);
-#pragma unroll 4
-    for (int kk = wk * KSPAN; kk < (wk + 1) * KSPAN; kk += 2) {
-      float a[TM], b[TN];
+    float fa[2][TM][4], fb[2][TN][4];
+    fetch(0, fa[0], fb[0]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[(kk + lhi) * AS + wm0 + i * 32 + l31];
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) fetch(g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lhi) * BS + wn0 + j * 32 + l31];
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
