@@ -534,13 +534,17 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   }
   int ks = d->ksplit;
   if (ks <= 0) {
+    // Split K so that (a) there are >= 2 workgroups per CU to overlap each other's barriers and (b) the grid is
+    // close to a multiple of the 256 CUs (MFMA throughput is per CU: 384 blocks on 256 CUs would idle 25 %).
     const long blocks = (long)mt * nt * k.nphase;
+    const int kmax = ktot_min / 8 > 0 ? ktot_min / 8 : 1;
     ks = 1;
-    if (blocks < 384) {
-      ks = (int)((512 + blocks - 1) / blocks);
-      const int kmax = ktot_min / 4 > 0 ? ktot_min / 4 : 1;
-      if (ks > kmax) ks = kmax;
-      if (ks > 64) ks = 64;
+    double best = -1.0;
+    for (int c = 1; c <= 32 && c <= kmax; ++c) {
+      const long b = blocks * c;
+      const double eff = (double)b / (double)(((b + 255) / 256) * 256);
+      const double score = (b >= 512 ? eff : eff * (double)b / 512.0) - 0.004 * c;
+      if (score > best + 1e-9) { best = score; ks = c; }
     }
   }
   if (d->out_act != PG_OUT_NONE) ks = 1;

@@ -30,6 +30,7 @@ struct WgradK {
 };
 
 struct Pix { int n, sy, sx, ly, lx; bool lok; };
+struct PixState { int n, sy, sx; };   // small-grid pixel of one tile row, advanced by 32 pixels per K tile
 
 __device__ __forceinline__ Pix decode_pix(const WgradK& p, int k, int r, int s) {
   Pix q;
@@ -40,6 +41,31 @@ __device__ __forceinline__ Pix decode_pix(const WgradK& p, int k, int r, int s) 
   q.sx = rem - q.sy * p.Ws;
   q.ly = q.sy * p.stride + r - p.pad;
   q.lx = q.sx * p.stride + s - p.pad;
+  q.lok = q.ly >= 0 && q.ly < p.Hl && q.lx >= 0 && q.lx < p.Wl;
+  return q;
+}
+
+__device__ __forceinline__ PixState pix_init(const WgradK& p, int k) {
+  PixState st;
+  const int hw = p.Hs * p.Ws;
+  st.n = k / hw;
+  const int rem = k - st.n * hw;
+  st.sy = rem / p.Ws;
+  st.sx = rem - st.sy * p.Ws;
+  return st;
+}
+__device__ __forceinline__ void pix_advance(const WgradK& p, PixState& st, int advy, int advx) {
+  st.sx += advx;
+  st.sy += advy;
+  if (st.sx >= p.Ws) { st.sx -= p.Ws; st.sy += 1; }
+  if (st.sy >= p.Hs) { const int q = st.sy / p.Hs; st.n += q; st.sy -= q * p.Hs; }
+}
+__device__ __forceinline__ Pix pix_of(const WgradK& p, const PixState& st, int r, int s) {
+  Pix q;
+  q.n = st.n < p.N ? st.n : -1;
+  q.sy = st.sy; q.sx = st.sx;
+  q.ly = st.sy * p.stride + r - p.pad;
+  q.lx = st.sx * p.stride + s - p.pad;
   q.lok = q.ly >= 0 && q.ly < p.Hl && q.lx >= 0 && q.lx < p.Wl;
   return q;
 }
@@ -67,6 +93,16 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   const int kt0 = split * kper, kt1 = min(nkt, kt0 + kper);
   if (kt0 >= kt1) return;
   const float slope = act_slope(p.act);
+  const int advy = WBK / p.Ws, advx = WBK - advy * p.Ws;
+  PixState a_st[YS ? 1 : A_PASS], b_st[XS ? 1 : B_PASS];
+  if (!YS) {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) a_st[i] = pix_init(p, kt0 * WBK + tid / A_CPR + i * (256 / A_CPR));
+  } else a_st[0] = pix_init(p, kt0 * WBK + (tid & 31));
+  if (!XS) {
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) b_st[i] = pix_init(p, kt0 * WBK + tid / B_CPR + i * (256 / B_CPR));
+  } else b_st[0] = pix_init(p, kt0 * WBK + (tid & 31));
 
   // source of this ci tile (vec mode: a tile never straddles sources)
   int jsrc = 0;
@@ -81,26 +117,23 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   float ras[YS ? A_SC : 1];
   float rbs[XS ? B_SC : 1];
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int /*kt: tiles are visited in order, pixel state advances*/) {
     // ---------------- A = dY  [pixel][co]
     if (!YS) {
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
-        const int pr = tid / A_CPR + i * (256 / A_CPR);
-        const int k = kt * WBK + pr;
         const int co = co0 + (tid % A_CPR) * 4;
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < p.Kpix && co < p.Cout) {
-          const Pix q = decode_pix(p, k, r, s);
+        const Pix q = pix_of(p, a_st[i], r, s);
+        pix_advance(p, a_st[i], advy, advx);
+        if (q.n >= 0 && co < p.Cout) {
           if (p.x_is_large) ra[i] = *reinterpret_cast<const float4*>(p.dY + (((long)q.n * p.Hs + q.sy) * p.Ws + q.sx) * p.Cout + co);
           else if (q.lok) ra[i] = *reinterpret_cast<const float4*>(p.dY + (((long)q.n * p.Hl + q.ly) * p.Wl + q.lx) * p.Cout + co);
         }
       }
     } else {
-      const int pl = tid & 31;
-      const int k = kt * WBK + pl;
-      Pix q; q.n = -1;
-      if (k < p.Kpix) q = decode_pix(p, k, r, s);
+      const Pix q = pix_of(p, a_st[0], r, s);
+      pix_advance(p, a_st[0], advy, advx);
 #pragma unroll
       for (int e = 0; e < A_SC; ++e) {
         const int co = co0 + (tid >> 5) + 8 * e;
@@ -119,13 +152,12 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
       b_ok = 0;
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) {
-        const int pr = tid / B_CPR + i * (256 / B_CPR);
-        const int k = kt * WBK + pr;
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         rbm[i] = make_float4(1.f, 1.f, 1.f, 1.f);
         rba[i] = 1.f; rbb[i] = 0.f;
-        if (k < p.Kpix) {
-          const Pix q = decode_pix(p, k, r, s);
+        const Pix q = pix_of(p, b_st[i], r, s);
+        pix_advance(p, b_st[i], advy, advx);
+        if (q.n >= 0) {
           const bool ok = p.x_is_large ? q.lok : true;
           if (ok) {
             b_ok |= 1u << i;
@@ -138,10 +170,8 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
         }
       }
     } else {
-      const int pl = tid & 31;
-      const int k = kt * WBK + pl;
-      Pix q; q.n = -1;
-      if (k < p.Kpix) q = decode_pix(p, k, r, s);
+      const Pix q = pix_of(p, b_st[0], r, s);
+      pix_advance(p, b_st[0], advy, advx);
 #pragma unroll
       for (int e = 0; e < B_SC; ++e) {
         const int ci = ci0 + (tid >> 5) + 8 * e;
@@ -285,16 +315,19 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   PG_REQUIRE(kp > 0 && kp < (1L << 31), "pg_conv_wgrad: pixel count out of range");
   k.Kpix = (int)kp;
   const int xs = d->scalar_x ? 1 : 0, ys = d->scalar_y ? 1 : 0;
-  int cfg;  // 0: 128x64, 1: 64x64, 2: 32x64 (intra-block split-K)
+  int cfg;  // 0: 128x64, 1: 64x64, 2: 32x64 (intra-block split-K), 3: 128x128
+  bool all128 = !xs;
+  for (int j = 0; j < d->nsrc; ++j) all128 = all128 && (d->src[j].C % 128 == 0);
   if (ys || d->Cout <= 32) cfg = 2;
-  else if (d->Cout % 128 == 0) cfg = 0;
+  else if (d->Cout % 128 == 0) cfg = all128 ? 3 : 0;
   else cfg = 1;
   if (!xs)
     for (int j = 0; j < d->nsrc; ++j)
       PG_REQUIRE(d->src[j].C % 64 == 0, "pg_conv_wgrad: vec X needs C%%64==0 (src %d has %d)", j, d->src[j].C);
   if (!ys) PG_REQUIRE(d->Cout % 4 == 0, "pg_conv_wgrad: vec dY needs Cout%%4==0");
-  const int BMs[3] = {128, 64, 32};
-  const int mt = cdiv(d->Cout, BMs[cfg]), nt = cdiv(ctot, 64);
+  const int BMs[4] = {128, 64, 32, 128};
+  const int BNw = cfg == 3 ? 128 : 64;
+  const int mt = cdiv(d->Cout, BMs[cfg]), nt = cdiv(ctot, BNw);
   const int nkt = cdiv(kp, WBK);
   int ks = d->ksplit;
   if (ks <= 0) {
@@ -309,7 +342,9 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   dim3 grid(nt, mt, k.ntaps * ks);
 #define PG_WG(BM, WGM, WGN, WGK, XS, YS) \
   hipLaunchKernelGGL((wgrad_igemm_kernel<BM, 64, WGM, WGN, WGK, XS, YS>), grid, dim3(256), 0, st, k)
-  if (cfg == 0) {
+  if (cfg == 3) {
+    hipLaunchKernelGGL((wgrad_igemm_kernel<128, 128, 2, 2, 1, 0, 0>), grid, dim3(256), 0, st, k);
+  } else if (cfg == 0) {
     PG_REQUIRE(!xs && !ys, "pg_conv_wgrad: scalar operands need Cout<=64");
     PG_WG(128, 2, 2, 1, 0, 0);
   } else if (cfg == 1) {
