@@ -108,10 +108,25 @@ typedef struct {
   float* dW;                /* packed [KH][KW][Cout][Cin]                                          */
   int32_t Cout, Cin;
   int32_t ksplit;           /* 0 = auto                                                            */
-  int32_t _pad;
+  int32_t cout_store;       /* 0 = Cout; else only rows co < cout_store of dW (row stride Cin) are written    */
 } pg_wgrad_t;
 
 int pg_conv_wgrad(const pg_wgrad_t* desc, void* stream);
+
+/* ---- small-N edge layers (the generator's 256->3 output convolution, models/networks.py:228), re-associated so
+ * that no MFMA tile is 29/32 empty (csrc/edge.hip):
+ * tap_gather:  out[n,co,y,x] = act(bias[co] + sum_{r,s} Y[n,y+r-pad,x+s-pad,(r*KW+s)*Co+co]) after a 1x1 pg_conv;
+ * im2col_taps: G[n,y,x,(r*KW+s)*C+c] = dY[n,c,y-(r-pad),x-(s-pad)], zero padded to Cpad channels (wgrad operand);
+ * small_cout_dgrad: dX[p][ci] = sum_{tap,co} dY[p-off(tap)][co]*W[tap][co][ci], split over dst[] like pg_conv's
+ *              data-gradient epilogue (K = taps*Co is tiny: an HBM-bound streaming kernel).                     */
+int pg_tap_gather(const float* Y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co,
+                  const float* bias, int32_t out_act, float* out, int64_t oN, int64_t oC, int64_t oH, int64_t oW,
+                  void* stream);
+int pg_im2col_taps(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H, int32_t W,
+                   int32_t KH, int32_t KW, int32_t pad, int32_t C, int32_t Cpad, float* G, void* stream);
+int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H,
+                        int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co, const float* Wt,
+                        const pg_dst_t* dst, int32_t ndst, void* stream);
 
 /* db[c] += sum over rows of a strided [rows][C] view (bias gradient; torch autograd of conv bias). */
 int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,

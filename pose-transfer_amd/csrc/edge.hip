@@ -1,0 +1,179 @@
+// Edge-layer kernels (gfx950): the 256->3 output convolution of the generator (reference models/networks.py:228:
+// ReLU -> Conv2d(k3,p1,bias) -> Tanh) has GEMM-N = 3, which wastes 29/32 of an MFMA tile.  It is re-associated as
+//   forward : Y[p][(tap,co)] = W[tap][co][:] . x[p][:]   (a 1x1 convolution with N = 27 -> pg_conv, 84 % tile use)
+//             out[q][co]     = tanh(b[co] + sum_tap Y[q+off(tap)][(tap,co)])          (pg_tap_gather, HBM-bound, 28 MB)
+//   wgrad   : G[p][(tap,co)] = dY[p-off(tap)][co]                                     (pg_im2col_taps, 28 MB)
+//             dW[(tap,co)][ci] = sum_p G[p][(tap,co)] * x[p][ci]                      (pg_conv_wgrad as a 1x1, M = 27)
+//   dgrad   : dX[p][ci] = sum_{tap,co} dY[p-off(tap)][co] * W[tap][co][ci]            (pg_small_cout_dgrad: K = 27 only,
+//             so this is an HBM-bound streaming kernel: read fwd + write dz = 8 B per element)
+#include "common.h"
+
+namespace pg {
+
+// out[n,co,y,x] = act(bias[co] + sum_{r,s} Y[n, y+r-pad, x+s-pad, (r*KW+s)*Co + co]);  Y NHWC with T*Co channels
+__global__ __launch_bounds__(256) void tap_gather_kernel(const float* Y, int N, int H, int W, int KH, int KW, int pad,
+                                                         int Co, const float* bias, int out_act, float* out, long oN,
+                                                         long oC, long oH, long oW) {
+  const long total = (long)N * H * W;
+  const int CT = KH * KW * Co;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const long r0 = i / W;
+    const int y = (int)(r0 % H);
+    const int n = (int)(r0 / H);
+    for (int co = 0; co < Co; ++co) {
+      float acc = bias ? bias[co] : 0.f;
+      for (int r = 0; r < KH; ++r) {
+        const int yy = y + r - pad;
+        if (yy < 0 || yy >= H) continue;
+        for (int s = 0; s < KW; ++s) {
+          const int xx = x + s - pad;
+          if (xx < 0 || xx >= W) continue;
+          acc += Y[(((long)n * H + yy) * W + xx) * CT + (r * KW + s) * Co + co];
+        }
+      }
+      if (out_act == PG_OUT_TANH) acc = tanhf(acc);
+      out[(long)n * oN + (long)co * oC + (long)y * oH + (long)x * oW] = acc;
+    }
+  }
+}
+
+// G[n,y,x,(r*KW+s)*C + c] = dY[n,c,y-(r-pad),x-(s-pad)] (0 outside), channels [T*C, Cpad) zero-filled
+__global__ __launch_bounds__(256) void im2col_taps_kernel(const float* dY, long yN, long yC, long yH, long yW, int N,
+                                                          int H, int W, int KH, int KW, int pad, int C, int Cpad,
+                                                          float* G) {
+  const long total = (long)N * H * W * Cpad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Cpad);
+    long r0 = i / Cpad;
+    const int x = (int)(r0 % W); r0 /= W;
+    const int y = (int)(r0 % H);
+    const int n = (int)(r0 / H);
+    float v = 0.f;
+    if (k < KH * KW * C) {
+      const int tap = k / C, c = k - tap * C;
+      const int r = tap / KW, s = tap - r * KW;
+      const int yy = y - (r - pad), xx = x - (s - pad);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = dY[(long)n * yN + (long)c * yC + (long)yy * yH + (long)xx * yW];
+    }
+    G[i] = v;
+  }
+}
+
+struct SmallDgradK {
+  const float* dY; long yN, yC, yH, yW;
+  int N, H, W, KH, KW, pad, Co, Ctot;
+  const float* Wt;                 // packed [KH][KW][Co][Ctot]
+  pg_dst_t dst[PG_MAX_SRC];
+  int ndst;
+  int dstart[PG_MAX_SRC + 1];
+};
+
+__global__ __launch_bounds__(256) void small_cout_dgrad_kernel(const SmallDgradK p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];     // KH*KW*Co*Ctot floats
+  const int wn = p.KH * p.KW * p.Co * p.Ctot;
+  for (int i = threadIdx.x * 4; i < wn; i += 256 * 4)
+    *reinterpret_cast<float4*>(&wl[i]) = *reinterpret_cast<const float4*>(&p.Wt[i]);
+  __syncthreads();
+  const int cpp = p.Ctot >> 2;     // float4 chunks per pixel
+  const long items = (long)p.N * p.H * p.W * cpp;
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const int cg = (int)(it % cpp) * 4;
+    const long pix = it / cpp;
+    const int x = (int)(pix % p.W);
+    const long r0 = pix / p.W;
+    const int y = (int)(r0 % p.H);
+    const int n = (int)(r0 / p.H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < p.KH; ++r) {
+      const int yy = y - (r - p.pad);
+      if (yy < 0 || yy >= p.H) continue;
+      for (int s = 0; s < p.KW; ++s) {
+        const int xx = x - (s - p.pad);
+        if (xx < 0 || xx >= p.W) continue;
+        for (int co = 0; co < p.Co; ++co) {
+          const float g = p.dY[(long)n * p.yN + (long)co * p.yC + (long)yy * p.yH + (long)xx * p.yW];
+          const float4 w = *reinterpret_cast<const float4*>(&wl[((r * p.KW + s) * p.Co + co) * p.Ctot + cg]);
+          acc.x += g * w.x; acc.y += g * w.y; acc.z += g * w.z; acc.w += g * w.w;
+        }
+      }
+    }
+    int d = 0;
+#pragma unroll
+    for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.ndst && cg >= p.dstart[q]) d = q;
+    const pg_dst_t& ds = p.dst[d];
+    const int c = cg - p.dstart[d];
+    const long idx = pix * ds.C + c;
+    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (ds.mask) mk = *reinterpret_cast<const float4*>(ds.mask + (long)n * ds.C + c);
+    float g4[4] = {acc.x, acc.y, acc.z, acc.w};
+    const float m4[4] = {mk.x, mk.y, mk.z, mk.w};
+    if (ds.fwd) {
+      const float4 f = *reinterpret_cast<const float4*>(ds.fwd + idx);
+      const float a = ds.aff ? ds.aff[2 * n] : 1.f, b = ds.aff ? ds.aff[2 * n + 1] : 0.f;
+      const float f4[4] = {f.x, f.y, f.z, f.w};
+      const float slope = act_slope(ds.act);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g4[e] *= act_grad_s((f4[e] * a + b) * m4[e], slope);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g4[e] *= m4[e];
+    float4* o = reinterpret_cast<float4*>(ds.grad + idx);
+    if (ds.accumulate) { const float4 old = *o; g4[0] += old.x; g4[1] += old.y; g4[2] += old.z; g4[3] += old.w; }
+    *o = make_float4(g4[0], g4[1], g4[2], g4[3]);
+  }
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_tap_gather(const float* Y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad,
+                             int32_t Co, const float* bias, int32_t out_act, float* out, int64_t oN, int64_t oC,
+                             int64_t oH, int64_t oW, void* stream) {
+  PG_REQUIRE(Y && out && N > 0 && Co > 0, "pg_tap_gather: bad arguments");
+  long blocks = ((long)N * H * W + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(tap_gather_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, Y, N, H, W, KH, KW, pad, Co,
+                     bias, out_act, out, (long)oN, (long)oC, (long)oH, (long)oW);
+  PG_LAUNCH_OK("pg_tap_gather");
+  return 0;
+}
+
+extern "C" int pg_im2col_taps(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H,
+                              int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t C, int32_t Cpad, float* G,
+                              void* stream) {
+  PG_REQUIRE(dY && G && N > 0 && Cpad >= KH * KW * C, "pg_im2col_taps: bad arguments");
+  long blocks = ((long)N * H * W * Cpad + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(im2col_taps_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
+                     (long)yH, (long)yW, N, H, W, KH, KW, pad, C, Cpad, G);
+  PG_LAUNCH_OK("pg_im2col_taps");
+  return 0;
+}
+
+extern "C" int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H,
+                                   int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co, const float* Wt,
+                                   const pg_dst_t* dst, int32_t ndst, void* stream) {
+  PG_REQUIRE(dY && Wt && dst && ndst >= 1 && ndst <= PG_MAX_SRC, "pg_small_cout_dgrad: bad arguments");
+  SmallDgradK k;
+  memset(&k, 0, sizeof(k));
+  k.dY = dY; k.yN = yN; k.yC = yC; k.yH = yH; k.yW = yW;
+  k.N = N; k.H = H; k.W = W; k.KH = KH; k.KW = KW; k.pad = pad; k.Co = Co; k.Wt = Wt;
+  int c = 0;
+  for (int j = 0; j < ndst; ++j) {
+    k.dst[j] = dst[j]; k.dstart[j] = c; c += dst[j].C;
+    PG_REQUIRE(dst[j].C % 4 == 0, "pg_small_cout_dgrad: destination channels must be multiples of 4");
+  }
+  for (int j = ndst; j <= PG_MAX_SRC; ++j) k.dstart[j] = c;
+  k.ndst = ndst; k.Ctot = c;
+  const size_t lds = sizeof(float) * (size_t)KH * KW * Co * c;
+  PG_REQUIRE(lds <= 160 * 1024 && (KH * KW * Co * c) % 4 == 0, "pg_small_cout_dgrad: weight tile does not fit LDS");
+  if (lds > 64 * 1024)
+    PG_HIP(hipFuncSetAttribute((const void*)small_cout_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  long blocks = ((long)N * H * W * (c / 4) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;      // each block stages the weights once: keep blocks long-lived
+  hipLaunchKernelGGL(small_cout_dgrad_kernel, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, k);
+  PG_LAUNCH_OK("pg_small_cout_dgrad");
+  return 0;
+}

@@ -26,7 +26,7 @@ struct WgradK {
   int Hs, Ws, Hl, Wl;
   int KW, stride, pad;
   float* dW;
-  int ksplit, Kpix, ntaps;
+  int ksplit, Kpix, ntaps, cout_store;
 };
 
 struct Pix { int n, sy, sx, ly, lx; bool lok; };
@@ -117,18 +117,21 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   float ras[YS ? A_SC : 1];
   float rbs[XS ? B_SC : 1];
 
-  auto load_tile = [&](int /*kt: tiles are visited in order, pixel state advances*/) {
+  auto load_tile = [&](int kt) {   // tiles are visited in order: the pixel states advance by one tile per call
     // ---------------- A = dY  [pixel][co]
     if (!YS) {
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
         const int co = co0 + (tid % A_CPR) * 4;
         ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const Pix q = pix_of(p, a_st[i], r, s);
-        pix_advance(p, a_st[i], advy, advx);
-        if (q.n >= 0 && co < p.Cout) {
-          if (p.x_is_large) ra[i] = *reinterpret_cast<const float4*>(p.dY + (((long)q.n * p.Hs + q.sy) * p.Ws + q.sx) * p.Cout + co);
-          else if (q.lok) ra[i] = *reinterpret_cast<const float4*>(p.dY + (((long)q.n * p.Hl + q.ly) * p.Wl + q.lx) * p.Cout + co);
+        if (p.x_is_large) {      // dY is the small tensor: dense [pixel][co], no coordinates needed
+          const int k = kt * WBK + tid / A_CPR + i * (256 / A_CPR);
+          if (k < p.Kpix && co < p.Cout) ra[i] = *reinterpret_cast<const float4*>(p.dY + (long)k * p.Cout + co);
+        } else {
+          const Pix q = pix_of(p, a_st[i], r, s);
+          pix_advance(p, a_st[i], advy, advx);
+          if (q.n >= 0 && q.lok && co < p.Cout)
+            ra[i] = *reinterpret_cast<const float4*>(p.dY + (long)((q.n * p.Hl + q.ly) * p.Wl + q.lx) * p.Cout + co);
         }
       }
     } else {
@@ -155,17 +158,17 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
         rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         rbm[i] = make_float4(1.f, 1.f, 1.f, 1.f);
         rba[i] = 1.f; rbb[i] = 0.f;
-        const Pix q = pix_of(p, b_st[i], r, s);
+        const Pix q = pix_of(p, b_st[i], r, s);       // the sample index is needed for aff/mask either way
         pix_advance(p, b_st[i], advy, advx);
         if (q.n >= 0) {
           const bool ok = p.x_is_large ? q.lok : true;
           if (ok) {
             b_ok |= 1u << i;
-            const long pixidx = p.x_is_large ? (((long)q.n * p.Hl + q.ly) * p.Wl + q.lx)
-                                             : (((long)q.n * p.Hs + q.sy) * p.Ws + q.sx);
-            rb[i] = *reinterpret_cast<const float4*>(sx.ptr + pixidx * sx.C + cl);
+            const int pixidx = p.x_is_large ? ((q.n * p.Hl + q.ly) * p.Wl + q.lx)
+                                            : (kt * WBK + tid / B_CPR + i * (256 / B_CPR));
+            rb[i] = *reinterpret_cast<const float4*>(sx.ptr + (long)pixidx * sx.C + cl);
             if (sx.aff) { rba[i] = sx.aff[2 * q.n]; rbb[i] = sx.aff[2 * q.n + 1]; }
-            if (sx.mask) rbm[i] = *reinterpret_cast<const float4*>(sx.mask + (long)q.n * sx.C + cl);
+            if (sx.mask) rbm[i] = *reinterpret_cast<const float4*>(sx.mask + q.n * sx.C + cl);
           }
         }
       }
@@ -278,12 +281,12 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int co = co0 + wm0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
-      if (co >= p.Cout) continue;
+      if (co >= p.cout_store) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int ci = ci0 + wn0 + j * 32 + l31;
         if (ci >= p.Ctot) continue;
-        float* o = p.dW + ((long)tap * p.Cout + co) * p.Ctot + ci;
+        float* o = p.dW + ((long)tap * p.cout_store + co) * p.Ctot + ci;
         if (atomic) atomicAdd(o, acc[i][j][q]); else *o += acc[i][j][q];
       }
     }
@@ -311,6 +314,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   k.Hs = d->Hs; k.Ws = d->Ws; k.Hl = d->Hl; k.Wl = d->Wl;
   k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dW = d->dW;
   k.ntaps = d->KH * d->KW;
+  k.cout_store = d->cout_store > 0 ? d->cout_store : d->Cout;
   const long kp = (long)d->N * d->Hs * d->Ws;
   PG_REQUIRE(kp > 0 && kp < (1L << 31), "pg_conv_wgrad: pixel count out of range");
   k.Kpix = (int)kp;

@@ -11,7 +11,7 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(LIBDIR, "libposegan_hip.so")
-SOURCES = ["api.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "igemm_conv.hip", "igemm_wgrad.hip"]
+SOURCES = ["api.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "edge.hip", "igemm_conv.hip", "igemm_wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 

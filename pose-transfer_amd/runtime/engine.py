@@ -24,7 +24,7 @@ class KernelProfiler:
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
     CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32"}
-    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64"}
+    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128"}
 
     def __init__(self):
         self.records = []
@@ -220,7 +220,7 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
 
 
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
-           y_strides=None, ksplit=0):
+           y_strides=None, ksplit=0, cout_store=0):
     d = L.WgradDesc()
     for i, s in enumerate(srcs):
         d.src[i] = s
@@ -234,6 +234,7 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
     d.KH, d.KW, d.stride, d.pad = K, K, stride, pad
     d.dW, d.Cout, d.Cin = L.ptr(dW), Cout, Cin
     d.ksplit = ksplit
+    d.cout_store = cout_store
     if PROFILER is not None:
         PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout,
                         lambda: L.check(L.load().pg_conv_wgrad(d, L.stream()), "pg_conv_wgrad"))
@@ -321,6 +322,8 @@ class GeneratorEngine:
             self.d_norm.append(NormState(N, device))
         self.drop = [torch.ones(N, self.dec[i], **f32) for i in range(min(3, self.ndec - 1))]
         self.out = torch.empty(N, 3, H, W, **f32)
+        self.y_taps = torch.empty(N, H, W, 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
+        self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh) for its weight gradient
         self.warps = torch.empty(N, T_WARPS, 8, **f32)
         self.input = None
         self._drop_counter = 0
@@ -421,9 +424,12 @@ class GeneratorEngine:
         i = self.ndec - 1
         srcs = self._dec_sources(i)
         cin = sum(a.C for _, _, a in srcs)
-        _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 3, 1, 1, H, W,
-              A.p("decoder.net.%d.weight" % (i + 1)), 3, cin, out=self.out, out_strides=(3 * H * W, H * W, W, 1),
-              bias=A.p("decoder.net.%d.bias" % (i + 1)), out_act=L.OUT_TANH)
+        # 256->3 output conv (networks.py:228) re-associated: 1x1 conv to 27 = 9 taps x 3 channels, then tap gather
+        # + bias + tanh (csrc/edge.hip) — a 3-wide GEMM-N would leave 29/32 of every MFMA tile empty
+        _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W,
+              A.p("decoder.net.%d.weight" % (i + 1)), 27, cin, out=self.y_taps)
+        L.call("pg_tap_gather", L.ptr(self.y_taps), N, H, W, 3, 3, 1, 3, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
+               L.OUT_TANH, L.ptr(self.out), 3 * H * W, H * W, W, 1, L.stream())
         return self.out
 
     # -------------------------------------------------------------------------------- backward
@@ -455,12 +461,15 @@ class GeneratorEngine:
         wkey = "decoder.net.%d.weight" % (i + 1)
         L.call("pg_bias_grad", L.ptr(dpre), N, H * W, 3, 3 * H * W, 1, H * W, L.ptr(A.g("decoder.net.%d.bias" % (i + 1))),
                L.stream())
-        _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, dpre, 3, cin, True, H, W, H, W, 3, 1, 1, A.g(wkey),
-               y_strides=ystr)
+        L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
+               L.ptr(self.g_taps), L.stream())
+        _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, self.g_taps, 32, cin, True, H, W, H, W, 1, 1, 0, A.g(wkey),
+               cout_store=27)
         self._ready("decoder.net.%d." % (i + 1))
-        dsrc = Act(dpre, 3, strides=ystr)
-        _conv([dsrc.src()], N, H, W, L.ACT_NONE, 1, 3, 1, 1, H, W, A.p(wkey), 3, cin, transposed=True, scalar_in=True,
-              dsts=self._dsts_for(srcs, True))
+        dsts = self._dsts_for(srcs, True)
+        arr = (L.Dst * len(dsts))(*dsts)
+        L.call("pg_small_cout_dgrad", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3,
+               L.ptr(A.p(wkey)), arr, len(dsts), L.stream())
         # ---- up blocks
         for i in range(self.ndec - 2, -1, -1):
             srcs = self._dec_sources(i)

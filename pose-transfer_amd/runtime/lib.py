@@ -53,13 +53,16 @@ class WgradDesc(C.Structure):
                 ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hl", C.c_int32), ("Wl", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("dW", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32),
-                ("ksplit", C.c_int32), ("_pad", C.c_int32)]
+                ("ksplit", C.c_int32), ("cout_store", C.c_int32)]
 
 
 _i32, _i64, _u64, _f32, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 _PROTOS = {
     "pg_conv": [C.POINTER(ConvDesc), _vp],
     "pg_conv_wgrad": [C.POINTER(WgradDesc), _vp],
+    "pg_tap_gather": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
+    "pg_im2col_taps": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pg_small_cout_dgrad": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, C.POINTER(Dst), _i32, _vp],
     "pg_bias_grad": [_vp, _i64, _i64, _i32, _i64, _i64, _i64, _vp, _vp],
     "pg_norm_stats": [_vp, _i32, _i64, _vp, _vp],
     "pg_norm_finalize": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],

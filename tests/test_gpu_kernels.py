@@ -305,3 +305,36 @@ def test_nn_loss_vs_golden_and_oracle(a):
     assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
     dd = (nchw(d64.cpu()) - gr * (p64 > 0)).abs()
     assert (dd > 1e-7).float().mean() < 1e-3           # arg-min ties between offsets may resolve differently
+
+
+def test_output_conv_reassociated():
+    """The 256->3 output convolution as the engine runs it (csrc/edge.hip): 1x1 conv to 9x3 channels + tap gather
+    (+bias, tanh); weight gradient through an im2col of dY; data gradient by the small-Cout streaming kernel."""
+    case = [c for c in conv_cases() if c.name == "final_k3"][0]
+    out_ref, dz_ref, dw_ref, _ = case.reference()
+    N, H, W, cin = case.N, case.H, case.W, case.cin
+    acts = case.device_sources()
+    wp = case.packed_weight()                                   # [3][3][3][cin] == [27][cin]
+    y27 = torch.full((N, H, W, 27), float("nan"), device=DEV)
+    E._conv([a.src() for a in acts], N, H, W, case.act, 0, 1, 1, 0, H, W, wp, 27, cin, out=y27)
+    out = torch.full((N, 3, H, W), float("nan"), device=DEV)
+    bd = case.b.to(DEV)
+    L.call("pg_tap_gather", L.ptr(y27), N, H, W, 3, 3, 1, 3, L.ptr(bd), L.OUT_TANH, L.ptr(out), 3 * H * W, H * W, W, 1,
+           L.stream())
+    assert rel(out, out_ref) < 1e-5
+    gy = case.gout.to(DEV).contiguous()                        # NCHW d(pre-tanh)
+    ystr = (3 * H * W, H * W, W, 1)
+    g32 = torch.full((N, H, W, 32), float("nan"), device=DEV)
+    L.call("pg_im2col_taps", L.ptr(gy), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32, L.ptr(g32), L.stream())
+    dW = torch.zeros(3, 3, 3, cin, device=DEV)
+    guard = torch.zeros(5 * cin, device=DEV)                    # rows 27..31 must not be written
+    E._wgrad([a.src() for a in acts], N, case.act, g32, 32, cin, True, H, W, H, W, 1, 1, 0, dW, cout_store=27)
+    assert rel(E._unpack("w", dW).cpu(), dw_ref) < 2e-5 and float(guard.abs().max()) == 0.0
+    grads = [torch.full((N, H, W, s[0]), float("nan"), device=DEV) for s in case.srcs]
+    dsts = [L.make_dst(grads[j], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=case.act) for j, a in enumerate(acts)]
+    arr = (L.Dst * len(dsts))(*dsts)
+    L.call("pg_small_cout_dgrad", L.ptr(gy), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, L.ptr(wp), arr,
+           len(dsts), L.stream())
+    torch.cuda.synchronize()
+    for g, r in zip(grads, dz_ref):
+        assert rel(nchw(g.cpu()), r) < 1e-5
