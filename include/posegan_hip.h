@@ -128,6 +128,13 @@ int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int64_t yH, int
                         int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co, const float* Wt,
                         const pg_dst_t* dst, int32_t ndst, void* stream);
 
+/* first-layer convolutions with few NCHW input channels and 64 outputs (models/networks.py:186 k3 s1 p1; :341 k4 s2 p0):
+ * the input patch of an 8x16 output tile is staged in LDS and feeds the MFMA directly (csrc/edge.hip).
+ * `Wt` = pg_repack_small_cin(W packed [KH][KW][64][Cin]) -> [Cin][KH*KW][64]; sources use their (sN,sC,sH,sW) strides. */
+int pg_repack_small_cin(const float* W, int32_t KH, int32_t KW, int32_t Cout, int32_t Cin, float* Wt, void* stream);
+int pg_small_cin_conv(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                      int32_t pad, const float* Wt, const float* bias, float* out, void* stream);
+
 /* db[c] += sum over rows of a strided [rows][C] view (bias gradient; torch autograd of conv bias). */
 int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,
                  int64_t s_inner, int64_t sC, float* db, void* stream);

@@ -177,3 +177,165 @@ extern "C" int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int6
   PG_LAUNCH_OK("pg_small_cout_dgrad");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// First-layer convolutions: few input channels (3+P / P / 3+2P+3) straight from NCHW tensors, 64 output channels.
+//   encoder level 0 : nn.Conv2d(cin, 64, k3, p1, bias)      reference models/networks.py:186
+//   discriminator   : nn.Conv2d(3+2P+3, 64, k4, s2, bias)   reference models/networks.py:341
+// The generic implicit-GEMM gather spends its time on per-element address math for these (K = 9*21 = 189 is tiny and
+// ragged).  Here a workgroup stages the INPUT PATCH of its 8x16 output-pixel tile in LDS once per 8-channel chunk and
+// the MFMA A-operand is read directly out of the patch (no im2col tile, no bounds checks in the inner loop); the
+// weight chunk comes from a [c][tap][co] repack (pg_repack_small_cin) as contiguous float4s.
+namespace pg {
+
+struct SmallCinK {
+  pg_src_t src[PG_MAX_SRC];
+  int nsrc, Ctot;
+  int cstart[PG_MAX_SRC + 1];
+  int N, Hi, Wi, Ho, Wo, pad;
+  const float* Wt;      // repacked [Ctot][K*K][64]
+  const float* bias;
+  float* out;           // NHWC [N][Ho][Wo][64]
+  int tiles_x, tiles_y;
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void small_cin_conv_kernel(const SmallCinK p) {
+  constexpr int TH = 8, TW = 16, CCH = 8, T = K * K;
+  constexpr int PH = (TH - 1) * S + K;
+  constexpr int PWU = (TW - 1) * S + K;                      // used columns
+  constexpr int PWS = (S == 1) ? PWU : 20;                   // row stride (S=2: per-parity half row, padded 17 -> 20)
+  constexpr int ROWF = (S == 1) ? PWS : 2 * PWS;             // floats per patch row
+  constexpr int PATCH = CCH * PH * ROWF;
+  constexpr int KC = CCH * T;                                // K-dim per chunk (72 / 128)
+  __shared__ __attribute__((aligned(16))) float smem[PATCH + KC * 64];
+  float* patch = smem;
+  float* wl = smem + PATCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y;
+  const int n = b / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+  const int wy0 = (wave >> 1) * 4;                           // this wave: output rows wy0..wy0+3, channels wn0..wn0+31
+  const int wn0 = (wave & 1) * 32;
+  // per-lane pixel offsets inside the patch for the two 32-pixel MFMA row tiles (rows wy0+2i+(l31>>4), col l31&15)
+  int pixoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int y = wy0 + 2 * i + (l31 >> 4), x = l31 & 15;
+    pixoff[i] = y * S * ROWF + x;                            // S=2: x indexes the per-parity half row
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  for (int c0 = 0; c0 < p.Ctot; c0 += CCH) {
+    __syncthreads();
+    // ---- stage the input patch of channels c0..c0+7 (zero outside the image / beyond Ctot)
+    for (int e = tid; e < CCH * PH * PWU; e += 256) {
+      const int col = e % PWU;
+      const int rr = (e / PWU) % PH;
+      const int cl = e / (PWU * PH);
+      const int c = c0 + cl;
+      float v = 0.f;
+      const int iy = iy0 + rr, ix = ix0 + col;
+      if (c < p.Ctot && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) {
+        int j = 0;
+#pragma unroll
+        for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && c >= p.cstart[q]) j = q;
+        const pg_src_t& s = p.src[j];
+        v = s.ptr[(long)n * s.sN + (long)(c - p.cstart[j]) * s.sC + (long)iy * s.sH + (long)ix * s.sW];
+      }
+      const int dst = (S == 1) ? ((cl * PH + rr) * ROWF + col)
+                               : ((cl * PH + rr) * ROWF + (col & 1) * PWS + (col >> 1));
+      patch[dst] = v;
+    }
+    // ---- stage the weight chunk [(cl*T + tap)][co] (contiguous in the repacked layout)
+    for (int e = tid * 4; e < KC * 64; e += 256 * 4) {
+      const int cl = e / (T * 64);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + cl < p.Ctot) v = *reinterpret_cast<const float4*>(p.Wt + (long)c0 * T * 64 + e);
+      *reinterpret_cast<float4*>(&wl[e]) = v;
+    }
+    __syncthreads();
+    // ---- MFMA over the chunk: k = cl*T + r*K + s, pairs (kk, kk+1) on the two lane halves
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2) {
+      // compile-time patch offsets of k = kk and k = kk+1
+      constexpr int dummy = 0; (void)dummy;
+      const int k0 = kk, k1 = kk + 1;
+      const int c_0 = k0 / T, t_0 = k0 % T, r_0 = t_0 / K, s_0 = t_0 % K;
+      const int c_1 = k1 / T, t_1 = k1 % T, r_1 = t_1 / K, s_1 = t_1 % K;
+      const int o0 = (S == 1) ? ((c_0 * PH + r_0) * ROWF + s_0) : ((c_0 * PH + r_0) * ROWF + (s_0 & 1) * PWS + (s_0 >> 1));
+      const int o1 = (S == 1) ? ((c_1 * PH + r_1) * ROWF + s_1) : ((c_1 * PH + r_1) * ROWF + (s_1 & 1) * PWS + (s_1 >> 1));
+      const int koff = lhi ? o1 : o0;
+      const float bv = wl[(kk + lhi) * 64 + wn0 + l31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float av = patch[koff + pixoff[i]];
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: + bias, NHWC store
+  const int co = wn0 + l31;
+  const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;          // pixel index inside the 32-pixel tile
+      const int oy = oy0 + wy0 + 2 * i + (row >> 4), ox = ox0 + (row & 15);
+      if (oy < p.Ho && ox < p.Wo) p.out[(((long)n * p.Ho + oy) * p.Wo + ox) * 64 + co] = acc[i][r] + bias;
+    }
+}
+
+__global__ void repack_small_cin_kernel(const float* W, int T, int Cout, int Cin, float* Wt) {
+  // W packed [tap][co][ci]  ->  Wt [ci][tap][co]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * Cout * Cin) return;
+  const int co = i % Cout;
+  const int tap = (i / Cout) % T;
+  const int ci = i / (Cout * T);
+  Wt[i] = W[((long)tap * Cout + co) * Cin + ci];
+}
+
+}  // namespace pg
+
+extern "C" int pg_repack_small_cin(const float* W, int32_t KH, int32_t KW, int32_t Cout, int32_t Cin, float* Wt,
+                                   void* stream) {
+  PG_REQUIRE(W && Wt && Cout > 0 && Cin > 0, "pg_repack_small_cin: bad arguments");
+  const int n = KH * KW * Cout * Cin;
+  hipLaunchKernelGGL(pg::repack_small_cin_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, KH * KW, Cout,
+                     Cin, Wt);
+  PG_LAUNCH_OK("pg_repack_small_cin");
+  return 0;
+}
+
+extern "C" int pg_small_cin_conv(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
+                                 int32_t stride, int32_t pad, const float* Wt, const float* bias, float* out,
+                                 void* stream) {
+  PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && Wt && out, "pg_small_cin_conv: bad arguments");
+  PG_REQUIRE((K == 3 && stride == 1) || (K == 4 && stride == 2), "pg_small_cin_conv: only k3s1 / k4s2 (got k%d s%d)", K, stride);
+  pg::SmallCinK k;
+  memset(&k, 0, sizeof(k));
+  int c = 0;
+  for (int j = 0; j < nsrc; ++j) { k.src[j] = src[j]; k.cstart[j] = c; c += src[j].C; }
+  for (int j = nsrc; j <= PG_MAX_SRC; ++j) k.cstart[j] = c;
+  k.nsrc = nsrc; k.Ctot = c;
+  k.N = N; k.Hi = Hi; k.Wi = Wi; k.pad = pad;
+  k.Ho = (Hi + 2 * pad - K) / stride + 1; k.Wo = (Wi + 2 * pad - K) / stride + 1;
+  k.Wt = Wt; k.bias = bias; k.out = out;
+  k.tiles_x = (k.Wo + 15) / 16; k.tiles_y = (k.Ho + 7) / 8;
+  dim3 grid((unsigned)(k.tiles_x * k.tiles_y * N));
+  if (K == 3) hipLaunchKernelGGL((pg::small_cin_conv_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL((pg::small_cin_conv_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, k);
+  PG_LAUNCH_OK("pg_small_cin_conv");
+  return 0;
+}

@@ -219,6 +219,15 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
     L.check(L.load().pg_conv(d, L.stream()), "pg_conv")
 
 
+def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
+    """First-layer convolution (few NCHW input channels -> 64 NHWC): repack the weights, then the patch kernel."""
+    cin = sum(a.C for a in acts)
+    L.call("pg_repack_small_cin", L.ptr(W), K, K, 64, cin, L.ptr(wt_buf), L.stream())
+    arr = (L.Src * len(acts))(*[a.src() for a in acts])
+    L.call("pg_small_cin_conv", arr, len(acts), N, Hi, Wi, K, stride, pad, L.ptr(wt_buf), L.ptr(bias),
+           out if isinstance(out, int) else L.ptr(out), L.stream())
+
+
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
            y_strides=None, ksplit=0, cout_store=0):
     d = L.WgradDesc()
@@ -322,6 +331,8 @@ class GeneratorEngine:
             self.d_norm.append(NormState(N, device))
         self.drop = [torch.ones(N, self.dec[i], **f32) for i in range(min(3, self.ndec - 1))]
         self.out = torch.empty(N, 3, H, W, **f32)
+        cin0 = {"encoder_app": 3 + pose_dim, "encoder_pose": pose_dim, "encoder": 3 + 2 * pose_dim}
+        self.wt0 = {e: torch.empty(cin0[e] * 9 * 64, **f32) for e in self.encs}    # [Cin][9][64] repack of conv 0
         self.y_taps = torch.empty(N, H, W, 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
         self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh) for its weight gradient
         self.warps = torch.empty(N, T_WARPS, 8, **f32)
@@ -395,8 +406,12 @@ class GeneratorEngine:
         # ---- encoders (reference networks.py:193-202)
         for e in self.encs:
             s0 = self._enc_in_src(e, inp)
-            _conv([s0.src()], N, H, W, L.ACT_NONE, 0, 3, 1, 1, H, W, A.p(e + ".net.0.weight"), self.enc[0], s0.C,
-                  scalar_in=True, out=self.e_raw[e][0], bias=A.p(e + ".net.0.bias"))
+            if self.enc[0] == 64:
+                _small_cin_conv([s0], N, H, W, 3, 1, 1, A.p(e + ".net.0.weight"), A.p(e + ".net.0.bias"), self.wt0[e],
+                                self.e_raw[e][0])
+            else:
+                _conv([s0.src()], N, H, W, L.ACT_NONE, 0, 3, 1, 1, H, W, A.p(e + ".net.0.weight"), self.enc[0], s0.C,
+                      scalar_in=True, out=self.e_raw[e][0], bias=A.p(e + ".net.0.bias"))
             for l in range(1, self.nlev):
                 hi, wi = self.hw[l - 1]
                 ho, wo = self.hw[l]
@@ -551,6 +566,7 @@ class DiscriminatorEngine:
         self.raw = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
         self.dz = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
         self.norm = [NormState(M, device) if 0 < j < self.nblk - 1 else None for j in range(self.nblk)]
+        self.wt0 = torch.empty((3 + 2 * pose_dim + 3) * 16 * 64, **f32)          # [Cin][16][64] repack of the stem
         self.K = hs[-1] * ws[-1]               # outputs per image (49 at 256^2)
         self.inputs = None
         self.grad_ready_cb = None
@@ -590,8 +606,7 @@ class DiscriminatorEngine:
             assert all(t.is_contiguous() and t.dtype == torch.float32 for t in pair)
             srcs = self._stem_srcs(pair)
             out_ptr = self.raw[0].data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
-            _conv([a.src() for a in srcs], n, H, W, L.ACT_NONE, 0, 4, 2, 0, self.hs[0], self.ws[0], A.p("net.0.weight"),
-                  64, 3 + 2 * self.P + 3, scalar_in=True, out=out_ptr, bias=A.p("net.0.bias"))
+            _small_cin_conv(srcs, n, H, W, 4, 2, 0, A.p("net.0.weight"), A.p("net.0.bias"), self.wt0, out_ptr)
             off += n
         assert off == self.M
         for j in range(1, self.nblk):

@@ -338,3 +338,21 @@ def test_output_conv_reassociated():
     torch.cuda.synchronize()
     for g, r in zip(grads, dz_ref):
         assert rel(nchw(g.cpu()), r) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["first_k3", "stem_k4p0"])
+def test_small_cin_patch_conv(name):
+    """First-layer convolutions through the LDS-patch MFMA kernel (csrc/edge.hip) vs F.conv2d, incl. ragged tiles."""
+    for hw in ((12, 10), (24, 40), (33, 19)):
+        base = [c for c in conv_cases() if c.name == name][0]
+        case = ConvCase(name + "%dx%d" % hw, "conv", base.srcs, 64, 2, hw[0], hw[1], base.K, base.stride, base.pad,
+                        L.ACT_NONE, bias=True, scalar=True)
+        out_ref, _, _, _ = case.reference()
+        acts = case.device_sources()
+        wp = case.packed_weight()
+        wt = torch.empty(case.cin * case.K * case.K * 64, device=DEV)
+        out = torch.full((case.N, case.Ho, case.Wo, 64), float("nan"), device=DEV)
+        bd = case.b.to(DEV)
+        E._small_cin_conv(acts, case.N, case.H, case.W, case.K, case.stride, case.pad, wp, bd, wt, out)
+        torch.cuda.synchronize()
+        assert rel(nchw(out.cpu()), out_ref) < 1e-5, hw
