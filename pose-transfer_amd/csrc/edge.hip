@@ -76,10 +76,18 @@ __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(const SmallDgradK
     *reinterpret_cast<float4*>(&wl[i]) = *reinterpret_cast<const float4*>(&p.Wt[i]);
   __syncthreads();
   const int cpp = p.Ctot >> 2;     // float4 chunks per pixel
+  // One wave-iteration covers 64 consecutive float4 chunks.  When a pixel has >= 64 chunks per wave-iteration the
+  // pixel index is wave-uniform (made provably so with readfirstlane) and the dY taps become scalar loads.
   const long items = (long)p.N * p.H * p.W * cpp;
+  const bool uni = (cpp % 64) == 0;
   for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
     const int cg = (int)(it % cpp) * 4;
-    const long pix = it / cpp;
+    long pix = it / cpp;
+    if (uni) {
+      const int lo = __builtin_amdgcn_readfirstlane((int)(pix & 0xffffffff));
+      const int hi = __builtin_amdgcn_readfirstlane((int)(pix >> 32));
+      pix = ((long)hi << 32) | (unsigned)lo;
+    }
     const int x = (int)(pix % p.W);
     const long r0 = pix / p.W;
     const int y = (int)(r0 % p.H);
@@ -172,7 +180,7 @@ extern "C" int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int6
   if (lds > 64 * 1024)
     PG_HIP(hipFuncSetAttribute((const void*)small_cout_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   long blocks = ((long)N * H * W * (c / 4) + 255) / 256;
-  if (blocks > 1024) blocks = 1024;      // each block stages the weights once: keep blocks long-lived
+  if (blocks > 8192) blocks = 8192;      // each block stages the weights once (27 KB): enough blocks to hide latency
   hipLaunchKernelGGL(small_cout_dgrad_kernel, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_small_cout_dgrad");
   return 0;

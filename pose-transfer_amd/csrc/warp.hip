@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const 
           float* d = db + ((long)yy * w + xx) * C + cc;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (a4[e] == t) atomicAdd(d + e, g[e] * m * wg[k]);
+            if (a4[e] == t) {
+              const float v = g[e] * m * wg[k];
+              if (v != 0.f) atomicAdd(d + e, v);     // ReLU'd consumers make about half of the gradients exact zeros
+            }
         }
       }
     }

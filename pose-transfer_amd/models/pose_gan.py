@@ -84,8 +84,10 @@ class DeformablePose_GAN(nn.Module):
                 raise Exception("only content_loss_layer=block1_conv2 (vgg19.features[:2]) is implemented")
             self.set_vgg_weights(*_default_vgg_conv1(getattr(opt, "vgg_weights", None)))
         self.world = DP.world_size()
-        self.g_reducer = DP.GradReducer(self.gen.arena, self.world) if self.world > 1 else None
-        self.d_reducer = DP.GradReducer(self.disc.arena, self.world) if self.world > 1 else None
+        # PG_FORCE_REDUCER=1 exercises the bucketed all-reduce path even at world size 1 (single-GPU test of the DP code)
+        use_red = self.world > 1 or (os.environ.get("PG_FORCE_REDUCER") == "1" and DP.dist.is_initialized())
+        self.g_reducer = DP.GradReducer(self.gen.arena, max(self.world, 2) if use_red else 1) if use_red else None
+        self.d_reducer = DP.GradReducer(self.disc.arena, max(self.world, 2) if use_red else 1) if use_red else None
         self._loss = torch.zeros(8, dtype=torch.float32, device=device)
         self._bufs = {}
 

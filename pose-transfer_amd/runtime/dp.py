@@ -27,7 +27,7 @@ def rank():
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* when launched by torch.distributed.run."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or dist.is_initialized():
+    if dist.is_initialized() or (ws <= 1 and "RANK" not in os.environ):
         return world_size()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -251,23 +251,45 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
     L.check(L.load().pg_conv_wgrad(d, L.stream()), "pg_conv_wgrad")
 
 
+class NormScratch:
+    """All per-sample statistics buffers of one engine in ONE allocation, so that a forward (backward) pass zeroes
+    them with a single memset instead of one tiny fill launch per norm layer."""
+
+    def __init__(self, count, N, device):
+        self.sums = torch.zeros(count, N, 2, dtype=torch.float64, device=device)
+        self.bsums = torch.zeros(count, N, 2, dtype=torch.float64, device=device)
+        self.used = 0
+
+    def take(self):
+        i = self.used
+        self.used += 1
+        return self.sums[i], self.bsums[i]
+
+
 class NormState:
     """Scratch for one per-sample norm: stats (double), mean/rstd, the emitted affine, backward sums."""
 
-    def __init__(self, N, device):
-        self.sums = torch.zeros(N, 2, dtype=torch.float64, device=device)
-        self.bsums = torch.zeros(N, 2, dtype=torch.float64, device=device)
+    def __init__(self, N, device, scratch=None):
+        if scratch is not None:
+            self.sums, self.bsums = scratch.take()
+            self.shared = True
+        else:
+            self.sums = torch.zeros(N, 2, dtype=torch.float64, device=device)
+            self.bsums = torch.zeros(N, 2, dtype=torch.float64, device=device)
+            self.shared = False
         self.mr = torch.zeros(N, 2, dtype=torch.float32, device=device)
         self.aff = torch.zeros(N, 2, dtype=torch.float32, device=device)
 
     def forward(self, y, N, Lr, gamma, beta):
-        self.sums.zero_()
+        if not self.shared:
+            self.sums.zero_()
         L.call("pg_norm_stats", L.ptr(y), N, Lr, L.ptr(self.sums), L.stream())
         L.call("pg_norm_finalize", L.ptr(self.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(self.mr),
                L.ptr(self.aff), L.stream())
 
     def backward(self, dz, y, N, Lr, gamma, dgamma, dbeta):
-        self.bsums.zero_()
+        if not self.shared:
+            self.bsums.zero_()
         L.call("pg_norm_bwd_reduce", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), L.stream())
         L.call("pg_norm_bwd_apply", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
                L.ptr(dgamma), L.ptr(dbeta), L.stream())
@@ -315,7 +337,8 @@ class GeneratorEngine:
         # encoder activations (raw), grads, norm state
         self.e_raw = {e: [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nlev)] for e in self.encs}
         self.e_dz = {e: [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nlev)] for e in self.encs}
-        self.e_norm = {e: [NormState(N, device) if 0 < l < self.nlev - 1 else None for l in range(self.nlev)] for e in self.encs}
+        self.nscr = NormScratch(len(self.encs) * self.nlev + self.ndec, N, device)
+        self.e_norm = {e: [NormState(N, device, self.nscr) if 0 < l < self.nlev - 1 else None for l in range(self.nlev)] for e in self.encs}
         # warped appearance skips (levels 0..3)
         self.nwarp = min(4, self.nlev) if deformable else 0
         self.w_out = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nwarp)]
@@ -328,7 +351,7 @@ class GeneratorEngine:
             h, w = hw[self.nlev - 2 - i]
             self.d_raw.append(torch.empty(N, h, w, self.dec[i], **f32))
             self.d_dz.append(torch.empty(N, h, w, self.dec[i], **f32))
-            self.d_norm.append(NormState(N, device))
+            self.d_norm.append(NormState(N, device, self.nscr))
         self.drop = [torch.ones(N, self.dec[i], **f32) for i in range(min(3, self.ndec - 1))]
         self.out = torch.empty(N, 3, H, W, **f32)
         cin0 = {"encoder_app": 3 + pose_dim, "encoder_pose": pose_dim, "encoder": 3 + 2 * pose_dim}
@@ -395,6 +418,7 @@ class GeneratorEngine:
         A, N, H, W = self.A, self.N, self.H, self.W
         assert tuple(inp.shape) == (N, 3 + 2 * self.P, H, W) and inp.is_contiguous() and inp.dtype == torch.float32
         self.input = inp
+        self.nscr.sums.zero_()
         if not hasattr(self, "use_drop"):
             self.set_dropout(None, train=True)
         if self.deformable:
@@ -467,6 +491,7 @@ class GeneratorEngine:
         A, N, H, W = self.A, self.N, self.H, self.W
         assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
         ystr = (3 * H * W, H * W, W, 1)
+        self.nscr.bsums.zero_()
         for l in range(self.nwarp):
             self.e_dz["encoder_app"][l].zero_()
         # ---- final conv k3s1p1 (+bias, tanh handled by the caller)
@@ -565,7 +590,8 @@ class DiscriminatorEngine:
         self.hs, self.ws = hs, ws
         self.raw = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
         self.dz = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
-        self.norm = [NormState(M, device) if 0 < j < self.nblk - 1 else None for j in range(self.nblk)]
+        self.nscr = NormScratch(self.nblk, M, device)
+        self.norm = [NormState(M, device, self.nscr) if 0 < j < self.nblk - 1 else None for j in range(self.nblk)]
         self.wt0 = torch.empty((3 + 2 * pose_dim + 3) * 16 * 64, **f32)          # [Cin][16][64] repack of the stem
         self.K = hs[-1] * ws[-1]               # outputs per image (49 at 256^2)
         self.inputs = None
@@ -600,6 +626,7 @@ class DiscriminatorEngine:
         """pairs: list of (input NCHW (n,3+2P,H,W), judged NCHW (n,3,H,W)); sum n == M.  Returns logits (M,K)."""
         A, H, W = self.A, self.H, self.W
         self.inputs = pairs
+        self.nscr.sums.zero_()
         off = 0
         for pair in pairs:
             n = pair[0].shape[0]
@@ -621,6 +648,7 @@ class DiscriminatorEngine:
         """dlogits (M,K).  need_wgrad: accumulate weight grads (dis_update).  image_grad: list of NCHW (n,3,H,W)
         buffers (one per forward pair, or None) receiving d/d(judged image) (gen_update)."""
         A, M, H, W = self.A, self.M, self.H, self.W
+        self.nscr.bsums.zero_()
         j = self.nblk - 1
         ystr = (self.K, 1, self.ws[j], 1)
         wkey = "net.%d.net.1.weight" % j

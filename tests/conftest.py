@@ -19,3 +19,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# PG_FORCE_REDUCER=1 (+ RANK/WORLD_SIZE/MASTER_* in the environment) runs the GPU suite with the data-parallel
+# gradient reducer active at world size 1, so the bucketed RCCL all-reduce path is exercised on a single GPU.
+if os.environ.get("PG_FORCE_REDUCER") == "1" and "RANK" in os.environ:
+    from pose_transfer_amd.runtime import dp as _dp
+    _dp.init_from_env()
