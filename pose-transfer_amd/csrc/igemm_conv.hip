@@ -44,12 +44,15 @@ struct ConvK {
   int dstart[PG_MAX_SRC + 1];
 };
 
-struct RowInfo {   // per M-row of the block tile, built once in LDS
+struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
   int n;           // sample index, -1 = row outside the problem
-  int iy, ix;      // input base coordinate (q*si)
-  int pix;         // n*Ho*Wo + oy*Wo + ox
-  long off;        // n*oN + oy*oH + ox*oW
+  short iy, ix;    // input base coordinate (q*si)
+  short oy, ox;    // output coordinate
 };
+
+// All global loads of the K loop are UNCONDITIONAL straight-line code (a load inside a branch makes the compiler drain
+// vmcnt at the join, exposing the full memory latency every K tile).  Rows without a dropout mask read this table.
+__device__ __attribute__((aligned(16))) const float kOnes[2048] = {[0 ... 2047] = 1.0f};
 
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
@@ -69,10 +72,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int AS_CNT = 32 / (256 / BM);   // scalar-A elements per thread
   constexpr int BS_CNT = BN / 8;            // scalar-B elements per thread
 
-  __shared__ __attribute__((aligned(16))) float smem[BM * AS + BN * BSK + BM * (sizeof(RowInfo) / 4)];
-  float* As = smem;
-  float* Bs = smem + BM * AS;
-  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + BM * AS + BN * BSK);
+  // two LDS stages: tile t+1 is written while tile t is being multiplied -> ONE barrier per K tile, and a wave's
+  // loader work is followed directly by its own MFMAs (the co-resident workgroup fills the MFMA pipe meanwhile)
+  constexpr int A_SZ = BM * AS, B_SZ = BN * BSK;
+  constexpr int AFF_SZ = (AMODE == A_VEC) ? BM * PG_MAX_SRC * 2 : 0;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ) + BM * (sizeof(RowInfo) / 4) + AFF_SZ];
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * A_SZ;
+  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + 2 * (A_SZ + B_SZ));
+  float* const affs = smem + 2 * (A_SZ + B_SZ) + BM * (sizeof(RowInfo) / 4);   // [row][src](a,b): deferred-norm affine
+  __shared__ int taps_l[MAXTAP];             // this phase's (dy, dx, weight tap) packed: LDS, not kernarg vector loads
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -83,10 +92,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int ntap = p.ntap[phase];
   const float slope = act_slope(p.act);
 
+  if (tid < MAXTAP)
+    taps_l[tid] = (p.dy[phase][tid] & 0xff) | ((p.dx[phase][tid] & 0xff) << 8) | ((int)p.wtap[phase][tid] << 16);
   if (tid < BM) {
     RowInfo ri;
     const int m = m0 + tid;
-    ri.n = -1; ri.iy = 0; ri.ix = 0; ri.pix = 0; ri.off = 0;
+    ri.n = -1; ri.iy = 0; ri.ix = 0; ri.oy = 0; ri.ox = 0;
     if (m < p.M) {
       const int gg = p.Gy * p.Gx;
       const int n = m / gg;
@@ -97,13 +108,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       const int ox = qx * p.so + p.phx[phase];
       if (oy < p.Ho && ox < p.Wo) {
         ri.n = n;
-        ri.iy = qy * p.si;
-        ri.ix = qx * p.si;
-        ri.pix = (n * p.Ho + oy) * p.Wo + ox;
-        ri.off = (long)n * p.oN + (long)oy * p.oH + (long)ox * p.oW;
+        ri.iy = (short)(qy * p.si);
+        ri.ix = (short)(qx * p.si);
+        ri.oy = (short)oy;
+        ri.ox = (short)ox;
       }
     }
     rows[tid] = ri;
+    if (AMODE == A_VEC) {
+#pragma unroll
+      for (int j = 0; j < PG_MAX_SRC; ++j) {
+        float a = 1.f, b = 0.f;
+        if (j < p.nsrc && p.src[j].aff && ri.n >= 0) { a = p.src[j].aff[2 * ri.n]; b = p.src[j].aff[2 * ri.n + 1]; }
+        affs[(tid * PG_MAX_SRC + j) * 2] = a;
+        affs[(tid * PG_MAX_SRC + j) * 2 + 1] = b;
+      }
+    }
   }
   __syncthreads();
 
@@ -133,7 +153,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   float4 rmask[A_ROWS];
   float raa[A_ROWS], rab[A_ROWS];
   unsigned a_ok = 0;
-  bool a_has_mask = false;
   float rs[AS_CNT];
   float4 rb[(BMODE == B_NT) ? B_ROWS : (BMODE == B_NN ? NN_PASS : 1)];
   float rbs[BS_CNT];
@@ -151,24 +170,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && cc >= p.cstart[q]) j = q;
       if (tap != a_tap || j != a_src) {
-        // (tap, source) changed: rebuild the per-row pointers / bounds; otherwise they just advance by one K tile
+        // (tap, source) changed: rebuild the per-row pointers / bounds (address arithmetic + LDS reads only);
+        // otherwise the pointers just advance by one K tile
         const pg_src_t& s = p.src[j];
         const int cl = cc - p.cstart[j] + (tid & 7) * 4;
-        const int dyv = p.dy[phase][tap], dxv = p.dx[phase][tap];
+        const int tp = taps_l[tap];
+        const int dyv = (int)(signed char)(tp & 0xff), dxv = (int)(signed char)((tp >> 8) & 0xff);
         a_ok = 0;
-        a_has_mask = (s.mask != nullptr);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
           const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
           const bool ok = a_n[i] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-          raa[i] = 1.f; rab[i] = 0.f;
-          aptr[i] = s.ptr; mptr[i] = s.ptr;
-          if (ok) {
-            a_ok |= (1u << i);
-            aptr[i] = s.ptr + ((((long)a_n[i] * p.Hi + iy) * p.Wi + ix) * s.C + cl);
-            if (s.aff) { raa[i] = s.aff[2 * a_n[i]]; rab[i] = s.aff[2 * a_n[i] + 1]; }
-            if (s.mask) mptr[i] = s.mask + ((long)a_n[i] * s.C + cl);
-          }
+          const int row = (tid >> 3) + 32 * i;
+          raa[i] = affs[(row * PG_MAX_SRC + j) * 2];
+          rab[i] = affs[(row * PG_MAX_SRC + j) * 2 + 1];
+          const int nn = ok ? a_n[i] : 0;
+          a_ok |= (ok ? 1u : 0u) << i;
+          aptr[i] = s.ptr + (ok ? ((((long)nn * p.Hi + iy) * p.Wi + ix) * s.C + cl) : (long)cl);
+          mptr[i] = s.mask ? (s.mask + ((long)nn * s.C + cl)) : (kOnes + (cl & 511));
         }
         a_tap = tap; a_src = j;
       } else {
@@ -176,13 +195,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         for (int i = 0; i < A_ROWS; ++i) { aptr[i] += BK; mptr[i] += BK; }
       }
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rmask[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if ((a_ok >> i) & 1u) {
-          ra[i] = *reinterpret_cast<const float4*>(aptr[i]);
-          if (a_has_mask) rmask[i] = *reinterpret_cast<const float4*>(mptr[i]);
-        }
+      for (int i = 0; i < A_ROWS; ++i) {     // unconditional: invalid rows read a valid dummy address, zeroed at store
+        ra[i] = *reinterpret_cast<const float4*>(aptr[i]);
+        rmask[i] = *reinterpret_cast<const float4*>(mptr[i]);
       }
     } else {
 #pragma unroll
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       const int tap = kt / cpt;
       if (tap != b_tap) {
         const int cc = (kt - tap * cpt) * BK + (tid & 7) * 4;
-        const long base = (long)p.wtap[phase][tap] * p.wCout;
+        const long base = (long)(taps_l[tap] >> 16) * p.wCout;
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
           const int n = nb0 + (tid >> 3) + 32 * i;
@@ -221,17 +236,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         for (int i = 0; i < B_ROWS; ++i) bptr[i] += BK;
       }
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const int n = nb0 + (tid >> 3) + 32 * i;
-        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);
-      }
+      for (int i = 0; i < B_ROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);   // row clamped; zeroed at store
     } else if (BMODE == B_NN) {
       const int tap = kt / cpt;
       const int n = nb0 + (tid % NN_CPR) * 4;
       if (tap != b_tap) {
         const int cc = (kt - tap * cpt) * BK;
-        const long base = (long)p.wtap[phase][tap] * p.wCout;
+        const long base = (long)(taps_l[tap] >> 16) * p.wCout;
 #pragma unroll
         for (int i = 0; i < NN_PASS; ++i) {
           const int kr = tid / NN_CPR + i * (256 / NN_CPR);
@@ -243,10 +254,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         for (int i = 0; i < NN_PASS; ++i) bptr[i] += (long)BK * p.wCin;
       }
 #pragma unroll
-      for (int i = 0; i < NN_PASS; ++i) {
-        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.n_cnt) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);
-      }
+      for (int i = 0; i < NN_PASS; ++i) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);   // column clamped; zeroed at store
     } else {
 #pragma unroll
       for (int e = 0; e < BS_CNT; ++e) {
@@ -267,7 +275,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](int stage) {
+    float* As = As0 + stage * A_SZ;
+    float* Bs = Bs0 + stage * B_SZ;
     if (AMODE == A_VEC) {
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
@@ -287,13 +297,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     }
     if (BMODE == B_NT) {
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i)
-        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * BSK + (tid & 7) * 4]) = rb[i];
+      for (int i = 0; i < B_ROWS; ++i) {
+        const bool ok = nb0 + (tid >> 3) + 32 * i < p.n_cnt;
+        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * BSK + (tid & 7) * 4]) =
+            ok ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     } else if (BMODE == B_NN) {
+      const bool ok = nb0 + (tid % NN_CPR) * 4 < p.n_cnt;
 #pragma unroll
       for (int i = 0; i < NN_PASS; ++i) {
         const int kr = tid / NN_CPR + i * (256 / NN_CPR);
-        *reinterpret_cast<float4*>(&Bs[kr * BS + (tid % NN_CPR) * 4]) = rb[i];
+        *reinterpret_cast<float4*>(&Bs[kr * BS + (tid % NN_CPR) * 4]) = ok ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
@@ -319,7 +333,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   // operand fetch for k-group g (8 k's): element e pairs k = 8g+e (lanes<32) with k = 8g+4+e (lanes>=32)
-  auto fetch = [&](int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+  auto fetch = [&](int stage, int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+    const float* As = As0 + stage * A_SZ;
+    const float* Bs = Bs0 + stage * B_SZ;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + l31) * AS + g * 8 + lhi * 4]);
@@ -337,16 +353,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     }
   };
 
-  if (kt0 < kt1) load_tile(kt0);
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+    if (kt0 + 1 < kt1) load_tile(kt0 + 1);
+  }
+  __syncthreads();
+  int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < kt1) load_tile(kt + 1);
+    if (kt + 1 < kt1) {
+      store_tile(stage ^ 1);                 // registers hold tile kt+1 (fetched during the previous iteration)
+      if (kt + 2 < kt1) load_tile(kt + 2);
+    }
     float fa[2][TM][4], fb[2][TN][4];
-    fetch(0, fa[0], fb[0]);
+    fetch(stage, 0, fa[0], fb[0]);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      if (g + 1 < BK / 8) fetch(g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+      if (g + 1 < BK / 8) fetch(stage, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -356,6 +379,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+    stage ^= 1;
   }
   if (kt0 >= kt1) return;   // empty split: contributes nothing
 
@@ -376,7 +400,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           if (ri.n < 0 || !nval) continue;
           float g = acc[i][j][r] + bv;
           if (p.out_act == PG_OUT_TANH) g = tanhf(g);
-          float* o = p.out + ri.off + (long)ng * p.oC;
+          float* o = p.out + ((long)ri.n * p.oN + (long)ri.oy * p.oH + (long)ri.ox * p.oW) + (long)ng * p.oC;
           if (atomic) atomicAdd(o, g); else *o = g;
         }
       } else {
@@ -395,7 +419,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           const RowInfo ri = rows[row];
           rn[r] = nval ? ri.n : -1;
-          idx[r] = (long)ri.pix * ds.C + c;
+          idx[r] = (long)((ri.n * p.Ho + ri.oy) * p.Wo + ri.ox) * ds.C + c;
           fz[r] = 0.f; mk[r] = 1.f;
           if (rn[r] >= 0) {
             if (ds.fwd) {
