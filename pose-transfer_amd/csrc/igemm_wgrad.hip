@@ -29,6 +29,11 @@ struct WgradK {
   int ksplit, Kpix, ntaps, cout_store;
 };
 
+// Unconditional-load helpers: a load inside a branch makes the compiler drain vmcnt at the join (full memory latency
+// exposed every K tile), so invalid rows read these dummies / a clamped address and are zeroed at the LDS store.
+__device__ __attribute__((aligned(16))) const float kOnesW[2048] = {[0 ... 2047] = 1.0f};
+__device__ __attribute__((aligned(16))) const float kIdentAff[4] = {1.0f, 0.0f, 1.0f, 0.0f};
+
 struct Pix { int n, sy, sx, ly, lx; bool lok; };
 struct PixState { int n, sy, sx; };   // small-grid pixel of one tile row, advanced by 32 pixels per K tile
 
@@ -78,9 +83,10 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   constexpr int A_CPR = BM / 4, A_PASS = (BM / 32 > 0) ? BM / 32 : 1;   // float4 chunks per pixel row / passes
   constexpr int B_CPR = BN / 4, B_PASS = BN / 32;
   constexpr int A_SC = BM / 8, B_SC = BN / 8;                            // scalar elements per thread
-  __shared__ __attribute__((aligned(16))) float smem[WBK * AS + WBK * BS];
-  float* As = smem;
-  float* Bs = smem + WBK * AS;
+  constexpr int A_SZ = WBK * AS, B_SZ = WBK * BS;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];   // two stages: one barrier per K tile
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * A_SZ;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tap = blockIdx.z / p.ksplit;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   float4 rb[XS ? 1 : B_PASS];
   float4 rbm[XS ? 1 : B_PASS];
   float rba[XS ? 1 : B_PASS], rbb[XS ? 1 : B_PASS];
-  unsigned b_ok = 0;
+  unsigned b_ok = 0, a_ok = 0;
   float ras[YS ? A_SC : 1];
   float rbs[XS ? B_SC : 1];
 
@@ -123,16 +129,21 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
         const int co = co0 + (tid % A_CPR) * 4;
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool cok = co < p.Cout;
+        long idx;
+        bool ok;
         if (p.x_is_large) {      // dY is the small tensor: dense [pixel][co], no coordinates needed
           const int k = kt * WBK + tid / A_CPR + i * (256 / A_CPR);
-          if (k < p.Kpix && co < p.Cout) ra[i] = *reinterpret_cast<const float4*>(p.dY + (long)k * p.Cout + co);
+          ok = k < p.Kpix && cok;
+          idx = ok ? ((long)k * p.Cout + co) : 0;
         } else {
           const Pix q = pix_of(p, a_st[i], r, s);
           pix_advance(p, a_st[i], advy, advx);
-          if (q.n >= 0 && q.lok && co < p.Cout)
-            ra[i] = *reinterpret_cast<const float4*>(p.dY + (long)((q.n * p.Hl + q.ly) * p.Wl + q.lx) * p.Cout + co);
+          ok = q.n >= 0 && q.lok && cok;
+          idx = ok ? ((long)((q.n * p.Hl + q.ly) * p.Wl + q.lx) * p.Cout + co) : 0;
         }
+        a_ok = (a_ok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+        ra[i] = *reinterpret_cast<const float4*>(p.dY + idx);
       }
     } else {
       const Pix q = pix_of(p, a_st[0], r, s);
@@ -155,22 +166,18 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
       b_ok = 0;
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) {
-        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rbm[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        rba[i] = 1.f; rbb[i] = 0.f;
         const Pix q = pix_of(p, b_st[i], r, s);       // the sample index is needed for aff/mask either way
         pix_advance(p, b_st[i], advy, advx);
-        if (q.n >= 0) {
-          const bool ok = p.x_is_large ? q.lok : true;
-          if (ok) {
-            b_ok |= 1u << i;
-            const int pixidx = p.x_is_large ? ((q.n * p.Hl + q.ly) * p.Wl + q.lx)
-                                            : (kt * WBK + tid / B_CPR + i * (256 / B_CPR));
-            rb[i] = *reinterpret_cast<const float4*>(sx.ptr + (long)pixidx * sx.C + cl);
-            if (sx.aff) { rba[i] = sx.aff[2 * q.n]; rbb[i] = sx.aff[2 * q.n + 1]; }
-            if (sx.mask) rbm[i] = *reinterpret_cast<const float4*>(sx.mask + q.n * sx.C + cl);
-          }
-        }
+        const bool ok = q.n >= 0 && (p.x_is_large ? q.lok : true);
+        b_ok |= (ok ? 1u : 0u) << i;
+        const int nn = ok ? q.n : 0;
+        const int pixidx = !ok ? 0 : (p.x_is_large ? ((q.n * p.Hl + q.ly) * p.Wl + q.lx)
+                                                    : (kt * WBK + tid / B_CPR + i * (256 / B_CPR)));
+        const float* ap = sx.aff ? (sx.aff + 2 * nn) : kIdentAff;
+        const float* mp = sx.mask ? (sx.mask + (long)nn * sx.C + cl) : (kOnesW + (cl & 511));
+        rb[i] = *reinterpret_cast<const float4*>(sx.ptr + (long)pixidx * sx.C + cl);
+        rba[i] = ap[0]; rbb[i] = ap[1];
+        rbm[i] = *reinterpret_cast<const float4*>(mp);
       }
     } else {
       const Pix q = pix_of(p, b_st[0], r, s);
@@ -193,20 +200,21 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](int stage) {
+    float* As = As0 + stage * A_SZ;
+    float* Bs = Bs0 + stage * B_SZ;
     if (!YS) {
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
         const int pr = tid / A_CPR + i * (256 / A_CPR);
-        *reinterpret_cast<float4*>(&As[pr * AS + (tid % A_CPR) * 4]) = ra[i];
+        *reinterpret_cast<float4*>(&As[pr * AS + (tid % A_CPR) * 4]) =
+            ((a_ok >> i) & 1u) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
       for (int e = 0; e < A_SC; ++e) As[(tid & 31) * AS + (tid >> 5) + 8 * e] = ras[e];
     }
     if (!XS) {
-      const pg_src_t& sx = p.src[jsrc];
-      const bool hm = sx.mask != nullptr;
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) {
         const int pr = tid / B_CPR + i * (256 / B_CPR);
@@ -243,7 +251,9 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
 
   // operand fetch for k-group g (8 pixels of this wave's K span), register double-buffered against the MFMAs
   constexpr int NG = KSPAN / 8;
-  auto fetch = [&](int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+  auto fetch = [&](int stage, int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+    const float* As = As0 + stage * A_SZ;
+    const float* Bs = Bs0 + stage * B_SZ;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int kk = wk * KSPAN + g * 8 + lhi * 4 + e;
@@ -255,15 +265,20 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   };
 
   load_tile(kt0);
+  store_tile(0);
+  if (kt0 + 1 < kt1) load_tile(kt0 + 1);
+  __syncthreads();
+  int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < kt1) load_tile(kt + 1);
+    if (kt + 1 < kt1) {
+      store_tile(stage ^ 1);
+      if (kt + 2 < kt1) load_tile(kt + 2);
+    }
     float fa[2][TM][4], fb[2][TN][4];
-    fetch(0, fa[0], fb[0]);
+    fetch(stage, 0, fa[0], fb[0]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) fetch(g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+      if (g + 1 < NG) fetch(stage, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -273,6 +288,7 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+    stage ^= 1;
   }
 
   const bool atomic = (p.ksplit > 1) || (WGK > 1);
