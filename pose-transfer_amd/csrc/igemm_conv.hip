@@ -15,6 +15,12 @@
 // Split-K (atomic accumulate) fills the 256 CUs on the deep, small-M layers.
 #include "common.h"
 
+// -DPG_ABLATE=n builds diagnostic variants of the K loop (tools/ablate.sh): 1 = no global loads, 2 = no LDS stores,
+// 4 = no MFMA (operands kept live).  0 (default) is the product kernel.
+#ifndef PG_ABLATE
+#define PG_ABLATE 0
+#endif
+
 namespace pg {
 
 constexpr int BK = 32;
@@ -52,7 +58,10 @@ struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
 
 // All global loads of the K loop are UNCONDITIONAL straight-line code (a load inside a branch makes the compiler drain
 // vmcnt at the join, exposing the full memory latency every K tile).  Rows without a dropout mask read this table.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wc99-designator"
 __device__ __attribute__((aligned(16))) const float kOnes[2048] = {[0 ... 2047] = 1.0f};
+#pragma clang diagnostic pop
 
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
@@ -362,21 +371,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     if (kt + 1 < kt1) {
-      store_tile(stage ^ 1);                 // registers hold tile kt+1 (fetched during the previous iteration)
-      if (kt + 2 < kt1) load_tile(kt + 2);
+      if constexpr (!(PG_ABLATE & 2)) store_tile(stage ^ 1);   // registers hold tile kt+1 (fetched one iteration ago)
+      if constexpr (!(PG_ABLATE & 1)) { if (kt + 2 < kt1) load_tile(kt + 2); }
     }
     float fa[2][TM][4], fb[2][TN][4];
     fetch(stage, 0, fa[0], fb[0]);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       if (g + 1 < BK / 8) fetch(stage, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+      if constexpr (!(PG_ABLATE & 4)) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[g & 1][i][e]));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[g & 1][j][e]));
+        }
+      }
     }
     __syncthreads();
     stage ^= 1;

@@ -31,7 +31,10 @@ struct WgradK {
 
 // Unconditional-load helpers: a load inside a branch makes the compiler drain vmcnt at the join (full memory latency
 // exposed every K tile), so invalid rows read these dummies / a clamped address and are zeroed at the LDS store.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wc99-designator"
 __device__ __attribute__((aligned(16))) const float kOnesW[2048] = {[0 ... 2047] = 1.0f};
+#pragma clang diagnostic pop
 __device__ __attribute__((aligned(16))) const float kIdentAff[4] = {1.0f, 0.0f, 1.0f, 0.0f};
 
 struct Pix { int n, sy, sx, ly, lx; bool lok; };

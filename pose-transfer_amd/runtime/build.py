@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
-LIB = os.path.join(LIBDIR, "libposegan_hip.so")
+LIB = os.environ.get("PG_LIB") or os.path.join(LIBDIR, "libposegan_hip.so")
 SOURCES = ["api.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "edge.hip", "igemm_conv.hip", "igemm_wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
