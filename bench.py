@@ -33,7 +33,7 @@ from pose_transfer_amd.runtime import engine as E  # noqa: E402
 from pose_transfer_amd.utils import synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-P = 18
+P = 18                            # key-points; --pose_dim overrides (config 3 uses 32)
 
 
 def make_opt(args):
@@ -100,6 +100,18 @@ def cpu_baseline(args):
                       "(%d threads), %.1f s" % (size, size, n, cores, dt)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/round1_pmc.json, made by
+    tools/pmc_bench.sh on the default workload): 2*FETCH_SIZE + WRITE_SIZE, in bytes (MI355X_MICROARCH.md: FETCH_SIZE
+    reads half of a wide coalesced stream on gfx950).  None when no PMC summary is available."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))
+        k = d["kernels"].get(kernel)
+        return None if k is None else int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,12 +119,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE.json configs[1]: 4)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--pose_dim", type=int, default=18)
     ap.add_argument("--content_loss_layer", default="none")
     ap.add_argument("--nn_loss_area_size", type=int, default=1)
     ap.add_argument("--l1_penalty_weight", type=float, default=100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
+    global P
+    P = args.pose_dim
 
     world = dp.init_from_env()
     rank = dp.rank()
@@ -160,7 +175,7 @@ def main():
             name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(name),
                     "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "flops_per_launch_avg": d["flops"] / d["launches"],
                     "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
@@ -177,8 +192,9 @@ def main():
             "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "src_deformable warp_skip=mask gen_type=baseline, fasion %dx%d, 18 kpts, batch %d/GPU, "
-                                   "fp32 (BASELINE.json configs[1])" % (args.size, args.size, args.batch),
+            "config": {"workload": "src_deformable warp_skip=mask gen_type=baseline, %dx%d, %d kpts, batch %d/GPU, fp32%s"
+                                   % (args.size, args.size, P, args.batch,
+                                      " (BASELINE.json configs[1])" if (args.size, P, args.batch) == (256, 18, 4) else ""),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size},
             "step_tflops": round(sf * ips / 1e12, 2),
