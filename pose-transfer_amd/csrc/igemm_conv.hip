@@ -16,7 +16,7 @@
 #include "common.h"
 
 // -DPG_ABLATE=n builds diagnostic variants of the K loop (tools/ablate.sh): 1 = no global loads, 2 = no LDS stores,
-// 4 = no MFMA (operands kept live).  0 (default) is the product kernel.
+// 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only).  0 = the product kernel.
 #ifndef PG_ABLATE
 #define PG_ABLATE 0
 #endif
@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           mptr[i] = s.mask ? (s.mask + ((long)nn * s.C + cl)) : (kOnes + (cl & 511));
         }
         a_tap = tap; a_src = j;
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): no scalar load may stay in flight past this rare path, or the
+                                              // compiler must use lgkmcnt(0) (SMEM returns out of order) for every LDS wait below
       } else {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) { aptr[i] += BK; mptr[i] += BK; }
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           bptr[i] = p.W + (base + p.n_off + (n < p.n_cnt ? n : 0)) * p.wCin + cc;
         }
         b_tap = tap;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
       } else {
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) bptr[i] += BK;
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           bptr[i] = p.W + (base + cc + kr) * p.wCin + p.n_off + (n < p.n_cnt ? n : 0);
         }
         b_tap = tap;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
       } else {
 #pragma unroll
         for (int i = 0; i < NN_PASS; ++i) bptr[i] += (long)BK * p.wCin;
@@ -341,63 +345,113 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int wn0 = (wave % WGN) * (TN * 32);
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  // operand fetch for k-group g (8 k's): element e pairs k = 8g+e (lanes<32) with k = 8g+4+e (lanes>=32)
+  // operand fetch for k-group g (8 k's): element e pairs k = 8g+e (lanes<32) with k = 8g+4+e (lanes>=32).
+  // The ds_reads are inline asm on purpose: hipcc's own waitcnt insertion drains lgkmcnt(0) before every MFMA group
+  // (scalar loads in flight make its LDS counts "out of order"), which exposes the LDS latency three times per tile
+  // with nothing queued on the matrix pipe (measured 129 vs 150 TFLOP/s for the MFMA-only loop).  Issued this way
+  // the compiler does not track them; the counted waits below (lds_wait<N>) do, and any younger LDS/SMEM operation
+  // the compiler adds only makes those waits stricter, never weaker.
+  constexpr int NRD = TM + (B_KN ? 4 * TN : TN);           // LDS reads per fetch (<= 10)
+  const unsigned a_base = (unsigned)(size_t)As0 + (unsigned)((wm0 + l31) * AS + lhi * 4) * 4u;
+  const unsigned b_base = B_KN ? (unsigned)(size_t)Bs0 + (unsigned)((lhi * 4) * BS + wn0 + l31) * 4u
+                               : (unsigned)(size_t)Bs0 + (unsigned)((wn0 + l31) * BSK + lhi * 4) * 4u;
   auto fetch = [&](int stage, int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
-    const float* As = As0 + stage * A_SZ;
-    const float* Bs = Bs0 + stage * B_SZ;
+    if constexpr ((PG_ABLATE & 16) != 0) { if (stage >= 0) return; }   // diagnostic: operands stay constant
+    const unsigned aa = a_base + (unsigned)(stage * A_SZ + g * 8) * 4u;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + i * 32 + l31) * AS + g * 8 + lhi * 4]);
-      fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+      f32x4 v;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(aa + (unsigned)(i * 32 * AS) * 4u));
+      fa[i][0] = v[0]; fa[i][1] = v[1]; fa[i][2] = v[2]; fa[i][3] = v[3];
     }
+    if constexpr (B_KN) {
+      const unsigned bb = b_base + (unsigned)(stage * B_SZ + g * 8 * BS) * 4u;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      if (B_KN) {
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) fb[j][e] = Bs[(g * 8 + lhi * 4 + e) * BS + wn0 + j * 32 + l31];
-      } else {
-        const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + j * 32 + l31) * BSK + g * 8 + lhi * 4]);
-        fb[j][0] = v.x; fb[j][1] = v.y; fb[j][2] = v.z; fb[j][3] = v.w;
+        for (int e = 0; e < 4; ++e)
+          asm volatile("ds_read_b32 %0, %1" : "=v"(fb[j][e]) : "v"(bb + (unsigned)(e * BS + j * 32) * 4u));
+    } else {
+      const unsigned bb = b_base + (unsigned)(stage * B_SZ + g * 8) * 4u;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x4 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(bb + (unsigned)(j * 32 * BSK) * 4u));
+        fb[j][0] = v[0]; fb[j][1] = v[1]; fb[j][2] = v[2]; fb[j][3] = v[3];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // wait until at most `n` of this wave's LDS/SMEM operations are outstanding, then fence the scheduler
+#define PG_LDS_WAIT(n)                                              \
+  do {                                                              \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+
+  // 16 MFMAs of one k-group (8 k's) from one operand register set
+  auto mfma_group = [&](const float (&fa)[TM][4], const float (&fb)[TN][4]) {
+    if constexpr (!(PG_ABLATE & 4)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i][e]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j][e]));
       }
     }
   };
+  static_assert(BK == 32, "the K loop below is written for 4 k-groups per tile");
 
+  // K loop.  Two LDS stages, two operand register sets (A/B).  Per tile:  [write tile t+1 to the other stage, issue the
+  // global loads of tile t+2]  g1<-LDS | MFMA g0 | g2<-LDS | MFMA g1 | g3<-LDS | MFMA g2 | BARRIER | next g0<-LDS |
+  // MFMA g3.  Every LDS read of the current stage is complete before the barrier (so the next iteration may overwrite
+  // it), the other stage is complete after it, and each operand fetch has 16 MFMAs (1024 cycles) to land behind.
+  float fa[2][TM][4] = {}, fb[2][TN][4] = {};
   if (kt0 < kt1) {
     load_tile(kt0);
     store_tile(0);
     if (kt0 + 1 < kt1) load_tile(kt0 + 1);
   }
   __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  if (kt0 < kt1) fetch(0, 0, fa[0], fb[0]);
   int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    if (kt + 1 < kt1) {
+    const bool more = kt + 1 < kt1;
+    if (more) {
       if constexpr (!(PG_ABLATE & 2)) store_tile(stage ^ 1);   // registers hold tile kt+1 (fetched one iteration ago)
       if constexpr (!(PG_ABLATE & 1)) { if (kt + 2 < kt1) load_tile(kt + 2); }
     }
-    float fa[2][TM][4], fb[2][TN][4];
-    fetch(stage, 0, fa[0], fb[0]);
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      if (g + 1 < BK / 8) fetch(stage, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
-      if constexpr (!(PG_ABLATE & 4)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[g & 1][i][e]));
-#pragma unroll
-          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[g & 1][j][e]));
-        }
-      }
-    }
-    __syncthreads();
+    // one operand set is always a full fetch (NRD reads) ahead of the MFMAs that consume the other one
+    fetch(stage, 1, fa[1], fb[1]);
+    PG_LDS_WAIT(NRD);                      // set A (fetched behind the previous barrier) has landed
+    __builtin_amdgcn_s_setprio(1);         // MFMA phase outranks the co-resident workgroup's loader phase
+    mfma_group(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(stage, 2, fa[0], fb[0]);
+    PG_LDS_WAIT(NRD);                      // set B = g1
+    mfma_group(fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(stage, 3, fa[1], fb[1]);
+    PG_LDS_WAIT(NRD);                      // set A = g2
+    mfma_group(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    PG_LDS_WAIT(0);                        // every read of this stage has completed (the next store may overwrite it)
+    if constexpr (!(PG_ABLATE & 8)) __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(stage ^ 1, 0, fa[0], fb[0]);
+    mfma_group(fa[1], fb[1]);              // g3 landed before the barrier
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
     stage ^= 1;
   }
   if (kt0 >= kt1) return;   // empty split: contributes nothing
