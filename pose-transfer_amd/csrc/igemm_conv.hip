@@ -14,6 +14,7 @@
 //   Global->register prefetch of tile t+1 overlaps the 16 MFMA k-steps of tile t (64 cycles each per SIMD).
 // Split-K (atomic accumulate) fills the 256 CUs on the deep, small-M layers.
 #include "common.h"
+#include <type_traits>
 
 // -DPG_ABLATE=n builds diagnostic variants of the K loop (tools/ablate.sh): 1 = no global loads, 2 = no LDS stores,
 // 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only).  0 = the product kernel.
@@ -63,6 +64,20 @@ struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
 __device__ __attribute__((aligned(16))) const float kOnes[2048] = {[0 ... 2047] = 1.0f};
 #pragma clang diagnostic pop
 
+// f32 MFMA runs on the SIMD's fp32 lanes: every VALU instruction of a co-resident wave steals matrix throughput
+// (measured: an idle partner leaves the MFMA+fetch loop at 139 TFLOP/s, an active loader partner at 100).  So the
+// loaders below are written for minimum VALU count: 32-bit byte offsets against wave-uniform bases (one v_add per
+// row per tile instead of 64-bit pointer arithmetic), the activation picked once per tile, masks only when present,
+// and zero padding through an affine of (0,0) instead of per-element selects.
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f32x4& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read32(float& v, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int m0 = blockIdx.x * BM;
   const int nb0 = blockIdx.y * BN;
   const int ntap = p.ntap[phase];
-  const float slope = act_slope(p.act);
+  const bool b_edge = nb0 + BN > p.n_cnt;     // uniform: only edge tiles pay for zeroing rows beyond N
 
   if (tid < MAXTAP)
     taps_l[tid] = (p.dy[phase][tid] & 0xff) | ((p.dx[phase][tid] & 0xff) << 8) | ((int)p.wtap[phase][tid] << 16);
@@ -161,13 +176,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   float4 ra[A_ROWS];
   float4 rmask[A_ROWS];
   float raa[A_ROWS], rab[A_ROWS];
-  unsigned a_ok = 0;
   float rs[AS_CNT];
   float4 rb[(BMODE == B_NT) ? B_ROWS : (BMODE == B_NN ? NN_PASS : 1)];
   float rbs[BS_CNT];
-  const float* aptr[A_ROWS];
-  const float* mptr[A_ROWS];
-  const float* bptr[(BMODE == B_NT) ? B_ROWS : (BMODE == B_NN ? NN_PASS : 1)];
+  const char* a_base = nullptr;     // wave-uniform bases; per-row 32-bit BYTE offsets
+  const char* m_base = nullptr;
+  unsigned aoff[A_ROWS], moff[A_ROWS];
+  unsigned boff[(BMODE == B_NT) ? B_ROWS : (BMODE == B_NN ? NN_PASS : 1)];
+  bool a_has_mask = false;
   int a_tap = -1, a_src = -1, b_tap = -1;
 
   auto load_tile = [&](int kt) {
@@ -179,36 +195,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && cc >= p.cstart[q]) j = q;
       if (tap != a_tap || j != a_src) {
-        // (tap, source) changed: rebuild the per-row pointers / bounds (address arithmetic + LDS reads only);
-        // otherwise the pointers just advance by one K tile
+        // (tap, source) changed: rebuild the per-row offsets / bounds (address arithmetic + LDS reads only);
+        // otherwise the offsets just advance by one K tile
         const pg_src_t& s = p.src[j];
         const int cl = cc - p.cstart[j] + (tid & 7) * 4;
         const int tp = taps_l[tap];
         const int dyv = (int)(signed char)(tp & 0xff), dxv = (int)(signed char)((tp >> 8) & 0xff);
-        a_ok = 0;
+        a_base = reinterpret_cast<const char*>(s.ptr);
+        a_has_mask = s.mask != nullptr;
+        m_base = reinterpret_cast<const char*>(a_has_mask ? s.mask : kOnes);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
           const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
           const bool ok = a_n[i] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
           const int row = (tid >> 3) + 32 * i;
-          raa[i] = affs[(row * PG_MAX_SRC + j) * 2];
-          rab[i] = affs[(row * PG_MAX_SRC + j) * 2 + 1];
+          // zero padding = affine (0,0) on a valid dummy element (first pixel of the source): no per-element select
+          raa[i] = ok ? affs[(row * PG_MAX_SRC + j) * 2] : 0.f;
+          rab[i] = ok ? affs[(row * PG_MAX_SRC + j) * 2 + 1] : 0.f;
           const int nn = ok ? a_n[i] : 0;
-          a_ok |= (ok ? 1u : 0u) << i;
-          aptr[i] = s.ptr + (ok ? ((((long)nn * p.Hi + iy) * p.Wi + ix) * s.C + cl) : (long)cl);
-          mptr[i] = s.mask ? (s.mask + ((long)nn * s.C + cl)) : (kOnes + (cl & 511));
+          const unsigned pix = ok ? (unsigned)((nn * p.Hi + iy) * p.Wi + ix) : 0u;
+          aoff[i] = (pix * (unsigned)s.C + (unsigned)cl) * 4u;
+          moff[i] = a_has_mask ? ((unsigned)(nn * s.C + cl) * 4u) : ((unsigned)(cl & 511) * 4u);
         }
         a_tap = tap; a_src = j;
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): no scalar load may stay in flight past this rare path, or the
-                                              // compiler must use lgkmcnt(0) (SMEM returns out of order) for every LDS wait below
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): no scalar load stays in flight past this rare path
       } else {
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) { aptr[i] += BK; mptr[i] += BK; }
+        for (int i = 0; i < A_ROWS; ++i) { aoff[i] += BK * 4; moff[i] += BK * 4; }
       }
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {     // unconditional: invalid rows read a valid dummy address, zeroed at store
-        ra[i] = *reinterpret_cast<const float4*>(aptr[i]);
-        rmask[i] = *reinterpret_cast<const float4*>(mptr[i]);
+      for (int i = 0; i < A_ROWS; ++i) {     // unconditional straight-line loads
+        ra[i] = *reinterpret_cast<const float4*>(a_base + aoff[i]);
+        rmask[i] = *reinterpret_cast<const float4*>(m_base + moff[i]);
       }
     } else {
 #pragma unroll
@@ -235,39 +253,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       const int tap = kt / cpt;
       if (tap != b_tap) {
         const int cc = (kt - tap * cpt) * BK + (tid & 7) * 4;
-        const long base = (long)(taps_l[tap] >> 16) * p.wCout;
+        const int base = (taps_l[tap] >> 16) * p.wCout;
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
           const int n = nb0 + (tid >> 3) + 32 * i;
-          bptr[i] = p.W + (base + p.n_off + (n < p.n_cnt ? n : 0)) * p.wCin + cc;
+          boff[i] = (unsigned)((base + p.n_off + (n < p.n_cnt ? n : 0)) * p.wCin + cc) * 4u;
         }
         b_tap = tap;
         __builtin_amdgcn_s_waitcnt(0xC07F);
       } else {
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) bptr[i] += BK;
+        for (int i = 0; i < B_ROWS; ++i) boff[i] += BK * 4;
       }
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);   // row clamped; zeroed at store
+      for (int i = 0; i < B_ROWS; ++i)      // row clamped; zeroed at store
+        rb[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.W) + boff[i]);
     } else if (BMODE == B_NN) {
       const int tap = kt / cpt;
       const int n = nb0 + (tid % NN_CPR) * 4;
       if (tap != b_tap) {
         const int cc = (kt - tap * cpt) * BK;
-        const long base = (long)(taps_l[tap] >> 16) * p.wCout;
+        const int base = (taps_l[tap] >> 16) * p.wCout;
 #pragma unroll
         for (int i = 0; i < NN_PASS; ++i) {
           const int kr = tid / NN_CPR + i * (256 / NN_CPR);
-          bptr[i] = p.W + (base + cc + kr) * p.wCin + p.n_off + (n < p.n_cnt ? n : 0);
+          boff[i] = (unsigned)((base + cc + kr) * p.wCin + p.n_off + (n < p.n_cnt ? n : 0)) * 4u;
         }
         b_tap = tap;
         __builtin_amdgcn_s_waitcnt(0xC07F);
       } else {
 #pragma unroll
-        for (int i = 0; i < NN_PASS; ++i) bptr[i] += (long)BK * p.wCin;
+        for (int i = 0; i < NN_PASS; ++i) boff[i] += (unsigned)(BK * p.wCin) * 4u;
       }
 #pragma unroll
-      for (int i = 0; i < NN_PASS; ++i) rb[i] = *reinterpret_cast<const float4*>(bptr[i]);   // column clamped; zeroed at store
+      for (int i = 0; i < NN_PASS; ++i)     // column clamped; zeroed at store
+        rb[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.W) + boff[i]);
     } else {
 #pragma unroll
       for (int e = 0; e < BS_CNT; ++e) {
@@ -292,17 +312,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     float* As = As0 + stage * A_SZ;
     float* Bs = Bs0 + stage * B_SZ;
     if (AMODE == A_VEC) {
+      // act((a*x+b)*mask): the activation / mask variant is picked once per tile (uniform), 2-4 VALU per element
+      auto emit = [&](auto has_mask, auto act_c) {
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-        const float mk[4] = {rmask[i].x, rmask[i].y, rmask[i].z, rmask[i].w};
-        const bool ok = (a_ok >> i) & 1u;
+        for (int i = 0; i < A_ROWS; ++i) {
+          float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+          const float mk[4] = {rmask[i].x, rmask[i].y, rmask[i].z, rmask[i].w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = apply_act_s((v[e] * raa[i] + rab[i]) * mk[e], slope);
-          v[e] = ok ? t : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            float t = fmaf(v[e], raa[i], rab[i]);
+            if constexpr (decltype(has_mask)::value) t *= mk[e];
+            if constexpr (decltype(act_c)::value == PG_ACT_RELU) t = fmaxf(t, 0.f);
+            if constexpr (decltype(act_c)::value == PG_ACT_LEAKY) t = fmaxf(t, 0.2f * t);
+            v[e] = t;
+          }
+          *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * AS + (tid & 7) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * AS + (tid & 7) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+      };
+      using T1 = std::integral_constant<bool, true>;
+      using T0 = std::integral_constant<bool, false>;
+      using AN = std::integral_constant<int, PG_ACT_NONE>;
+      using AR = std::integral_constant<int, PG_ACT_RELU>;
+      using AL = std::integral_constant<int, PG_ACT_LEAKY>;
+      if (a_has_mask) {
+        if (p.act == PG_ACT_RELU) emit(T1{}, AR{}); else if (p.act == PG_ACT_LEAKY) emit(T1{}, AL{}); else emit(T1{}, AN{});
+      } else {
+        if (p.act == PG_ACT_RELU) emit(T0{}, AR{}); else if (p.act == PG_ACT_LEAKY) emit(T0{}, AL{}); else emit(T0{}, AN{});
       }
     } else {
 #pragma unroll
@@ -311,16 +346,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     if (BMODE == B_NT) {
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i) {
-        const bool ok = nb0 + (tid >> 3) + 32 * i < p.n_cnt;
-        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * BSK + (tid & 7) * 4]) =
-            ok ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = rb[i];
+        if (b_edge && !(nb0 + (tid >> 3) + 32 * i < p.n_cnt)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * BSK + (tid & 7) * 4]) = v;
       }
     } else if (BMODE == B_NN) {
-      const bool ok = nb0 + (tid % NN_CPR) * 4 < p.n_cnt;
+      const bool zero = b_edge && !(nb0 + (tid % NN_CPR) * 4 < p.n_cnt);
 #pragma unroll
       for (int i = 0; i < NN_PASS; ++i) {
         const int kr = tid / NN_CPR + i * (256 / NN_CPR);
-        *reinterpret_cast<float4*>(&Bs[kr * BS + (tid % NN_CPR) * 4]) = ok ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&Bs[kr * BS + (tid % NN_CPR) * 4]) = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : rb[i];
       }
     } else {
 #pragma unroll
@@ -352,36 +387,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   // the compiler does not track them; the counted waits below (lds_wait<N>) do, and any younger LDS/SMEM operation
   // the compiler adds only makes those waits stricter, never weaker.
   constexpr int NRD = TM + (B_KN ? 4 * TN : TN);           // LDS reads per fetch (<= 10)
-  const unsigned a_base = (unsigned)(size_t)As0 + (unsigned)((wm0 + l31) * AS + lhi * 4) * 4u;
-  const unsigned b_base = B_KN ? (unsigned)(size_t)Bs0 + (unsigned)((lhi * 4) * BS + wn0 + l31) * 4u
+  const unsigned fa_base = (unsigned)(size_t)As0 + (unsigned)((wm0 + l31) * AS + lhi * 4) * 4u;
+  const unsigned fb_base = B_KN ? (unsigned)(size_t)Bs0 + (unsigned)((lhi * 4) * BS + wn0 + l31) * 4u
                                : (unsigned)(size_t)Bs0 + (unsigned)((wn0 + l31) * BSK + lhi * 4) * 4u;
-  auto fetch = [&](int stage, int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+  static_assert(TM <= 2 && TN <= 2, "fetch below is written out for at most 2x2 MFMA tiles per wave");
+  auto fetch = [&](int stage, auto gc, float (&fa)[TM][4], float (&fb)[TN][4]) {
+    constexpr int G = decltype(gc)::value;
     if constexpr ((PG_ABLATE & 16) != 0) { if (stage >= 0) return; }   // diagnostic: operands stay constant
-    const unsigned aa = a_base + (unsigned)(stage * A_SZ + g * 8) * 4u;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      f32x4 v;
-      asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(aa + (unsigned)(i * 32 * AS) * 4u));
-      fa[i][0] = v[0]; fa[i][1] = v[1]; fa[i][2] = v[2]; fa[i][3] = v[3];
+    const unsigned aa = fa_base + (unsigned)(stage * A_SZ) * 4u;     // one v_add per operand; the rest are immediates
+    const unsigned bb = fb_base + (unsigned)(stage * B_SZ) * 4u;
+    f32x4 v;
+    lds_read128<(G * 8) * 4>(v, aa);
+    fa[0][0] = v[0]; fa[0][1] = v[1]; fa[0][2] = v[2]; fa[0][3] = v[3];
+    if constexpr (TM > 1) {
+      f32x4 w;
+      lds_read128<(G * 8 + 32 * AS) * 4>(w, aa);
+      fa[TM - 1][0] = w[0]; fa[TM - 1][1] = w[1]; fa[TM - 1][2] = w[2]; fa[TM - 1][3] = w[3];
     }
     if constexpr (B_KN) {
-      const unsigned bb = b_base + (unsigned)(stage * B_SZ + g * 8 * BS) * 4u;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          asm volatile("ds_read_b32 %0, %1" : "=v"(fb[j][e]) : "v"(bb + (unsigned)(e * BS + j * 32) * 4u));
+      lds_read32<((G * 8 + 0) * BS) * 4>(fb[0][0], bb);
+      lds_read32<((G * 8 + 1) * BS) * 4>(fb[0][1], bb);
+      lds_read32<((G * 8 + 2) * BS) * 4>(fb[0][2], bb);
+      lds_read32<((G * 8 + 3) * BS) * 4>(fb[0][3], bb);
+      if constexpr (TN > 1) {
+        lds_read32<((G * 8 + 0) * BS + 32) * 4>(fb[TN - 1][0], bb);
+        lds_read32<((G * 8 + 1) * BS + 32) * 4>(fb[TN - 1][1], bb);
+        lds_read32<((G * 8 + 2) * BS + 32) * 4>(fb[TN - 1][2], bb);
+        lds_read32<((G * 8 + 3) * BS + 32) * 4>(fb[TN - 1][3], bb);
+      }
     } else {
-      const unsigned bb = b_base + (unsigned)(stage * B_SZ + g * 8) * 4u;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        f32x4 v;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(bb + (unsigned)(j * 32 * BSK) * 4u));
-        fb[j][0] = v[0]; fb[j][1] = v[1]; fb[j][2] = v[2]; fb[j][3] = v[3];
+      f32x4 u;
+      lds_read128<(G * 8) * 4>(u, bb);
+      fb[0][0] = u[0]; fb[0][1] = u[1]; fb[0][2] = u[2]; fb[0][3] = u[3];
+      if constexpr (TN > 1) {
+        f32x4 w;
+        lds_read128<(G * 8 + 32 * BSK) * 4>(w, bb);
+        fb[TN - 1][0] = w[0]; fb[TN - 1][1] = w[1]; fb[TN - 1][2] = w[2]; fb[TN - 1][3] = w[3];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  using G0 = std::integral_constant<int, 0>;
+  using G1 = std::integral_constant<int, 1>;
+  using G2 = std::integral_constant<int, 2>;
+  using G3 = std::integral_constant<int, 3>;
   // wait until at most `n` of this wave's LDS/SMEM operations are outstanding, then fence the scheduler
 #define PG_LDS_WAIT(n)                                              \
   do {                                                              \
@@ -423,7 +472,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   }
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
-  if (kt0 < kt1) fetch(0, 0, fa[0], fb[0]);
+  if (kt0 < kt1) fetch(0, G0{}, fa[0], fb[0]);
   int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
@@ -432,23 +481,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       if constexpr (!(PG_ABLATE & 1)) { if (kt + 2 < kt1) load_tile(kt + 2); }
     }
     // one operand set is always a full fetch (NRD reads) ahead of the MFMAs that consume the other one
-    fetch(stage, 1, fa[1], fb[1]);
+    fetch(stage, G1{}, fa[1], fb[1]);
     PG_LDS_WAIT(NRD);                      // set A (fetched behind the previous barrier) has landed
     __builtin_amdgcn_s_setprio(1);         // MFMA phase outranks the co-resident workgroup's loader phase
     mfma_group(fa[0], fb[0]);
     __builtin_amdgcn_sched_barrier(0);
-    fetch(stage, 2, fa[0], fb[0]);
+    fetch(stage, G2{}, fa[0], fb[0]);
     PG_LDS_WAIT(NRD);                      // set B = g1
     mfma_group(fa[1], fb[1]);
     __builtin_amdgcn_sched_barrier(0);
-    fetch(stage, 3, fa[1], fb[1]);
+    fetch(stage, G3{}, fa[1], fb[1]);
     PG_LDS_WAIT(NRD);                      // set A = g2
     mfma_group(fa[0], fb[0]);
     __builtin_amdgcn_sched_barrier(0);
     PG_LDS_WAIT(0);                        // every read of this stage has completed (the next store may overwrite it)
     if constexpr (!(PG_ABLATE & 8)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (more) fetch(stage ^ 1, 0, fa[0], fb[0]);
+    if (more) fetch(stage ^ 1, G0{}, fa[0], fb[0]);
     mfma_group(fa[1], fb[1]);              // g3 landed before the barrier
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
