@@ -123,11 +123,15 @@ def main():
     ap.add_argument("--content_loss_layer", default="none")
     ap.add_argument("--nn_loss_area_size", type=int, default=1)
     ap.add_argument("--l1_penalty_weight", type=float, default=100.0)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="MFMA operand format of the fwd/dgrad contractions (default f32 = the reference's arithmetic; "
+                         "the other modes are extra, non-headline measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
     global P
     P = args.pose_dim
+    E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2}[args.precision]
 
     world = dp.init_from_env()
     rank = dp.rank()
@@ -191,12 +195,14 @@ def main():
             "metric": "GAN train images/sec (gen+disc step) at %dx%d" % (args.size, args.size),
             "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 storage/accumulate, %s MFMA operands"
+            % args.precision, "data": "synthetic",
             "config": {"workload": "src_deformable warp_skip=mask gen_type=baseline, %dx%d, %d kpts, batch %d/GPU, fp32%s"
                                    % (args.size, args.size, P, args.batch,
                                       " (BASELINE.json configs[1])" if (args.size, P, args.batch) == (256, 18, 4) else ""),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
-                       "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size},
+                       "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size,
+                       "precision": args.precision},
             "step_tflops": round(sf * ips / 1e12, 2),
             "step_frac_of_f32_mfma_peak": round(sf * ips / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "roofline": roof, "cpu_baseline": cpu,

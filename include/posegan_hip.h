@@ -85,7 +85,16 @@ typedef struct {
   pg_dst_t dst[PG_MAX_SRC];
   int32_t ndst;
   int32_t ksplit;           /* 0 = auto; >1 splits K across workgroups (atomic accumulate)         */
+  int32_t precision;        /* PG_PREC_*: MFMA operand format (storage and accumulation stay fp32)  */
+  int32_t reserved0;
 } pg_conv_t;
+
+/* MFMA operand precision of pg_conv.  F32 is the reference-parity path and the default everywhere; BF16X3 splits
+   each fp32 operand into two bf16 (hi+lo, 3 MFMAs per product, ~2^-16 relative product error); BF16 rounds operands
+   to bf16 (mixed precision, NOT a parity mode).  Layers the low-precision kernels do not cover run in fp32. */
+#define PG_PREC_F32 0
+#define PG_PREC_BF16 1
+#define PG_PREC_BF16X3 2
 
 int pg_conv(const pg_conv_t* desc, void* stream);
 

@@ -69,6 +69,18 @@ __device__ __attribute__((aligned(16))) const float kOnes[2048] = {[0 ... 2047] 
 // loaders below are written for minimum VALU count: 32-bit byte offsets against wave-uniform bases (one v_add per
 // row per tile instead of 64-bit pointer arithmetic), the activation picked once per tile, masks only when present,
 // and zero padding through an affine of (0,0) instead of per-element selects.
+// ---- low-precision operand modes (PREC template parameter): 1 = bf16 MFMA operands (fp32 storage / accumulate),
+// 2 = "bf16x3": every fp32 operand is split as hi + lo (two bf16) and a*b ~ ah*bh + ah*bl + al*bh on the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate) — ~2^-16 relative product error, fp32-class results.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // RNE, lo -> bits 0..15
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ float bf16_lo_f32(unsigned packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi_f32(unsigned packed) { return __uint_as_float(packed & 0xffff0000u); }
+
 template <int OFF>
 __device__ __forceinline__ void lds_read128(f32x4& v, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
@@ -78,7 +90,7 @@ __device__ __forceinline__ void lds_read32(float& v, unsigned addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   // LDS layouts: A is [m][k] (row = 32 k's + 4 pad floats): the K-contiguous global float4 lands with ONE ds_write_b128
@@ -98,7 +110,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   // two LDS stages: tile t+1 is written while tile t is being multiplied -> ONE barrier per K tile, and a wave's
   // loader work is followed directly by its own MFMAs (the co-resident workgroup fills the MFMA pipe meanwhile)
-  constexpr int A_SZ = BM * AS, B_SZ = BN * BSK;
+  constexpr bool LP = PREC != 0;                 // bf16 operand tiles in LDS
+  constexpr int NPART = (PREC == 2) ? 2 : 1;     // hi (+ lo) parts
+  constexpr int ASB = 40;                        // bf16 row stride: 32 k's + 8 pad = 80 bytes (conflict-free b128 reads)
+  static_assert(!LP || (AMODE == A_VEC && BMODE != B_SCALAR), "low-precision modes exist for the vector loaders only");
+  constexpr int A_SZ = LP ? BM * ASB * NPART / 2 : BM * AS;     // in 4-byte units
+  constexpr int B_SZ = LP ? BN * ASB * NPART / 2 : BN * BSK;
   constexpr int AFF_SZ = (AMODE == A_VEC) ? BM * PG_MAX_SRC * 2 : 0;
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ) + BM * (sizeof(RowInfo) / 4) + AFF_SZ];
   float* const As0 = smem;
@@ -270,13 +287,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         rb[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.W) + boff[i]);
     } else if (BMODE == B_NN) {
       const int tap = kt / cpt;
-      const int n = nb0 + (tid % NN_CPR) * 4;
       if (tap != b_tap) {
         const int cc = (kt - tap * cpt) * BK;
         const int base = (taps_l[tap] >> 16) * p.wCout;
 #pragma unroll
         for (int i = 0; i < NN_PASS; ++i) {
-          const int kr = tid / NN_CPR + i * (256 / NN_CPR);
+          // fp32: lanes along n (coalesced float4 rows, [k][n] LDS image).  Low precision: lanes along k so that the
+          // transposing scatter into the [n][k] bf16 image is conflict-free
+          const int kr = LP ? (tid & 31) : (tid / NN_CPR + i * (256 / NN_CPR));
+          const int n = nb0 + (LP ? ((tid >> 5) + 8 * i) * 4 : (tid % NN_CPR) * 4);
           boff[i] = (unsigned)((base + cc + kr) * p.wCin + p.n_off + (n < p.n_cnt ? n : 0)) * 4u;
         }
         b_tap = tap;
@@ -308,9 +327,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     }
   };
 
+  // low-precision store: 4 consecutive k's of one row -> bf16 hi (and lo) parts, one ds_write_b64 each
+  auto store4_lp = [&](unsigned short* tile, int rows_in_tile, int row, int kq, const float (&t)[4]) {
+    const unsigned h01 = pack_bf16(t[0], t[1]), h23 = pack_bf16(t[2], t[3]);
+    *reinterpret_cast<uint2*>(tile + row * ASB + kq) = make_uint2(h01, h23);
+    if constexpr (PREC == 2) {
+      const unsigned l01 = pack_bf16(t[0] - bf16_lo_f32(h01), t[1] - bf16_hi_f32(h01));
+      const unsigned l23 = pack_bf16(t[2] - bf16_lo_f32(h23), t[3] - bf16_hi_f32(h23));
+      *reinterpret_cast<uint2*>(tile + rows_in_tile * ASB + row * ASB + kq) = make_uint2(l01, l23);
+    }
+  };
   auto store_tile = [&](int stage) {
     float* As = As0 + stage * A_SZ;
     float* Bs = Bs0 + stage * B_SZ;
+    if constexpr (LP) {
+      unsigned short* Ah = reinterpret_cast<unsigned short*>(As);
+      unsigned short* Bh = reinterpret_cast<unsigned short*>(Bs);
+      auto emit = [&](auto has_mask, auto act_c) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+          float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+          const float mk[4] = {rmask[i].x, rmask[i].y, rmask[i].z, rmask[i].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = fmaf(v[e], raa[i], rab[i]);
+            if constexpr (decltype(has_mask)::value) t *= mk[e];
+            if constexpr (decltype(act_c)::value == PG_ACT_RELU) t = fmaxf(t, 0.f);
+            if constexpr (decltype(act_c)::value == PG_ACT_LEAKY) t = fmaxf(t, 0.2f * t);
+            v[e] = t;
+          }
+          store4_lp(Ah, BM, (tid >> 3) + 32 * i, (tid & 7) * 4, v);
+        }
+      };
+      using T1 = std::integral_constant<bool, true>;
+      using T0 = std::integral_constant<bool, false>;
+      using AN = std::integral_constant<int, PG_ACT_NONE>;
+      using AR = std::integral_constant<int, PG_ACT_RELU>;
+      using AL = std::integral_constant<int, PG_ACT_LEAKY>;
+      if (a_has_mask) {
+        if (p.act == PG_ACT_RELU) emit(T1{}, AR{}); else if (p.act == PG_ACT_LEAKY) emit(T1{}, AL{}); else emit(T1{}, AN{});
+      } else {
+        if (p.act == PG_ACT_RELU) emit(T0{}, AR{}); else if (p.act == PG_ACT_LEAKY) emit(T0{}, AL{}); else emit(T0{}, AN{});
+      }
+      if constexpr (BMODE == B_NT) {
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+          float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+          if (b_edge && !(nb0 + (tid >> 3) + 32 * i < p.n_cnt)) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+          store4_lp(Bh, BN, (tid >> 3) + 32 * i, (tid & 7) * 4, v);
+        }
+      } else {   // B_NN: this thread holds 4 consecutive n at k = tid&31 -> transposing scatter of single bf16
+        const int kr = tid & 31;
+#pragma unroll
+        for (int i = 0; i < NN_PASS; ++i) {
+          const int nl = ((tid >> 5) + 8 * i) * 4;
+          float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+          if (b_edge && !(nb0 + nl < p.n_cnt)) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned h = pack_bf16(v[e], 0.f);
+            Bh[(nl + e) * ASB + kr] = (unsigned short)(h & 0xffffu);
+            if constexpr (PREC == 2) {
+              const unsigned l = pack_bf16(v[e] - bf16_lo_f32(h), 0.f);
+              Bh[BN * ASB + (nl + e) * ASB + kr] = (unsigned short)(l & 0xffffu);
+            }
+          }
+        }
+      }
+      return;
+    }
     if (AMODE == A_VEC) {
       // act((a*x+b)*mask): the activation / mask variant is picked once per tile (uniform), 2-4 VALU per element
       auto emit = [&](auto has_mask, auto act_c) {
@@ -460,6 +545,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   };
   static_assert(BK == 32, "the K loop below is written for 4 k-groups per tile");
 
+  if constexpr (LP) {
+    // -------- bf16 / bf16x3 K loop: 2 k-steps of 16 per tile on v_mfma_f32_32x32x16_bf16; lane (m=l31) reads its 8
+    // consecutive k's (16 bytes) per operand and k-step.  The loaders (same as fp32) bound this path.
+    if (kt0 < kt1) {
+      load_tile(kt0);
+      store_tile(0);
+      if (kt0 + 1 < kt1) load_tile(kt0 + 1);
+    }
+    __syncthreads();
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) {
+        store_tile(stage ^ 1);
+        if (kt + 2 < kt1) load_tile(kt + 2);
+      }
+      const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As0 + stage * A_SZ);
+      const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs0 + stage * B_SZ);
+      uint4 a[NPART][2][TM], b[NPART][2][TN];
+#pragma unroll
+      for (int q = 0; q < NPART; ++q)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            a[q][ks][i] = *reinterpret_cast<const uint4*>(Ah + q * BM * ASB + (wm0 + i * 32 + l31) * ASB + ks * 16 + lhi * 8);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            b[q][ks][j] = *reinterpret_cast<const uint4*>(Bh + q * BN * ASB + (wn0 + j * 32 + l31) * ASB + ks * 16 + lhi * 8);
+        }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (PREC == 2) {   // small terms first
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1][ks][i]),
+                                                                   __builtin_bit_cast(bf16x8, b[0][ks][j]), acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0][ks][i]),
+                                                                   __builtin_bit_cast(bf16x8, b[1][ks][j]), acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0][ks][i]),
+                                                                 __builtin_bit_cast(bf16x8, b[0][ks][j]), acc[i][j], 0, 0, 0);
+          }
+      __syncthreads();
+      stage ^= 1;
+    }
+  } else {
   // K loop.  Two LDS stages, two operand register sets (A/B).  Per tile:  [write tile t+1 to the other stage, issue the
   // global loads of tile t+2]  g1<-LDS | MFMA g0 | g2<-LDS | MFMA g1 | g3<-LDS | MFMA g2 | BARRIER | next g0<-LDS |
   // MFMA g3.  Every LDS read of the current stage is complete before the barrier (so the next iteration may overwrite
@@ -503,6 +636,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     __builtin_amdgcn_sched_barrier(0);
     stage ^= 1;
   }
+  }   // fp32 K loop
   if (kt0 >= kt1) return;   // empty split: contributes nothing
 
   // ------------------------------------------------------------------ epilogue
@@ -568,13 +702,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
 // ------------------------------------------------------------------------------------------- host side
 template <int BM, int BN, int WGM, int WGN>
-static void launch_cfg(const ConvK& k, int amode, int bmode, dim3 grid, hipStream_t st) {
+static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, dim3 grid, hipStream_t st) {
 #define PG_LAUNCH(A, B) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B>), grid, dim3(256), 0, st, k)
+#define PG_LAUNCH_LP(A, B, P) \
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B, P>), grid, dim3(256), 0, st, k)
+  if constexpr (WGN == 2) {   // low-precision operand modes: the three big vector-loader tiles only
+    if (prec != PG_PREC_F32 && amode == A_VEC && bmode != B_SCALAR) {
+      if (prec == PG_PREC_BF16 && bmode == B_NT) PG_LAUNCH_LP(A_VEC, B_NT, 1);
+      else if (prec == PG_PREC_BF16) PG_LAUNCH_LP(A_VEC, B_NN, 1);
+      else if (bmode == B_NT) PG_LAUNCH_LP(A_VEC, B_NT, 2);
+      else PG_LAUNCH_LP(A_VEC, B_NN, 2);
+      return;
+    }
+  }
   if (amode == A_VEC && bmode == B_NT) PG_LAUNCH(A_VEC, B_NT);
   else if (amode == A_VEC && bmode == B_NN) PG_LAUNCH(A_VEC, B_NN);
   else if (amode == A_VEC && bmode == B_SCALAR) PG_LAUNCH(A_VEC, B_SCALAR);
   else PG_LAUNCH(A_SCALAR, B_SCALAR);
 #undef PG_LAUNCH
+#undef PG_LAUNCH_LP
 }
 
 }  // namespace pg
@@ -587,6 +733,7 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   PG_REQUIRE(d->nsrc >= 1 && d->nsrc <= PG_MAX_SRC, "pg_conv: nsrc=%d", d->nsrc);
   PG_REQUIRE(d->KH * d->KW <= MAXTAP && d->stride >= 1 && d->stride <= 2, "pg_conv: unsupported kernel %dx%d s%d",
              d->KH, d->KW, d->stride);
+  PG_REQUIRE(d->precision >= PG_PREC_F32 && d->precision <= PG_PREC_BF16X3, "pg_conv: precision=%d", d->precision);
   ConvK k;
   memset(&k, 0, sizeof(k));
   k.nsrc = d->nsrc;
@@ -715,10 +862,10 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   }
   dim3 grid(mt, nt, k.nphase * ks);
   switch (cfg) {
-    case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, grid, st); break;
-    case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, grid, st); break;
-    case 2: launch_cfg<64, 64, 2, 2>(k, amode, bmode, grid, st); break;
-    default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, grid, st); break;
+    case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, grid, st); break;
+    case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, grid, st); break;
+    case 2: launch_cfg<64, 64, 2, 2>(k, amode, bmode, d->precision, grid, st); break;
+    default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
   last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16);

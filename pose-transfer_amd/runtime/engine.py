@@ -7,6 +7,7 @@ pre-activation (:150,152) and torch.cat (:241,245,271,284,286) are never materia
 carries a per-sample affine ``aff`` [N,2] and an optional channel mask [N,C] that consumers apply on
 load.  Parameters live in flat arenas (params / grads / Adam m / Adam v) in packed kernel layout.
 """
+import os
 import math
 
 import numpy as np
@@ -183,6 +184,11 @@ class Act:
         return s
 
 
+# MFMA operand precision of the forward / data-gradient contractions: 0 = fp32 (reference parity, default),
+# 1 = bf16 operands, 2 = bf16x3 split (include/posegan_hip.h PG_PREC_*).  Weight gradients always run in fp32.
+PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2}[os.environ.get("PG_PRECISION", "f32")]
+
+
 def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, transposed=False, scalar_in=False,
           out=None, out_strides=None, bias=None, out_act=L.OUT_NONE, dsts=None, n_off=0, n_cnt=0, ksplit=0):
     d = L.ConvDesc()
@@ -209,6 +215,7 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
             d.dst[i] = t
         d.ndst = len(dsts)
     d.ksplit = ksplit
+    d.precision = PRECISION
     if PROFILER is not None:
         sp = (Ho * Wo) if mode == 0 else (Hi * Wi)
         ncnt_ = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)

@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
                 ("out", C.c_void_p), ("bias", C.c_void_p),
                 ("oN", C.c_int64), ("oC", C.c_int64), ("oH", C.c_int64), ("oW", C.c_int64),
                 ("dst", Dst * PG_MAX_SRC),
-                ("ndst", C.c_int32), ("ksplit", C.c_int32)]
+                ("ndst", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

@@ -180,6 +180,31 @@ def test_conv_data_gradient(case, ksplit, acc):
         assert rel(g, r) < 1e-5, case.name
 
 
+# Operand-precision modes of pg_conv (include/posegan_hip.h PG_PREC_*).  fp32 is the parity path (tolerance 1e-5
+# above); bf16x3 (hi+lo split, 3 bf16 MFMAs per product) must stay fp32-class: relative error of the whole tensor
+# <= 5e-5 (product error ~2^-16 per term, random signs); plain bf16 is a mixed-precision option: <= 1e-2.
+PREC_TOL = {"bf16x3": 5e-5, "bf16": 1e-2}
+PREC_CASES = ["down_k4", "down_k4_odd", "down_k4_big", "down_small_m", "up_3src", "up_2src"]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("name", PREC_CASES)
+@pytest.mark.parametrize("ksplit", [1, 3])
+def test_conv_low_precision_modes(name, prec, ksplit, monkeypatch):
+    case = [c for c in conv_cases() if c.name == name][0]
+    monkeypatch.setattr(E, "PRECISION", {"bf16": 1, "bf16x3": 2}[prec])
+    out, dzs, _, _ = case.reference()
+    got = case.run_forward(ksplit)
+    assert (L.load().pg_last_launch_info() & 0xF) in (0, 1, 2), "expected a vector-loader tile"
+    assert rel(got, out) < PREC_TOL[prec], (name, prec, float(rel(got, out)))
+    gd = case.run_dgrad(ksplit, False)
+    for g, r in zip(gd, dzs):
+        assert rel(g, r) < PREC_TOL[prec], (name, prec, float(rel(g, r)))
+    if prec == "bf16":   # the mode must actually round operands: bit-identical-to-fp32 results would mean a silent fallback
+        monkeypatch.setattr(E, "PRECISION", 0)
+        assert rel(case.run_forward(ksplit), got) > 1e-5
+
+
 @pytest.mark.parametrize("name", ["final_k3", "disc_last"])
 def test_small_cout_data_gradient(name):
     """gradient through a 3- / 1-channel output: dY is a strided small-C operand (scalar A / scalar B path)."""
