@@ -17,7 +17,7 @@
 #include <type_traits>
 
 // -DPG_ABLATE=n builds diagnostic variants of the K loop (tools/ablate.sh): 1 = no global loads, 2 = no LDS stores,
-// 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only).  0 = the product kernel.
+// 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only), 128 = one workgroup per CU (LDS padding).  0 = the product kernel.
 #ifndef PG_ABLATE
 #define PG_ABLATE 0
 #endif
@@ -49,6 +49,7 @@ struct ConvK {
   pg_dst_t dst[PG_MAX_SRC];
   int ndst;
   int dstart[PG_MAX_SRC + 1];
+  int dst_uniform;          // every destination's C is a multiple of 32 (wave-uniform descriptor in the scatter)
 };
 
 struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
@@ -62,6 +63,7 @@ struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wc99-designator"
 __device__ __attribute__((aligned(16))) const float kOnes[2048] = {[0 ... 2047] = 1.0f};
+__device__ __attribute__((aligned(16))) const float kIdentAff[2] = {1.0f, 0.0f};
 #pragma clang diagnostic pop
 
 // f32 MFMA runs on the SIMD's fp32 lanes: every VALU instruction of a co-resident wave steals matrix throughput
@@ -122,6 +124,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   float* const Bs0 = smem + 2 * A_SZ;
   RowInfo* rows = reinterpret_cast<RowInfo*>(smem + 2 * (A_SZ + B_SZ));
   float* const affs = smem + 2 * (A_SZ + B_SZ) + BM * (sizeof(RowInfo) / 4);   // [row][src](a,b): deferred-norm affine
+#if (PG_ABLATE & 128)
+  __shared__ float pad_l[6000];              // diagnostic: push LDS past 80 KB -> one workgroup per CU
+  if (p.ksplit == 12345) pad_l[threadIdx.x] = 1.f;
+#endif
   __shared__ int taps_l[MAXTAP];             // this phase's (dy, dx, weight tap) packed: LDS, not kernarg vector loads
 
   const int tid = threadIdx.x;
@@ -641,6 +647,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   // ------------------------------------------------------------------ epilogue
   const bool atomic = p.ksplit > 1;
+  const int nbw = __builtin_amdgcn_readfirstlane(nb0 + wn0);   // wave-uniform first column (SGPR: uniform scatter path)
+  // NOTE: keep this free of lambdas that capture `p` and of runtime indices into p's arrays — either makes the
+  // compiler keep a scratch-memory copy of the whole kernel argument (and of acc[][] if these loops stay rolled).
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -659,41 +668,89 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           float* o = p.out + ((long)ri.n * p.oN + (long)ri.oy * p.oH + (long)ri.ox * p.oW) + (long)ng * p.oC;
           if (atomic) atomicAdd(o, g); else *o = g;
         }
-      } else {
-        int d = 0;
+      } else if constexpr (BMODE != B_SCALAR) {   // host guarantees dst_uniform for the vector weight loaders
+        // Data-gradient scatter, every destination's channel count a multiple of 32: the 32-column group of this
+        // MFMA tile lies in ONE destination, so the descriptor is wave-uniform (SGPRs).  All global loads of the 16
+        // rows are straight-line (dummy-but-valid addresses for absent rows) and issued before the first use: loads
+        // under divergent or even uniform branches make the compiler drain vmcnt at every join, which serialises
+        // 48 latencies per tile (measured: +25 % on the whole contraction).
+        const int ng0 = nbw + j * 32;
+        if (ng0 >= p.n_cnt) continue;
+        // constant-index field picks only: a runtime index into the by-value kernel argument would make the compiler
+        // copy the whole descriptor to scratch memory
+        float* gradp = p.dst[0].grad;
+        const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
+        int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0;
 #pragma unroll
-        for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.ndst && ng >= p.dstart[q]) d = q;
-        const pg_dst_t& ds = p.dst[d];
-        const int c = ng - p.dstart[d];
-        const float dslope = act_slope(ds.act);
-        // batch the forward-tensor loads of the 16 rows before any dependent store (latency, not bandwidth, bound)
-        float fz[16], mk[16];
-        long idx[16];
-        int rn[16];
+        for (int q = 1; q < PG_MAX_SRC; ++q)
+          if (q < p.ndst && ng0 >= p.dstart[q]) {
+            gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
+            C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q];
+          }
+        const int c = ng - cst;
+        const bool has_fwd = fwd0 != nullptr;
+        const float* const fwdp = has_fwd ? fwd0 : gradp;              // dummy reads when there is no activation
+        const float dslope = has_fwd ? act_slope(dact) : 1.f;          // slope 1: act' == 1 whatever was read
+        // absent affine / mask: identity tables instead of branches (one code path, loads always issued)
+        const bool fa_ = aff0 != nullptr && has_fwd, fm_ = mask0 != nullptr;
+        const float* const affp = fa_ ? aff0 : kIdentAff;
+        const float* const maskp = fm_ ? mask0 : kOnes;
+        const int affmul = fa_ ? 2 : 0;
+        const bool accum = dacc && !atomic;
+        float fz[16], mk[16], old[16];
+        float2 ab[16];
+        unsigned idx[16];
+        bool ok[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           const RowInfo ri = rows[row];
-          rn[r] = nval ? ri.n : -1;
-          idx[r] = (long)((ri.n * p.Ho + ri.oy) * p.Wo + ri.ox) * ds.C + c;
-          fz[r] = 0.f; mk[r] = 1.f;
-          if (rn[r] >= 0) {
-            if (ds.fwd) {
-              fz[r] = ds.fwd[idx[r]];
-              if (ds.aff) fz[r] = fz[r] * ds.aff[2 * rn[r]] + ds.aff[2 * rn[r] + 1];
-            }
-            if (ds.mask) mk[r] = ds.mask[(long)rn[r] * ds.C + c];
-          }
+          ok[r] = ri.n >= 0;
+          const int nn = ok[r] ? ri.n : 0;
+          idx[r] = ok[r] ? (unsigned)((nn * p.Ho + ri.oy) * p.Wo + ri.ox) * (unsigned)C + (unsigned)c : (unsigned)c;
+          fz[r] = fwdp[idx[r]];
+          ab[r] = *reinterpret_cast<const float2*>(affp + affmul * nn);
+          mk[r] = maskp[fm_ ? nn * C + c : (c & 511)];
+          old[r] = 0.f;
+        }
+        if (accum) {      // uniform; one extra batch of loads (encoder data-gradients add to the skip gradients)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = gradp[idx[r]];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (rn[r] < 0) continue;
+          const float z = fmaf(fz[r], ab[r].x, ab[r].y) * mk[r];
+          const float g = fmaf(acc[i][j][r] * mk[r], act_grad_s(z, dslope), old[r]);
+          if (ok[r]) {
+            if (atomic) atomicAdd(gradp + idx[r], g); else gradp[idx[r]] = g;
+          }
+        }
+      } else {
+        // generic scatter (destination channel counts not multiples of 32): per-lane destination, same arithmetic
+        pg_dst_t ds = p.dst[0];
+        int cst = 0;
+#pragma unroll
+        for (int q = 1; q < PG_MAX_SRC; ++q)
+          if (q < p.ndst && ng >= p.dstart[q]) { ds = p.dst[q]; cst = p.dstart[q]; }
+        const int c = ng - cst;
+        const float dslope = act_slope(ds.act);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const RowInfo ri = rows[row];
+          if (ri.n < 0 || !nval) continue;
+          const long idx = (long)((ri.n * p.Ho + ri.oy) * p.Wo + ri.ox) * ds.C + c;
           float g = acc[i][j][r];
-          if (ds.fwd) g *= act_grad_s(fz[r] * mk[r], dslope);
-          g *= mk[r];
-          if (atomic) atomicAdd(ds.grad + idx[r], g);
-          else if (ds.accumulate) ds.grad[idx[r]] += g;
-          else ds.grad[idx[r]] = g;
+          const float mkv = ds.mask ? ds.mask[(long)ri.n * ds.C + c] : 1.f;
+          if (ds.fwd) {
+            float z = ds.fwd[idx];
+            if (ds.aff) z = fmaf(z, ds.aff[2 * ri.n], ds.aff[2 * ri.n + 1]);
+            g *= act_grad_s(z * mkv, dslope);
+          }
+          g *= mkv;
+          if (atomic) atomicAdd(ds.grad + idx, g);
+          else if (ds.accumulate) ds.grad[idx] += g;
+          else ds.grad[idx] = g;
         }
       }
     }
@@ -754,6 +811,7 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   PG_REQUIRE(kfull == ctot, "pg_conv: operand channels %d != weight K dim %d", ctot, kfull);
   k.n_off = d->n_off;
   k.n_cnt = d->n_cnt > 0 ? d->n_cnt : nfull;
+  if (k.n_cnt % 32 != 0) k.dst_uniform = 0;
   PG_REQUIRE(k.n_off >= 0 && k.n_off + k.n_cnt <= nfull, "pg_conv: bad N sub-range");
   k.epilogue = d->epilogue; k.out_act = d->out_act; k.out = d->out; k.bias = d->bias;
   k.oN = d->oN; k.oC = d->oC; k.oH = d->oH; k.oW = d->oW;
@@ -796,6 +854,9 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
     int c = 0;
     for (int j = 0; j < d->ndst; ++j) { k.dst[j] = d->dst[j]; k.dstart[j] = c; c += d->dst[j].C; }
     for (int j = d->ndst; j <= PG_MAX_SRC; ++j) k.dstart[j] = c;
+    k.dst_uniform = 1;
+    for (int j = 0; j < d->ndst; ++j)
+      if (d->dst[j].C % 32 != 0 || (double)d->N * d->Ho * d->Wo * d->dst[j].C >= 4294967296.0) k.dst_uniform = 0;
     PG_REQUIRE(c == k.n_cnt, "pg_conv: dst channels %d != N %d", c, k.n_cnt);
   } else {
     PG_REQUIRE(d->out != nullptr, "pg_conv: out null");
@@ -811,6 +872,7 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   if (amode == A_SCALAR) bmode = B_SCALAR;
   else if (!d->w_transposed) bmode = B_NT;               // k contiguous: needs wCin%4 (true: Ctot%32==0)
   else bmode = (nvec_ok && d->wCin % 4 == 0) ? B_NN : B_SCALAR;
+  if (d->epilogue == 1 && !k.dst_uniform) bmode = B_SCALAR;   // the vector kernels carry the uniform scatter only
   // ---- tile config
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
   if (k.n_cnt <= 32) cfg = 3;

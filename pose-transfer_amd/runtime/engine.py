@@ -226,6 +226,14 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
     L.check(L.load().pg_conv(d, L.stream()), "pg_conv")
 
 
+def _conv_dgrad(gy_src, N, Hi, Wi, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, dsts, ksplit=0):
+    """Data-gradient of a layer whose packed weight is W [K][K][Cout][Cin]: contraction over (taps, Cout) of the
+    upstream gradient (N,Hi,Wi,Cout) into the layer input's (N,Ho,Wo,Cin), scattered to `dsts` with act'/mask applied.
+    (A per-tap pre-transposed weight copy was measured: no gain over reading the [k][n] operand directly.)"""
+    _conv([gy_src], N, Hi, Wi, L.ACT_NONE, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, transposed=True, dsts=dsts,
+          ksplit=ksplit)
+
+
 def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
     """First-layer convolution (few NCHW input channels -> 64 NHWC): repack the weights, then the patch kernel."""
     cin = sum(a.C for a in acts)
@@ -531,8 +539,8 @@ class GeneratorEngine:
             _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, dy, self.dec[i], cin, False, hi, wi, ho, wo, 4, 2, 1,
                    A.g(wkey))
             self._ready("decoder.net.%d." % i)
-            _conv([Act(dy, self.dec[i]).src()], N, ho, wo, L.ACT_NONE, 0, 4, 2, 1, hi, wi, A.p(wkey), self.dec[i], cin,
-                  transposed=True, dsts=self._dsts_for(srcs, True))
+            _conv_dgrad(Act(dy, self.dec[i]).src(), N, ho, wo, 0, 4, 2, 1, hi, wi, A.p(wkey), self.dec[i], cin,
+                        self._dsts_for(srcs, True))
         # ---- deformable skips
         for l in range(self.nwarp):
             L.call("pg_warp_mask_max_bwd", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
@@ -553,10 +561,10 @@ class GeneratorEngine:
                 _wgrad([xin.src()], N, L.ACT_LEAKY, dz, self.enc[l], self.enc[l - 1], True, ho, wo, hi, wi, 4, 2, 1,
                        A.g(wkey))
                 self._ready("%s.net.%d." % (e, l))
-                _conv([Act(dz, self.enc[l]).src()], N, ho, wo, L.ACT_NONE, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
-                      self.enc[l - 1], transposed=True,
-                      dsts=[L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
-                                       accumulate=True)])
+                _conv_dgrad(Act(dz, self.enc[l]).src(), N, ho, wo, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
+                            self.enc[l - 1],
+                            [L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
+                                        accumulate=True)])
         for e in self.encs:
             dz = self.e_dz[e][0]
             s0 = self._enc_in_src(e, self.input)
@@ -679,9 +687,9 @@ class DiscriminatorEngine:
                 _wgrad([xin.src()], M, L.ACT_LEAKY, dz, self.chans[j], self.chans[j - 1], True, self.hs[j], self.ws[j],
                        self.hs[j - 1], self.ws[j - 1], 4, 2, 1, A.g(wkey))
                 self._ready("net.%d." % j)
-            _conv([Act(dz, self.chans[j]).src()], M, self.hs[j], self.ws[j], L.ACT_NONE, 1, 4, 2, 1, self.hs[j - 1],
-                  self.ws[j - 1], A.p(wkey), self.chans[j], self.chans[j - 1], transposed=True,
-                  dsts=[L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)])
+            _conv_dgrad(Act(dz, self.chans[j]).src(), M, self.hs[j], self.ws[j], 1, 4, 2, 1, self.hs[j - 1],
+                        self.ws[j - 1], A.p(wkey), self.chans[j], self.chans[j - 1],
+                        [L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)])
         # stem
         dz0 = self.dz[0]
         cin = 3 + 2 * self.P + 3

@@ -148,8 +148,8 @@ class ConvCase:
         dsts = [L.make_dst(grads[j], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=self.act, accumulate=accumulate)
                 for j, a in enumerate(acts)]
         mode = 1 if self.kind == "conv" else 0          # the data-gradient runs the opposite geometry
-        E._conv([E.Act(gy, self.cout).src()], N, self.Ho, self.Wo, L.ACT_NONE, mode, self.K, self.stride, self.pad,
-                self.H, self.W, wp, self.cout, self.cin, transposed=True, dsts=dsts, ksplit=ksplit)
+        E._conv_dgrad(E.Act(gy, self.cout).src(), N, self.Ho, self.Wo, mode, self.K, self.stride, self.pad,
+                      self.H, self.W, wp, self.cout, self.cin, dsts, ksplit=ksplit)
         torch.cuda.synchronize()
         return [nchw(g.cpu()) - (0.5 if accumulate else 0.0) for g in grads]
 

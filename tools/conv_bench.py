@@ -50,8 +50,7 @@ def layer(name, kind, N, h, w, srcC, cout, K=4, stride=2, pad=1):
 
     def dgrad():
         dsts = [L.make_dst(d, a.C, fwd=a.t, aff=a.aff, act=act) for d, a in zip(dz, acts)]
-        E._conv([E.Act(gy, cout).src()], N, ho, wo, L.ACT_NONE, 1 - mode_f, K, stride, pad, h, w, W, cout, cin,
-                transposed=True, dsts=dsts)
+        E._conv_dgrad(E.Act(gy, cout).src(), N, ho, wo, 1 - mode_f, K, stride, pad, h, w, W, cout, cin, dsts)
 
     def wgrad():
         conv = kind == "conv"
