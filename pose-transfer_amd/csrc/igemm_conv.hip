@@ -17,7 +17,7 @@
 #include <type_traits>
 
 // -DPG_ABLATE=n builds diagnostic variants of the K loop (tools/ablate.sh): 1 = no global loads, 2 = no LDS stores,
-// 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only), 128 = one workgroup per CU (LDS padding).  0 = the product kernel.
+// 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only), 128 = one workgroup per CU (LDS padding), 256 = all global loads hit one 4 KB block.  0 = the product kernel.
 #ifndef PG_ABLATE
 #define PG_ABLATE 0
 #endif
@@ -82,6 +82,27 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // RNE,
 }
 __device__ __forceinline__ float bf16_lo_f32(unsigned packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16_hi_f32(unsigned packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// 128-bit load from GLOBAL memory at a wave-uniform base + per-lane byte offset.  The explicit address space keeps the
+// compiler from emitting FLAT loads when the base is a select of two pointers (FLAT counts on lgkmcnt as well and
+// would disturb the counted LDS waits); readfirstlane keeps the base in SGPRs (saddr form, no 64-bit VALU adds).
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float4 ldg128(const char* base, unsigned off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) const f32x4g gvec;
+  const f32x4g v = *reinterpret_cast<gvec*>(reinterpret_cast<unsigned long long>(base) + off);
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  (void)base; (void)off;
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+}
 
 template <int OFF>
 __device__ __forceinline__ void lds_read128(f32x4& v, unsigned addr) {
@@ -551,7 +572,209 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   };
   static_assert(BK == 32, "the K loop below is written for 4 k-groups per tile");
 
-  if constexpr (LP) {
+  constexpr bool PIPE = !LP && AMODE == A_VEC && BMODE != B_SCALAR && (PG_ABLATE & 255) == 0;
+  if constexpr (PIPE) {
+    // -------- software-pipelined fp32 K loop (vector loaders).
+    // The loader work of a tile is cut into 4 chunks (thread rows i with i % 4 == c) and chunk c travels with one of
+    // the four 16-MFMA groups of an iteration:  region = { global loads of chunk c-1 (tile t+2) | activation math +
+    // ds_write of chunk c (tile t+1) | MFMA group }, all straight-line, so the scheduler interleaves the VALU / LDS /
+    // VMEM instructions between the MFMAs of the SAME wave (sched_group_barrier pattern below) instead of leaving
+    // them to the co-resident workgroup.  Address updates (the only branchy part: a (tap, source) change rebuilds a
+    // row's offsets) sit between the regions.  Every chunk is loaded three regions (~3/4 tile) before it is stored.
+    // All loads and LDS stores are unconditional: past the last tile the cursor stops advancing (rows are re-read and
+    // written into an LDS stage nobody reads again).
+    if (kt0 >= kt1) return;               // empty split (block-uniform): contributes nothing
+    constexpr int B_CH = (BMODE == B_NT) ? B_ROWS : NN_PASS;
+    const float slope = act_slope(p.act);
+    const char* const w_base = uniform_ptr(reinterpret_cast<const char*>(p.W));
+    int ld_kt = kt0, ld_tap = kt0 / cpt, ld_ci = kt0 - (kt0 / cpt) * cpt;
+    int cur_tap = -1, cur_src = -1, cur_btap = -1;
+    bool chgA = true, chgB = true, has_mask = false;
+    unsigned stepA = 0, stepB = 0;
+    int srcC = 0, cl = 0, dyv = 0, dxv = 0, jsrc = 0, bbase = 0, bcc = 0;
+    bool bzero[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      bzero[i] = (BMODE == B_NT) ? !(nb0 + (tid >> 3) + 32 * i < p.n_cnt) : !(nb0 + (tid % NN_CPR) * 4 < p.n_cnt);
+
+    auto set_tile = [&](bool adv) {      // scalars of the tile the cursor points at (wave-uniform)
+      const int cc = ld_ci * BK;
+      int j = 0;
+#pragma unroll
+      for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && cc >= p.cstart[q]) j = q;
+      chgA = adv && (ld_tap != cur_tap || j != cur_src);
+      chgB = adv && ld_tap != cur_btap;
+      stepA = adv ? (unsigned)(BK * 4) : 0u;
+      stepB = adv ? ((BMODE == B_NT) ? (unsigned)(BK * 4) : (unsigned)(BK * p.wCin) * 4u) : 0u;
+      if (chgA) {
+        const float* sp = p.src[0].ptr; const float* sm = p.src[0].mask; int sC = p.src[0].C, cs = 0;
+#pragma unroll
+        for (int q = 1; q < PG_MAX_SRC; ++q)
+          if (q == j) { sp = p.src[q].ptr; sm = p.src[q].mask; sC = p.src[q].C; cs = p.cstart[q]; }
+        a_base = uniform_ptr(reinterpret_cast<const char*>(sp));
+        has_mask = sm != nullptr;
+        m_base = uniform_ptr(reinterpret_cast<const char*>(has_mask ? sm : kOnes));
+        srcC = sC; jsrc = j;
+        cl = cc - cs + (tid & 7) * 4;
+        const int tp = taps_l[ld_tap];
+        dyv = (int)(signed char)(tp & 0xff); dxv = (int)(signed char)((tp >> 8) & 0xff);
+        cur_tap = ld_tap; cur_src = j;
+      }
+      if (chgB) {
+        bbase = (taps_l[ld_tap] >> 16) * p.wCout;
+        bcc = cc;
+        cur_btap = ld_tap;
+      }
+    };
+    auto advance = [&]() {
+      const bool adv = ld_kt + 1 < kt1;
+      if (adv) { ++ld_kt; if (++ld_ci == cpt) { ld_ci = 0; ++ld_tap; } }
+      set_tile(adv);
+    };
+    auto update_chunk = [&](auto cc_) {
+      constexpr int c = decltype(cc_)::value;
+#pragma unroll
+      for (int i = c; i < A_ROWS; i += 4) {
+        if (chgA) {
+          const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
+          const bool ok = a_n[i] >= 0 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+          const int row = (tid >> 3) + 32 * i;
+          raa[i] = ok ? affs[(row * PG_MAX_SRC + jsrc) * 2] : 0.f;      // zero padding = affine (0, 0)
+          rab[i] = ok ? affs[(row * PG_MAX_SRC + jsrc) * 2 + 1] : 0.f;
+          const int nn = ok ? a_n[i] : 0;
+          const unsigned pix = ok ? (unsigned)((nn * p.Hi + iy) * p.Wi + ix) : 0u;
+          aoff[i] = (pix * (unsigned)srcC + (unsigned)cl) * 4u;
+          moff[i] = has_mask ? ((unsigned)(nn * srcC + cl) * 4u) : ((unsigned)(cl & 511) * 4u);
+        } else {
+          aoff[i] += stepA; moff[i] += stepA;
+        }
+      }
+#pragma unroll
+      for (int i = c; i < B_CH; i += 4) {
+        if (chgB) {
+          if constexpr (BMODE == B_NT) {
+            const int n = nb0 + (tid >> 3) + 32 * i;
+            boff[i] = (unsigned)((bbase + p.n_off + (n < p.n_cnt ? n : 0)) * p.wCin + bcc + (tid & 7) * 4) * 4u;
+          } else {
+            const int kr = tid / NN_CPR + i * (256 / NN_CPR);
+            const int n = nb0 + (tid % NN_CPR) * 4;
+            boff[i] = (unsigned)((bbase + bcc + kr) * p.wCin + p.n_off + (n < p.n_cnt ? n : 0)) * 4u;
+          }
+        } else {
+          boff[i] += stepB;
+        }
+      }
+    };
+    auto load_chunk = [&](auto cc_) {
+      constexpr int c = decltype(cc_)::value;
+#pragma unroll
+      for (int i = c; i < A_ROWS; i += 4) {
+        if constexpr ((PG_ABLATE & 256) != 0) {   // diagnostic: every load hits the same 4 KB (L1-resident)
+          ra[i] = ldg128(a_base, (unsigned)tid * 16u);
+          rmask[i] = ldg128(m_base, (unsigned)(tid & 31) * 16u);
+        } else {
+          ra[i] = ldg128(a_base, aoff[i]);
+          rmask[i] = ldg128(m_base, moff[i]);
+        }
+      }
+#pragma unroll
+      for (int i = c; i < B_CH; i += 4) {
+        if constexpr ((PG_ABLATE & 256) != 0) rb[i] = ldg128(w_base, (unsigned)tid * 16u);
+        else rb[i] = ldg128(w_base, boff[i]);
+      }
+    };
+    auto store_chunk = [&](int stage, auto cc_) {
+      constexpr int c = decltype(cc_)::value;
+      float* As = As0 + stage * A_SZ;
+      float* Bs = Bs0 + stage * B_SZ;
+#pragma unroll
+      for (int i = c; i < A_ROWS; i += 4) {
+        float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        const float mk[4] = {rmask[i].x, rmask[i].y, rmask[i].z, rmask[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = fmaf(v[e], raa[i], rab[i]) * mk[e];
+          v[e] = fmaxf(t, slope * t);          // slope 1 / 0 / 0.2 = none / relu / leaky-relu, no branch
+        }
+        *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * AS + (tid & 7) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+#pragma unroll
+      for (int i = c; i < B_CH; i += 4) {
+        float4 v = rb[i];
+        if (bzero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (BMODE == B_NT)
+          *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * BSK + (tid & 7) * 4]) = v;
+        else
+          *reinterpret_cast<float4*>(&Bs[(tid / NN_CPR + i * (256 / NN_CPR)) * BS + (tid % NN_CPR) * 4]) = v;
+      }
+    };
+    // interleave request for one region: the chunk's VMEM reads first, then 1 MFMA : VPER VALU, the LDS writes late
+    constexpr int NM = 4 * TM * TN;
+    constexpr int VPER = (28 + NM - 1) / NM;
+    auto interleave = [&]() {
+      __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+#pragma unroll
+      for (int k = 0; k < NM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);
+        if (k == NM / 2 || k == NM - 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+
+    float fa[2][TM][4] = {}, fb[2][TN][4] = {};
+    // prologue: tile kt0 -> stage 0; tile kt0+1 in registers, its chunk 0 already in stage 1; chunk 0 -> tile kt0+2
+    set_tile(true);
+    update_chunk(C0{}); update_chunk(C1{}); update_chunk(C2{}); update_chunk(C3{});
+    load_chunk(C0{}); load_chunk(C1{}); load_chunk(C2{}); load_chunk(C3{});
+    store_chunk(0, C0{}); store_chunk(0, C1{}); store_chunk(0, C2{}); store_chunk(0, C3{});
+    advance();
+    update_chunk(C0{}); update_chunk(C1{}); update_chunk(C2{}); update_chunk(C3{});
+    load_chunk(C0{}); load_chunk(C1{}); load_chunk(C2{}); load_chunk(C3{});
+    store_chunk(1, C0{});
+    advance();
+    update_chunk(C0{});
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(0, G0{}, fa[0], fb[0]);
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = kt + 1 < kt1;
+      fetch(stage, G1{}, fa[1], fb[1]);
+      PG_LDS_WAIT(NRD);
+      __builtin_amdgcn_s_setprio(1);
+      load_chunk(C0{}); store_chunk(stage ^ 1, C1{}); mfma_group(fa[0], fb[0]); interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      update_chunk(C1{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(stage, G2{}, fa[0], fb[0]);
+      PG_LDS_WAIT(NRD);
+      load_chunk(C1{}); store_chunk(stage ^ 1, C2{}); mfma_group(fa[1], fb[1]); interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      update_chunk(C2{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(stage, G3{}, fa[1], fb[1]);
+      PG_LDS_WAIT(NRD);
+      load_chunk(C2{}); store_chunk(stage ^ 1, C3{}); mfma_group(fa[0], fb[0]); interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      update_chunk(C3{});
+      __builtin_amdgcn_sched_barrier(0);
+      PG_LDS_WAIT(0);                      // this wave's reads of `stage` and writes of `stage^1` are complete
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) fetch(stage ^ 1, G0{}, fa[0], fb[0]);
+      load_chunk(C3{}); store_chunk(stage, C0{}); mfma_group(fa[1], fb[1]); interleave();   // chunk 0 of tile kt+2
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      advance();
+      update_chunk(C0{});
+      __builtin_amdgcn_sched_barrier(0);
+      stage ^= 1;
+    }
+  } else if constexpr (LP) {
     // -------- bf16 / bf16x3 K loop: 2 k-steps of 16 per tile on v_mfma_f32_32x32x16_bf16; lane (m=l31) reads its 8
     // consecutive k's (16 bytes) per operand and k-step.  The loaders (same as fp32) bound this path.
     if (kt0 < kt1) {
