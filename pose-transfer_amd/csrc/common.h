@@ -67,6 +67,39 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 // branch-free forms: slope = 0 (ReLU), 0.2 (LeakyReLU), 1 (identity); exact for every finite input
+// 128-bit load from GLOBAL memory at a wave-uniform base + per-lane byte offset.  The explicit address space keeps the
+// compiler from emitting FLAT loads when the base is a select of two pointers (FLAT counts on lgkmcnt as well and
+// would disturb the counted LDS waits); readfirstlane keeps the base in SGPRs (saddr form, no 64-bit VALU adds).
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float4 ldg128(const char* base, unsigned off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) const f32x4g gvec;
+  const f32x4g v = *reinterpret_cast<gvec*>(reinterpret_cast<unsigned long long>(base) + off);
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  (void)base; (void)off;
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+}
+__device__ __forceinline__ float2 ldg64(const char* base, unsigned off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x2g __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) const f32x2g gvec;
+  const f32x2g v = *reinterpret_cast<gvec*>(reinterpret_cast<unsigned long long>(base) + off);
+  return make_float2(v[0], v[1]);
+#else
+  (void)base; (void)off;
+  return make_float2(0.f, 0.f);
+#endif
+}
+
+
 __device__ __forceinline__ float act_slope(int act) { return act == PG_ACT_RELU ? 0.f : (act == PG_ACT_LEAKY ? 0.2f : 1.f); }
 __device__ __forceinline__ float apply_act_s(float v, float slope) { return fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)); }
 __device__ __forceinline__ float act_grad_s(float z, float slope) { return z > 0.f ? 1.f : slope; }

@@ -83,27 +83,6 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // RNE,
 __device__ __forceinline__ float bf16_lo_f32(unsigned packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16_hi_f32(unsigned packed) { return __uint_as_float(packed & 0xffff0000u); }
 
-// 128-bit load from GLOBAL memory at a wave-uniform base + per-lane byte offset.  The explicit address space keeps the
-// compiler from emitting FLAT loads when the base is a select of two pointers (FLAT counts on lgkmcnt as well and
-// would disturb the counted LDS waits); readfirstlane keeps the base in SGPRs (saddr form, no 64-bit VALU adds).
-__device__ __forceinline__ const char* uniform_ptr(const char* q) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ float4 ldg128(const char* base, unsigned off) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef float f32x4g __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(1))) const f32x4g gvec;
-  const f32x4g v = *reinterpret_cast<gvec*>(reinterpret_cast<unsigned long long>(base) + off);
-  return make_float4(v[0], v[1], v[2], v[3]);
-#else
-  (void)base; (void)off;
-  return make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-}
-
 template <int OFF>
 __device__ __forceinline__ void lds_read128(f32x4& v, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));

@@ -9,6 +9,7 @@
 // single ds_write_b128.  X carries the forward prologue (deferred per-sample norm, dropout mask, activation) and
 // the virtual concat of up to 4 sources.  K is split across workgroups (float atomics into the zeroed dW).
 #include "common.h"
+#include <type_traits>
 
 namespace pg {
 
@@ -49,7 +50,7 @@ __device__ __forceinline__ Pix decode_pix(const WgradK& p, int k, int r, int s) 
   q.sx = rem - q.sy * p.Ws;
   q.ly = q.sy * p.stride + r - p.pad;
   q.lx = q.sx * p.stride + s - p.pad;
-  q.lok = q.ly >= 0 && q.ly < p.Hl && q.lx >= 0 && q.lx < p.Wl;
+  q.lok = (q.ly >= 0) & (q.ly < p.Hl) & (q.lx >= 0) & (q.lx < p.Wl);   // bitwise: no short-circuit control flow
   return q;
 }
 
@@ -68,13 +69,23 @@ __device__ __forceinline__ void pix_advance(const WgradK& p, PixState& st, int a
   if (st.sx >= p.Ws) { st.sx -= p.Ws; st.sy += 1; }
   if (st.sy >= p.Hs) { const int q = st.sy / p.Hs; st.n += q; st.sy -= q * p.Hs; }
 }
+// branch-free variant: the step is pre-split into (samples, rows, columns) with rows < Hs and columns < Ws
+__device__ __forceinline__ void pix_advance3(const WgradK& p, PixState& st, int advn, int advy, int advx) {
+  st.sx += advx;
+  const bool cx = st.sx >= p.Ws;
+  st.sx -= cx ? p.Ws : 0;
+  st.sy += advy + (cx ? 1 : 0);
+  const bool cy = st.sy >= p.Hs;
+  st.sy -= cy ? p.Hs : 0;
+  st.n += advn + (cy ? 1 : 0);
+}
 __device__ __forceinline__ Pix pix_of(const WgradK& p, const PixState& st, int r, int s) {
   Pix q;
   q.n = st.n < p.N ? st.n : -1;
   q.sy = st.sy; q.sx = st.sx;
   q.ly = st.sy * p.stride + r - p.pad;
   q.lx = st.sx * p.stride + s - p.pad;
-  q.lok = q.ly >= 0 && q.ly < p.Hl && q.lx >= 0 && q.lx < p.Wl;
+  q.lok = (q.ly >= 0) & (q.ly < p.Hl) & (q.lx >= 0) & (q.lx < p.Wl);   // bitwise: no short-circuit control flow
   return q;
 }
 
@@ -267,31 +278,164 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     }
   };
 
-  load_tile(kt0);
-  store_tile(0);
-  if (kt0 + 1 < kt1) load_tile(kt0 + 1);
-  __syncthreads();
-  int stage = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    if (kt + 1 < kt1) {
-      store_tile(stage ^ 1);
-      if (kt + 2 < kt1) load_tile(kt + 2);
-    }
-    float fa[2][TM][4], fb[2][TN][4];
-    fetch(stage, 0, fa[0], fb[0]);
+  constexpr bool PIPE = !XS && !YS && WGK == 1 && NG == 4;
+  if constexpr (PIPE) {
+    // -------- software-pipelined K loop (vector loaders): pass i of the loaders (A pass i + B pass i, i = 0..3) travels
+    // with k-group g == i of the MFMAs: region g = { activation math + ds_write of pass g (tile t+1) | pixel-state
+    // advance + global loads of pass g (tile t+2) | LDS fetch of group g+1 | 16 MFMAs of group g }, one basic block,
+    // interleaved by the sched_group_barrier pattern.  Loads and stores are unconditional: past the last tile a pass
+    // stops advancing and re-reads its rows (stored into an LDS stage nobody reads again).  Explicit global-address-
+    // space loads (no FLAT) off wave-uniform bases.
+    static_assert(A_PASS <= 4 && B_PASS <= 4, "one loader pass per k-group");
+    const pg_src_t& sx0 = p.src[0];
+    const float* xp = sx0.ptr; const float* xa = sx0.aff; const float* xm = sx0.mask; int xC = sx0.C, xcs = 0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) fetch(stage, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+    for (int q = 1; q < PG_MAX_SRC; ++q)
+      if (q == jsrc) { xp = p.src[q].ptr; xa = p.src[q].aff; xm = p.src[q].mask; xC = p.src[q].C; xcs = p.cstart[q]; }
+    const char* const x_base = uniform_ptr(reinterpret_cast<const char*>(xp));
+    const bool has_aff = xa != nullptr, has_mask = xm != nullptr;
+    const char* const aff_base = uniform_ptr(reinterpret_cast<const char*>(has_aff ? xa : kIdentAff));
+    const char* const m_base = uniform_ptr(reinterpret_cast<const char*>(has_mask ? xm : kOnesW));
+    const char* const y_base = uniform_ptr(reinterpret_cast<const char*>(p.dY));
+    const int cl = ci0 - xcs + (tid % B_CPR) * 4;
+    const int co = co0 + (tid % A_CPR) * 4;
+    const bool cok = co < p.Cout;
+    // launch-uniform flags held in VGPRs on purpose: selects on them compile to v_cndmask instead of scalar branches,
+    // which would cut the regions below into several basic blocks (nothing is interleaved across a branch)
+    int xl_v = p.x_is_large, hm_v = has_mask ? 1 : 0;
+    asm volatile("" : "+v"(xl_v), "+v"(hm_v));
+    const bool xl = xl_v != 0, hm = hm_v != 0;
+    const unsigned affmul = has_aff ? 8u : 0u;
+    int kc[4] = {kt0, kt0, kt0, kt0};           // tile each pass loads next (clamped at the last tile)
+    const int hw3 = p.Hs * p.Ws;
+    const int advn3 = WBK / hw3, advy3 = (WBK - advn3 * hw3) / p.Ws, advx3 = WBK - advn3 * hw3 - advy3 * p.Ws;
+    float2 rab2[B_PASS];
+
+    auto load_pass = [&](auto ic, bool first) {
+      constexpr int i = decltype(ic)::value;
+      const bool adv = !first && kc[i] + 1 < kt1;
+      if (adv) ++kc[i];
+      const int an = adv ? advn3 : 0, ay = adv ? advy3 : 0, ax = adv ? advx3 : 0;
+      if constexpr (i < A_PASS) {
+        // x_is_large: dY is the small tensor, dense [pixel][co]; otherwise dY is addressed through the tap geometry
+        const int k = kc[i] * WBK + tid / A_CPR + i * (256 / A_CPR);
+        pix_advance3(p, a_st[i], an, ay, ax);
+        const Pix q = pix_of(p, a_st[i], r, s);
+        const bool ok = cok & ((xl & (k < p.Kpix)) | (!xl & (q.n >= 0) & q.lok));   // bitwise on purpose
+        const unsigned pixa = xl ? (unsigned)k : (unsigned)((q.n * p.Hl + q.ly) * p.Wl + q.lx);
+        const unsigned off = ok ? (pixa * (unsigned)p.Cout + (unsigned)co) * 4u : 0u;
+        a_ok = (a_ok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+        ra[i] = ldg128(y_base, off);
+      }
+      if constexpr (i < B_PASS) {
+        pix_advance3(p, b_st[i], an, ay, ax);
+        const Pix q = pix_of(p, b_st[i], r, s);
+        const bool ok = (q.n >= 0) & (q.lok | !xl);
+        b_ok = (b_ok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+        const int nn = ok ? q.n : 0;
+        const int pixl = (q.n * p.Hl + q.ly) * p.Wl + q.lx, pixs = kc[i] * WBK + tid / B_CPR + i * (256 / B_CPR);
+        const int pixidx = ok ? (xl ? pixl : pixs) : 0;
+        rb[i] = ldg128(x_base, ((unsigned)pixidx * (unsigned)xC + (unsigned)cl) * 4u);
+        rab2[i] = ldg64(aff_base, (unsigned)nn * affmul);
+        const unsigned mo1 = ((unsigned)nn * (unsigned)xC + (unsigned)cl) * 4u, mo0 = (unsigned)(cl & 511) * 4u;
+        rbm[i] = ldg128(m_base, hm ? mo1 : mo0);
+      }
+    };
+    auto store_pass = [&](int stage, auto ic) {
+      constexpr int i = decltype(ic)::value;
+      float* As = As0 + stage * A_SZ;
+      float* Bs = Bs0 + stage * B_SZ;
+      if constexpr (i < A_PASS) {
+        const int pr = tid / A_CPR + i * (256 / A_CPR);
+        *reinterpret_cast<float4*>(&As[pr * AS + (tid % A_CPR) * 4]) =
+            ((a_ok >> i) & 1u) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if constexpr (i < B_PASS) {
+        const int pr = tid / B_CPR + i * (256 / B_CPR);
+        const bool ok = (b_ok >> i) & 1u;
+        float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+        const float mk[4] = {rbm[i].x, rbm[i].y, rbm[i].z, rbm[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = fmaf(v[e], rab2[i].x, rab2[i].y) * mk[e];
+          v[e] = ok ? fmaxf(t, slope * t) : 0.f;
+        }
+        *reinterpret_cast<float4*>(&Bs[pr * BS + (tid % B_CPR) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    };
+    constexpr int NM = 4 * TM * TN;
+    constexpr int VPER = (44 + NM - 1) / NM;
+    auto interleave = [&]() {
+#pragma unroll
+      for (int k = 0; k < NM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (4 * (TM + TN) + NM - 1) / NM, 0);
+        if (k == NM / 2 || k == NM / 2 + 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (k >= NM - 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto mfma16 = [&](const float (&fa)[TM][4], const float (&fb)[TN][4]) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
-    }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
+    // the pixel states were initialised AT tile kt0: the first load of every pass must not advance them
+    load_pass(I0{}, true); load_pass(I1{}, true); load_pass(I2{}, true); load_pass(I3{}, true);
+    store_pass(0, I0{}); store_pass(0, I1{}); store_pass(0, I2{}); store_pass(0, I3{});
+    load_pass(I0{}, false); load_pass(I1{}, false); load_pass(I2{}, false); load_pass(I3{}, false);
     __syncthreads();
-    stage ^= 1;
+    int stage = 0;
+    float fa[2][TM][4], fb[2][TN][4];
+    for (int kt = kt0; kt < kt1; ++kt) {
+      fetch(stage, 0, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      store_pass(stage ^ 1, I0{}); load_pass(I0{}, false); fetch(stage, 1, fa[1], fb[1]); mfma16(fa[0], fb[0]); interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      store_pass(stage ^ 1, I1{}); load_pass(I1{}, false); fetch(stage, 2, fa[0], fb[0]); mfma16(fa[1], fb[1]); interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      store_pass(stage ^ 1, I2{}); load_pass(I2{}, false); fetch(stage, 3, fa[1], fb[1]); mfma16(fa[0], fb[0]); interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      store_pass(stage ^ 1, I3{}); load_pass(I3{}, false); mfma16(fa[1], fb[1]); interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      stage ^= 1;
+    }
+  } else {
+  load_tile(kt0);
+    store_tile(0);
+    if (kt0 + 1 < kt1) load_tile(kt0 + 1);
+    __syncthreads();
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) {
+        store_tile(stage ^ 1);
+        if (kt + 2 < kt1) load_tile(kt + 2);
+      }
+      float fa[2][TM][4], fb[2][TN][4];
+      fetch(stage, 0, fa[0], fb[0]);
+  #pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) fetch(stage, g + 1, fa[(g + 1) & 1], fb[(g + 1) & 1]);
+  #pragma unroll
+        for (int e = 0; e < 4; ++e)
+  #pragma unroll
+          for (int i = 0; i < TM; ++i)
+  #pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][e], fb[g & 1][j][e], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      stage ^= 1;
+    }
   }
 
   const bool atomic = (p.ksplit > 1) || (WGK > 1);
