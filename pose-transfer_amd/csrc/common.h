@@ -87,6 +87,15 @@ __device__ __forceinline__ float4 ldg128(const char* base, unsigned off) {
   return make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
 }
+__device__ __forceinline__ float ldg32(const char* base, long off) {      // per-lane base allowed
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(1))) const float gf;
+  return *reinterpret_cast<gf*>(reinterpret_cast<unsigned long long>(base) + (unsigned long long)off);
+#else
+  (void)base; (void)off;
+  return 0.f;
+#endif
+}
 __device__ __forceinline__ float2 ldg64(const char* base, unsigned off) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef float f32x2g __attribute__((ext_vector_type(2)));

@@ -162,15 +162,17 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     } else {
       const Pix q = pix_of(p, a_st[0], r, s);
       pix_advance(p, a_st[0], advy, advx);
+      // strided dY (scalar mode): address and validity computed branch-free, the load itself is unconditional
+      // (loads under divergent branches are serialised by a vmcnt(0) at every join)
+      const bool xl = p.x_is_large != 0;
+      const bool pok = (q.n >= 0) & (xl | q.lok);
+      const long pbase = (long)(q.n >= 0 ? q.n : 0) * p.yN + (long)(xl ? q.sy : q.ly) * p.yH + (long)(xl ? q.sx : q.lx) * p.yW;
 #pragma unroll
       for (int e = 0; e < A_SC; ++e) {
         const int co = co0 + (tid >> 5) + 8 * e;
-        float v = 0.f;
-        if (q.n >= 0 && co < p.Cout) {
-          if (p.x_is_large) v = p.dY[(long)q.n * p.yN + (long)co * p.yC + (long)q.sy * p.yH + (long)q.sx * p.yW];
-          else if (q.lok) v = p.dY[(long)q.n * p.yN + (long)co * p.yC + (long)q.ly * p.yH + (long)q.lx * p.yW];
-        }
-        ras[e] = v;
+        const bool ok = pok & (co < p.Cout);
+        const float v = ldg32(reinterpret_cast<const char*>(p.dY), ok ? (pbase + (long)co * p.yC) * 4 : 0);
+        ras[e] = ok ? v : 0.f;
       }
     }
     // ---------------- B = X  [pixel][ci]
@@ -196,20 +198,25 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     } else {
       const Pix q = pix_of(p, b_st[0], r, s);
       pix_advance(p, b_st[0], advy, advx);
+      const bool xl = p.x_is_large != 0;
+      const bool pok = (q.n >= 0) & (q.lok | !xl);
+      const long nn = q.n >= 0 ? q.n : 0, yy = xl ? q.ly : q.sy, xx = xl ? q.lx : q.sx;
 #pragma unroll
       for (int e = 0; e < B_SC; ++e) {
         const int ci = ci0 + (tid >> 5) + 8 * e;
-        float v = 0.f;
-        if (q.n >= 0 && ci < p.Ctot) {
-          int j = 0;
+        // per-lane source pick with constant indices only, then ONE unconditional load (see the dY note above)
+        const float* sp = p.src[0].ptr;
+        long sN = p.src[0].sN, sC = p.src[0].sC, sH = p.src[0].sH, sW = p.src[0].sW;
+        int cs = 0;
 #pragma unroll
-          for (int t = 1; t < PG_MAX_SRC; ++t) if (t < p.nsrc && ci >= p.cstart[t]) j = t;
-          const pg_src_t& sx = p.src[j];
-          const long cbase = (long)q.n * sx.sN + (long)(ci - p.cstart[j]) * sx.sC;
-          if (p.x_is_large) { if (q.lok) v = sx.ptr[cbase + (long)q.ly * sx.sH + (long)q.lx * sx.sW]; }
-          else v = sx.ptr[cbase + (long)q.sy * sx.sH + (long)q.sx * sx.sW];
-        }
-        rbs[e] = v;
+        for (int t = 1; t < PG_MAX_SRC; ++t)
+          if (t < p.nsrc && ci >= p.cstart[t]) {
+            sp = p.src[t].ptr; sN = p.src[t].sN; sC = p.src[t].sC; sH = p.src[t].sH; sW = p.src[t].sW; cs = p.cstart[t];
+          }
+        const bool ok = pok & (ci < p.Ctot);
+        const long off = ok ? (nn * sN + (long)(ci - cs) * sC + yy * sH + xx * sW) * 4 : 0;
+        const float v = ldg32(reinterpret_cast<const char*>(sp), off);
+        rbs[e] = ok ? v : 0.f;
       }
     }
   };

@@ -158,37 +158,32 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const 
   const int n = blockIdx.y;
   if (threadIdx.x < T) th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
   __syncthreads();
-  const int cpp = C >> 2;
-  const long items = (long)h * w * cpp;
+  // One lane per (pixel, channel): every element has exactly ONE selected transform (the forward argmax), so a lane
+  // computes the taps of its own transform and issues its four corner atomics once — 4 atomic instructions per 64
+  // elements with all lanes active, instead of looping the wave over the T transforms with ~1/T of the lanes live.
+  // Lanes of one pixel that share a transform hit consecutive addresses (coalesced within the atomic).
+  const long items = (long)h * w * C;
   float* db = dfeat + (long)n * h * w * C;
+  const long nb = (long)n * h * w;
   for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-    const int cc = (int)(it % cpp) * 4;
-    const int pix = (int)(it / cpp);
+    const int pix = (int)(it / C);
+    const int c = (int)(it - (long)pix * C);
     const int i = pix / w, j = pix - i * w;
-    const long o = ((long)n * h * w + pix) * C + cc;
-    const uchar4 am = *reinterpret_cast<const uchar4*>(amax + o);
-    const float4 g4 = *reinterpret_cast<const float4*>(gout + o);
-    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-    const int a4[4] = {am.x, am.y, am.z, am.w};
-    const float* mp = masks + ((long)n * h * w + pix) * T;
-    for (int t = 0; t < T; ++t) {
-      if (a4[0] != t && a4[1] != t && a4[2] != t && a4[3] != t) continue;
-      const float m = mp[t];
-      const Taps tp = make_taps(th[t], i, j, h, w, align);
-      const float wg[4] = {tp.w00, tp.w01, tp.w10, tp.w11};
+    const long o = (nb + pix) * C + c;
+    const int t = amax[o];
+    const float g = gout[o];
+    const bool live = t < T;                       // 255: no transform won (all masks zero) -> no gradient
+    const int tt = live ? t : 0;
+    const float m = masks[(nb + pix) * T + tt];
+    const Taps tp = make_taps(th[tt], i, j, h, w, align);
+    const float gm = live ? g * m : 0.f;
+    const float wg[4] = {tp.w00, tp.w01, tp.w10, tp.w11};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int xx = tp.x0 + (k & 1), yy = tp.y0 + (k >> 1);
-        if (xx >= 0 && xx < w && yy >= 0 && yy < h) {
-          float* d = db + ((long)yy * w + xx) * C + cc;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (a4[e] == t) {
-              const float v = g[e] * m * wg[k];
-              if (v != 0.f) atomicAdd(d + e, v);     // ReLU'd consumers make about half of the gradients exact zeros
-            }
-        }
-      }
+    for (int k = 0; k < 4; ++k) {
+      const int xx = tp.x0 + (k & 1), yy = tp.y0 + (k >> 1);
+      const float v = gm * wg[k];
+      // ReLU'd consumers make about half of the gradients exact zeros
+      if (v != 0.f && xx >= 0 && xx < w && yy >= 0 && yy < h) atomicAdd(db + ((long)yy * w + xx) * C + c, v);
     }
   }
 }
@@ -211,6 +206,12 @@ extern "C" int pg_mask_pyramid(const void* masks, int32_t is_f64, int32_t N, int
                        (const float*)masks, N, T, H0, W0, h, w, out);
   PG_LAUNCH_OK("pg_mask_pyramid");
   return 0;
+}
+
+static int warp_bwd_grid(int C, int h, int w) {
+  long b = ((long)h * w * C + 255) / 256;
+  if (b > 8192) b = 8192;
+  return (int)b;
 }
 
 static int warp_grid(int C, int h, int w) {
@@ -236,7 +237,7 @@ extern "C" int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, co
                                     int32_t H0, int32_t W0, int32_t align_corners, float* dfeat, void* stream) {
   PG_REQUIRE(gout && argmax && warps && lvl_masks && dfeat, "pg_warp_mask_max_bwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_bwd: need T<=32, C%%4==0");
-  hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
+  hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
                      warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
   PG_LAUNCH_OK("pg_warp_mask_max_bwd");
   return 0;
