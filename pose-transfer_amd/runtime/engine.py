@@ -372,7 +372,8 @@ class GeneratorEngine:
         cin0 = {"encoder_app": 3 + pose_dim, "encoder_pose": pose_dim, "encoder": 3 + 2 * pose_dim}
         self.wt0 = {e: torch.empty(cin0[e] * 9 * 64, **f32) for e in self.encs}    # [Cin][9][64] repack of conv 0
         self.y_taps = torch.empty(N, H, W, 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
-        self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh) for its weight gradient
+        self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh): weight- and data-gradient operand
+        self.wt_out = torch.zeros((2 if deformable else 1) * self.enc[0] + self.dec[-2], 32, **f32)   # [cin][(tap, co)]
         self.warps = torch.empty(N, T_WARPS, 8, **f32)
         self.input = None
         self._drop_counter = 0
@@ -521,10 +522,11 @@ class GeneratorEngine:
         _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, self.g_taps, 32, cin, True, H, W, H, W, 1, 1, 0, A.g(wkey),
                cout_store=27)
         self._ready("decoder.net.%d." % (i + 1))
-        dsts = self._dsts_for(srcs, True)
-        arr = (L.Dst * len(dsts))(*dsts)
-        L.call("pg_small_cout_dgrad", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3,
-               L.ptr(A.p(wkey)), arr, len(dsts), L.stream())
+        # data-gradient of the 3-channel output conv = one K=32 contraction of the same im2col'd gradient with the
+        # weight viewed as [27 (tap, co)][cin] (transposed, zero-padded to 32), scattered with relu' / dropout mask
+        self.wt_out[:, :27].copy_(A.p(wkey).view(27, cin).t())
+        _conv([Act(self.g_taps, 32).src()], N, H, W, L.ACT_NONE, 0, 1, 1, 0, H, W, self.wt_out, cin, 32,
+              dsts=self._dsts_for(srcs, True))
         # ---- up blocks
         for i in range(self.ndec - 2, -1, -1):
             srcs = self._dec_sources(i)
