@@ -87,6 +87,9 @@ typedef struct {
   int32_t ksplit;           /* 0 = auto; >1 splits K across workgroups (atomic accumulate)         */
   int32_t precision;        /* PG_PREC_*: MFMA operand format (storage and accumulation stay fp32)  */
   int32_t reserved0;
+  double* stats;            /* optional [N][PG_STAT_SLOTS][2], caller-zeroed: per-sample (sum, sum of squares) of the stored output =
+                               pg_norm_stats of `out` (the following per-sample norm, models/networks.py:159), fused
+                               into the epilogue when the launch is not split-K; epilogue 0, dense NHWC only        */
 } pg_conv_t;
 
 /* MFMA operand precision of pg_conv.  F32 is the reference-parity path and the default everywhere; BF16X3 splits
@@ -150,8 +153,10 @@ int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_
 
 /* ---- per-sample normalisation: nn.InstanceNorm3d(1, eps=1e-3, affine=True) on x.unsqueeze(1)
  *      (models/networks.py:159,166-169) = LayerNorm over (C,H,W) with scalar gamma/beta.
- * stats: per-sample sum / sum of squares (double, caller zero-initialises `sums` [N][2]).
+ * stats: per-sample sum / sum of squares (double); the caller zero-initialises `sums` [N][PG_STAT_SLOTS][2] — partial
+ *        sums are spread over PG_STAT_SLOTS slots per sample (no single hot atomic address), finalize adds them up.
  * finalize: mr[N][2] = (mean, rstd);  aff[N][2] = (gamma*rstd, beta - gamma*mean*rstd).            */
+#define PG_STAT_SLOTS 16
 int pg_norm_stats(const float* y, int32_t N, int64_t L, double* sums, void* stream);
 int pg_norm_finalize(const double* sums, const float* gamma, const float* beta, int32_t N, int64_t L,
                      float eps, float* mr, float* aff, void* stream);

@@ -49,6 +49,7 @@ struct ConvK {
   pg_dst_t dst[PG_MAX_SRC];
   int ndst;
   int dstart[PG_MAX_SRC + 1];
+  double* stats;            // epilogue 0, ksplit 1: per-sample (sum, sum of squares) of the stored values, or null
   int dst_uniform;          // every destination's C is a multiple of 32 (wave-uniform descriptor in the scatter)
 };
 
@@ -90,6 +91,12 @@ __device__ __forceinline__ void lds_read128(f32x4& v, unsigned addr) {
 template <int OFF>
 __device__ __forceinline__ void lds_read32(float& v, unsigned addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
+// rare path of the fused statistics (a wave tile spanning more than two samples: only the 4x4 / 8x8 layers)
+__device__ __noinline__ void stat_spill(double* stats, int n, float g) {
+  atomicAdd(&stats[(long)n * PG_STAT_SLOTS * 2], (double)g);
+  atomicAdd(&stats[(long)n * PG_STAT_SLOTS * 2 + 1], (double)g * (double)g);
 }
 
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 0>
@@ -849,6 +856,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   // ------------------------------------------------------------------ epilogue
   const bool atomic = p.ksplit > 1;
+  const bool do_stats = p.stats != nullptr && p.epilogue == 0;      // host: only with ksplit == 1
+  int stat_n0 = 0;
+  if (do_stats) {                                                   // first valid sample of this wave's rows
+    const int nn = rows[wm0 + (lane & (TM * 32 - 1))].n;
+    int nf = nn >= 0 ? nn : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nf = min(nf, __shfl_xor(nf, o));
+    stat_n0 = nf;
+  }
+  float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
   const int nbw = __builtin_amdgcn_readfirstlane(nb0 + wn0);   // wave-uniform first column (SGPR: uniform scatter path)
   // NOTE: keep this free of lambdas that capture `p` and of runtime indices into p's arrays — either makes the
   // compiler keep a scratch-memory copy of the whole kernel argument (and of acc[][] if these loops stay rolled).
@@ -869,6 +886,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           if (p.out_act == PG_OUT_TANH) g = tanhf(g);
           float* o = p.out + ((long)ri.n * p.oN + (long)ri.oy * p.oH + (long)ri.ox * p.oW) + (long)ng * p.oC;
           if (atomic) atomicAdd(o, g); else *o = g;
+          // fused per-sample statistics of the following norm layer: tiles are sample-major, so a tile holds a short
+          // run of consecutive samples; this lane's values go to the accumulator of their offset from the first one
+          if (do_stats) {
+            const int dn = ri.n - stat_n0;
+            if (dn == 0) { st_s[0] += g; st_q[0] = fmaf(g, g, st_q[0]); }
+            else if (dn == 1) { st_s[1] += g; st_q[1] = fmaf(g, g, st_q[1]); }
+            else stat_spill(p.stats, ri.n, g);
+          }
         }
       } else if constexpr (BMODE != B_SCALAR) {   // host guarantees dst_uniform for the vector weight loaders
         // Data-gradient scatter, every destination's channel count a multiple of 32: the 32-column group of this
@@ -957,6 +982,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       }
     }
   }
+  if (do_stats) {
+    // block-level reduction (the operand stages in LDS are free now), then ONE pair of double atomics per sample
+    // slot and workgroup, spread over PG_STAT_SLOTS addresses per sample
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem);           // [wave][2 samples][sum, sumsq]
+    int* redn = reinterpret_cast<int*>(smem + 64);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double ds = wave_sum_d((double)st_s[k]), dq = wave_sum_d((double)st_q[k]);
+      if (lane == 0) { red[(wave * 2 + k) * 2] = ds; red[(wave * 2 + k) * 2 + 1] = dq; }
+    }
+    if (lane == 0) redn[wave] = stat_n0;
+    __syncthreads();
+    if (tid < 8) {                                            // (wave, k) pairs: merge equal samples, then add
+      const int w = tid >> 1, k = tid & 1;
+      const int n = redn[w] == 0x7fffffff ? -1 : redn[w] + k;
+      double ds = red[tid * 2], dq = red[tid * 2 + 1];
+      bool first = true;
+      for (int o = 0; o < tid; ++o) {
+        const int no = redn[o >> 1] == 0x7fffffff ? -1 : redn[o >> 1] + (o & 1);
+        if (no == n) first = false;
+      }
+      if (first && n >= 0) {
+        for (int o = tid + 1; o < 8; ++o) {
+          const int no = redn[o >> 1] == 0x7fffffff ? -1 : redn[o >> 1] + (o & 1);
+          if (no == n) { ds += red[o * 2]; dq += red[o * 2 + 1]; }
+        }
+        if (ds != 0.0 || dq != 0.0) {
+          const int slot = (blockIdx.x + blockIdx.y * 5 + blockIdx.z * 3) % PG_STAT_SLOTS;
+          atomicAdd(&p.stats[((long)n * PG_STAT_SLOTS + slot) * 2], ds);
+          atomicAdd(&p.stats[((long)n * PG_STAT_SLOTS + slot) * 2 + 1], dq);
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------- host side
@@ -985,6 +1045,8 @@ static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, dim3 grid
 }  // namespace pg
 
 using namespace pg;
+
+extern "C" int pg_norm_stats(const float* y, int32_t N, int64_t L, double* sums, void* stream);
 
 extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -1112,6 +1174,13 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   }
   if (ks < 1) ks = 1;
   k.ksplit = ks;
+  k.stats = nullptr;
+  if (d->stats != nullptr) {
+    PG_REQUIRE(d->epilogue == 0 && d->out_act == PG_OUT_NONE && d->oC == 1 && d->oW == (long)k.n_cnt &&
+               d->oH == (long)d->Wo * k.n_cnt && d->oN == (long)d->Ho * d->Wo * k.n_cnt,
+               "pg_conv: fused statistics need a dense NHWC output without output activation");
+    if (ks == 1) k.stats = d->stats;
+  }
   if (ks > 1) {   // atomic accumulation needs zero-initialised destinations
     if (d->epilogue == 0) {
       PG_REQUIRE(d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
@@ -1132,6 +1201,8 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
     default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
+  if (d->stats != nullptr && k.stats == nullptr)      // split-K (or scatter) launch: statistics from the stored tensor
+    return pg_norm_stats(d->out, d->N, (int64_t)d->Ho * d->Wo * k.n_cnt, d->stats, stream);
   last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16);
   return 0;
 }

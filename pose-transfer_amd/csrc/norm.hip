@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* y, long L,
   if (lane == 0) { red[w] = ds; red[4 + w] = dq; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[2 * n], red[0] + red[1] + red[2] + red[3]);
-    atomicAdd(&sums[2 * n + 1], red[4] + red[5] + red[6] + red[7]);
+    double* slot = sums + ((long)n * PG_STAT_SLOTS + (blockIdx.x % PG_STAT_SLOTS)) * 2;
+    atomicAdd(&slot[0], red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(&slot[1], red[4] + red[5] + red[6] + red[7]);
   }
 }
 
@@ -37,8 +38,13 @@ __global__ void norm_finalize_kernel(const double* sums, const float* gamma, con
                                      float eps, float* mr, float* aff) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const double mean = sums[2 * n] / (double)L;
-  double var = sums[2 * n + 1] / (double)L - mean * mean;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < PG_STAT_SLOTS; ++k) {     // partial sums are spread over slots to keep atomics off one address
+    s1 += sums[((long)n * PG_STAT_SLOTS + k) * 2];
+    s2 += sums[((long)n * PG_STAT_SLOTS + k) * 2 + 1];
+  }
+  const double mean = s1 / (double)L;
+  double var = s2 / (double)L - mean * mean;
   if (var < 0.0) var = 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
   const double g = (double)gamma[0], b = (double)beta[0];

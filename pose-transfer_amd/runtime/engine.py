@@ -190,7 +190,7 @@ PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2}[os.environ.get("PG_PRECISION", "f
 
 
 def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, transposed=False, scalar_in=False,
-          out=None, out_strides=None, bias=None, out_act=L.OUT_NONE, dsts=None, n_off=0, n_cnt=0, ksplit=0):
+          out=None, out_strides=None, bias=None, out_act=L.OUT_NONE, dsts=None, n_off=0, n_cnt=0, ksplit=0, stats=None):
     d = L.ConvDesc()
     for i, s in enumerate(srcs):
         d.src[i] = s
@@ -216,6 +216,7 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
         d.ndst = len(dsts)
     d.ksplit = ksplit
     d.precision = PRECISION
+    d.stats = L.ptr(stats)
     if PROFILER is not None:
         sp = (Ho * Wo) if mode == 0 else (Hi * Wi)
         ncnt_ = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
@@ -271,7 +272,7 @@ class NormScratch:
     them with a single memset instead of one tiny fill launch per norm layer."""
 
     def __init__(self, count, N, device):
-        self.sums = torch.zeros(count, N, 2, dtype=torch.float64, device=device)
+        self.sums = torch.zeros(count, N, L.STAT_SLOTS, 2, dtype=torch.float64, device=device)
         self.bsums = torch.zeros(count, N, 2, dtype=torch.float64, device=device)
         self.used = 0
 
@@ -289,16 +290,23 @@ class NormState:
             self.sums, self.bsums = scratch.take()
             self.shared = True
         else:
-            self.sums = torch.zeros(N, 2, dtype=torch.float64, device=device)
+            self.sums = torch.zeros(N, L.STAT_SLOTS, 2, dtype=torch.float64, device=device)
             self.bsums = torch.zeros(N, 2, dtype=torch.float64, device=device)
             self.shared = False
         self.mr = torch.zeros(N, 2, dtype=torch.float32, device=device)
         self.aff = torch.zeros(N, 2, dtype=torch.float32, device=device)
 
-    def forward(self, y, N, Lr, gamma, beta):
+    def stats_target(self):
+        """The (zeroed) statistics buffer a producing pg_conv accumulates into (pg_conv_t.stats)."""
         if not self.shared:
             self.sums.zero_()
-        L.call("pg_norm_stats", L.ptr(y), N, Lr, L.ptr(self.sums), L.stream())
+        return self.sums
+
+    def forward(self, y, N, Lr, gamma, beta, have_stats=False):
+        if not have_stats:
+            if not self.shared:
+                self.sums.zero_()
+            L.call("pg_norm_stats", L.ptr(y), N, Lr, L.ptr(self.sums), L.stream())
         L.call("pg_norm_finalize", L.ptr(self.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(self.mr),
                L.ptr(self.aff), L.stream())
 
@@ -455,11 +463,14 @@ class GeneratorEngine:
             for l in range(1, self.nlev):
                 hi, wi = self.hw[l - 1]
                 ho, wo = self.hw[l]
+                has_norm = l < self.nlev - 1
                 _conv([self._enc_act(e, l - 1).src()], N, hi, wi, L.ACT_LEAKY, 0, 4, 2, 1, ho, wo,
-                      A.p("%s.net.%d.net.1.weight" % (e, l)), self.enc[l], self.enc[l - 1], out=self.e_raw[e][l])
-                if l < self.nlev - 1:
+                      A.p("%s.net.%d.net.1.weight" % (e, l)), self.enc[l], self.enc[l - 1], out=self.e_raw[e][l],
+                      stats=self.e_norm[e][l].stats_target() if has_norm else None)
+                if has_norm:
                     self.e_norm[e][l].forward(self.e_raw[e][l], N, ho * wo * self.enc[l],
-                                              A.p("%s.net.%d.net.2.weight" % (e, l)), A.p("%s.net.%d.net.2.bias" % (e, l)))
+                                              A.p("%s.net.%d.net.2.weight" % (e, l)), A.p("%s.net.%d.net.2.bias" % (e, l)),
+                                              have_stats=True)
         # ---- deformable skips (reference networks.py:279-288, utils/pose_transform.py:69-92)
         for l in range(self.nwarp):
             a = self._enc_act("encoder_app", l)
@@ -473,9 +484,10 @@ class GeneratorEngine:
             ho, wo = 2 * hi, 2 * wi
             cin = sum(a.C for _, _, a in srcs)
             _conv([a.src() for _, _, a in srcs], N, hi, wi, L.ACT_RELU, 1, 4, 2, 1, ho, wo,
-                  A.p("decoder.net.%d.net.1.weight" % i), self.dec[i], cin, out=self.d_raw[i])
+                  A.p("decoder.net.%d.net.1.weight" % i), self.dec[i], cin, out=self.d_raw[i],
+                  stats=self.d_norm[i].stats_target())
             self.d_norm[i].forward(self.d_raw[i], N, ho * wo * self.dec[i], A.p("decoder.net.%d.net.3.weight" % i),
-                                   A.p("decoder.net.%d.net.3.bias" % i))
+                                   A.p("decoder.net.%d.net.3.bias" % i), have_stats=True)
         i = self.ndec - 1
         srcs = self._dec_sources(i)
         cin = sum(a.C for _, _, a in srcs)
@@ -655,10 +667,11 @@ class DiscriminatorEngine:
         assert off == self.M
         for j in range(1, self.nblk):
             _conv([self._act(j - 1).src()], self.M, self.hs[j - 1], self.ws[j - 1], L.ACT_LEAKY, 0, 4, 2, 1, self.hs[j],
-                  self.ws[j], A.p("net.%d.net.1.weight" % j), self.chans[j], self.chans[j - 1], out=self.raw[j])
+                  self.ws[j], A.p("net.%d.net.1.weight" % j), self.chans[j], self.chans[j - 1], out=self.raw[j],
+                  stats=self.norm[j].stats_target() if j < self.nblk - 1 else None)
             if j < self.nblk - 1:
                 self.norm[j].forward(self.raw[j], self.M, self.hs[j] * self.ws[j] * self.chans[j],
-                                     A.p("net.%d.net.2.weight" % j), A.p("net.%d.net.2.bias" % j))
+                                     A.p("net.%d.net.2.weight" % j), A.p("net.%d.net.2.bias" % j), have_stats=True)
         return self.raw[-1].view(self.M, self.K)
 
     def backward(self, dlogits, need_wgrad=True, image_grad=None):

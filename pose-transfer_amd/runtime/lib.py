@@ -12,6 +12,7 @@ import torch
 from . import build as _build
 
 PG_MAX_SRC = 4
+STAT_SLOTS = 16          # include/posegan_hip.h PG_STAT_SLOTS
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 OUT_NONE, OUT_TANH = 0, 1
 
@@ -41,7 +42,8 @@ class ConvDesc(C.Structure):
                 ("out", C.c_void_p), ("bias", C.c_void_p),
                 ("oN", C.c_int64), ("oC", C.c_int64), ("oH", C.c_int64), ("oW", C.c_int64),
                 ("dst", Dst * PG_MAX_SRC),
-                ("ndst", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32)]
+                ("ndst", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32),
+                ("stats", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

@@ -120,7 +120,7 @@ class ConvCase:
         key = "decoder.net.0.net.1.weight" if self.kind == "convT" else "w"
         return E._pack(key, self.w).to(DEV)
 
-    def run_forward(self, ksplit=0):
+    def run_forward(self, ksplit=0, stats=None):
         acts = self.device_sources()
         wp = self.packed_weight()
         N = self.N
@@ -134,7 +134,7 @@ class ConvCase:
         mode = 0 if self.kind == "conv" else 1
         E._conv([a.src() for a in acts], N, self.H, self.W, self.act, mode, self.K, self.stride, self.pad, self.Ho,
                 self.Wo, wp, self.cout, self.cin, scalar_in=self.scalar, out=out, out_strides=ostr, bias=b,
-                out_act=L.OUT_TANH if self.tanh else L.OUT_NONE, ksplit=ksplit)
+                out_act=L.OUT_TANH if self.tanh else L.OUT_NONE, ksplit=ksplit, stats=stats)
         torch.cuda.synchronize()
         return out.cpu() if self.nchw_out else nchw(out.cpu())
 

@@ -180,6 +180,24 @@ def test_conv_data_gradient(case, ksplit, acc):
         assert rel(g, r) < 1e-5, case.name
 
 
+@pytest.mark.parametrize("name", ["down_k4", "down_k4_odd", "down_k4_big", "down_small_m", "up_3src", "up_2src"])
+@pytest.mark.parametrize("ksplit", [1, 3])
+def test_conv_fused_norm_statistics(name, ksplit):
+    """pg_conv_t.stats: per-sample (sum, sum of squares) of the stored output, fused into the epilogue (ksplit 1) or
+    taken from the stored tensor (split-K) — the input of the reference's InstanceNorm3d(1) (networks.py:159)."""
+    case = [c for c in conv_cases() if c.name == name][0]
+    out, _, _, _ = case.reference()
+    stats = torch.zeros(case.N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
+    got = case.run_forward(ksplit, stats=stats)
+    assert rel(got, out) < 1e-5
+    o64 = out.double().reshape(case.N, -1)
+    ref = torch.stack([o64.sum(1), (o64 * o64).sum(1)], 1)
+    st = stats.cpu().sum(1)
+    scale = o64.abs().sum(1)
+    assert float(((st[:, 0] - ref[:, 0]).abs() / scale).max()) < 1e-6
+    assert float(((st[:, 1] - ref[:, 1]).abs() / ref[:, 1]).max()) < 1e-6
+
+
 # Operand-precision modes of pg_conv (include/posegan_hip.h PG_PREC_*).  fp32 is the parity path (tolerance 1e-5
 # above); bf16x3 (hi+lo split, 3 bf16 MFMAs per product) must stay fp32-class: relative error of the whole tensor
 # <= 5e-5 (product error ~2^-16 per term, random signs); plain bf16 is a mixed-precision option: <= 1e-2.
