@@ -17,7 +17,7 @@
 #include <type_traits>
 
 // -DPG_ABLATE=n builds diagnostic variants of the K loop (tools/ablate.sh): 1 = no global loads, 2 = no LDS stores,
-// 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only), 128 = one workgroup per CU (LDS padding), 256 = all global loads hit one 4 KB block.  0 = the product kernel.
+// 4 = no MFMA (operands kept live), 8 = no per-tile barrier (WRONG results, timing only), 128 = one workgroup per CU (LDS padding), 256 = all global loads hit one 4 KB block, 512 = relu-only, mask-free loader.  0 = the product kernel.
 #ifndef PG_ABLATE
 #define PG_ABLATE 0
 #endif
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   };
   static_assert(BK == 32, "the K loop below is written for 4 k-groups per tile");
 
-  constexpr bool PIPE = !LP && AMODE == A_VEC && BMODE != B_SCALAR && (PG_ABLATE & 255) == 0;
+  constexpr bool PIPE = !LP && AMODE == A_VEC && BMODE != B_SCALAR && (PG_ABLATE & 127) == 0;
   if constexpr (PIPE) {
     // -------- software-pipelined fp32 K loop (vector loaders).
     // The loader work of a tile is cut into 4 chunks (thread rows i with i % 4 == c) and chunk c travels with one of
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           rmask[i] = ldg128(m_base, (unsigned)(tid & 31) * 16u);
         } else {
           ra[i] = ldg128(a_base, aoff[i]);
-          rmask[i] = ldg128(m_base, moff[i]);
+          if constexpr (!(PG_ABLATE & 512)) rmask[i] = ldg128(m_base, moff[i]);
         }
       }
 #pragma unroll
@@ -679,6 +679,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         const float mk[4] = {rmask[i].x, rmask[i].y, rmask[i].z, rmask[i].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          if constexpr ((PG_ABLATE & 512) != 0) { v[e] = fmaxf(fmaf(v[e], raa[i], rab[i]), 0.f); continue; }
           const float t = fmaf(v[e], raa[i], rab[i]) * mk[e];
           v[e] = fmaxf(t, slope * t);          // slope 1 / 0 / 0.2 = none / relu / leaky-relu, no branch
         }
@@ -1201,8 +1202,8 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
     default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
+  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16);
   if (d->stats != nullptr && k.stats == nullptr)      // split-K (or scatter) launch: statistics from the stored tensor
     return pg_norm_stats(d->out, d->N, (int64_t)d->Ho * d->Wo * k.n_cnt, d->stats, stream);
-  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16);
   return 0;
 }

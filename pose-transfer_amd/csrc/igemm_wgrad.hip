@@ -535,7 +535,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   }
 #undef PG_WG
   PG_LAUNCH_OK("pg_conv_wgrad");
-  last_info() = cfg | (xs << 4) | (ys << 8) | (ks << 16) | (1 << 30);
+  last_info() = (narrow ? 4 : cfg) | (xs << 4) | (ys << 8) | (ks << 16) | (1 << 30);
   return 0;
 }
 

@@ -25,7 +25,7 @@ class KernelProfiler:
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
     CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32"}
-    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128"}
+    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32"}
 
     def __init__(self):
         self.records = []
