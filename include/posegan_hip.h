@@ -167,6 +167,13 @@ int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t
 int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
                       int32_t N, int64_t L, float* dgamma, float* dbeta, void* stream);
 
+/* ---- key-point heat-maps (utils/pose_utils.py:79-86 cords_to_map; SURVEY.md §8f row 1: the step before the path).
+ * cords [N][P][2] = (y, x) as float, -1 = missing (zero map); out[n*oN + c*oC + y*oH + x*oW] =
+ * float32(exp(-((y-cy)^2 + (x-cx)^2) / (2 sigma^2))) evaluated in float64 like numpy does.  With the strides of a
+ * channel slice of the NCHW network input the maps are written in place (no HWC array, no transpose, no H2D copy). */
+int pg_cords_to_map(const float* cords, int32_t N, int32_t P, int32_t H, int32_t W, float sigma, float* out,
+                    int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream);
+
 /* ---- deformable skip connection (utils/pose_transform.py:16-92)
  * mask pyramid: cv2.resize(mask_HWT,(w,h)) INTER_LINEAR (pose_transform.py:84-87) on device.
  *   masks [N][T][H0][W0] (float32, or float64 when is_f64) -> out [N][h][w][T] float32.            */

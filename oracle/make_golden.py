@@ -145,11 +145,31 @@ def load_sd(module, params):
     module.load_state_dict({k: t(v) for k, v in params.items()})
 
 
+def heatmap_fixture(rpu):
+    """tests/golden/heatmaps.npz: the reference's cords_to_map (utils/pose_utils.py:79-86) on seeded key-points with
+    missing entries (-1), integer coordinates as load_pose_cords_from_strings produces them."""
+    fix = {}
+    for tag, (h, w), p in (("a", (32, 24), 18), ("b", (20, 28), 16)):
+        ky = np.floor(synth.uniform(31, "hm/%s/y" % tag, (2, p)) * h).astype(np.int64)
+        kx = np.floor(synth.uniform(31, "hm/%s/x" % tag, (2, p)) * w).astype(np.int64)
+        miss = synth.uniform(31, "hm/%s/m" % tag, (2, p)) < 0.2
+        ky[miss] = -1
+        kx[miss & (synth.uniform(31, "hm/%s/m2" % tag, (2, p)) < 0.5)] = -1
+        cords = np.stack([ky, kx], -1)                       # (2, p, 2) as (y, x)
+        fix[tag + "_cords"] = cords
+        fix[tag + "_maps"] = np.stack([rpu.cords_to_map(cords[n], (h, w)) for n in range(2)])    # (2, h, w, p)
+    np.savez_compressed(os.path.join(OUT, "heatmaps.npz"), **fix)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_shims(os.path.join(REF, "src_deformable"))
+    if "--only-heatmaps" in sys.argv:
+        from utils import pose_utils as rpu
+        heatmap_fixture(rpu)
+        return
     from models import networks as rnet
     from models import pose_gan as rgan
     from utils import pose_transform as rpt
@@ -216,6 +236,7 @@ def main():
     dx2 = t(synth.uniform(15, "disc/x2", (2, 42, 96, 80), -1, 1))
     ops["disc_out_96x80"] = disc(dx2).detach().numpy()
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **ops)
+    heatmap_fixture(rpu)
 
     # ------------------------------------------------------------------ whole generator, 6 levels, 64x64
     gen_fix = {}

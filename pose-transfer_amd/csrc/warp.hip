@@ -188,9 +188,38 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const 
   }
 }
 
+
+// Key-point coordinates -> Gaussian heat-maps (reference utils/pose_utils.py:79-86, the step right before the path:
+// SURVEY.md §8f row 1).  numpy evaluates exp(-((yy-y)^2 + (xx-x)^2) / (2 sigma^2)) in float64 and stores float32; so
+// does this kernel.  A key-point with either coordinate == -1 (MISSING_VALUE) gives a zero map.
+__global__ __launch_bounds__(256) void cords_to_map_kernel(const float* cords, int P, int H, int W, double inv2s2,
+                                                           float* out, long oN, long oC, long oH, long oW) {
+  const int n = blockIdx.z, c = blockIdx.y;
+  const float cy = cords[((long)n * P + c) * 2], cx = cords[((long)n * P + c) * 2 + 1];
+  const bool missing = cy == -1.f || cx == -1.f;
+  float* o = out + (long)n * oN + (long)c * oC;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+    const int y = i / W, x = i - y * W;
+    const double dy = (double)y - (double)cy, dx = (double)x - (double)cx;
+    o[(long)y * oH + (long)x * oW] = missing ? 0.f : (float)exp(-(dy * dy + dx * dx) * inv2s2);
+  }
+}
+
 }  // namespace pg
 
 using namespace pg;
+
+extern "C" int pg_cords_to_map(const float* cords, int32_t N, int32_t P, int32_t H, int32_t W, float sigma, float* out,
+                               int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream) {
+  PG_REQUIRE(cords && out && N > 0 && P > 0 && H > 0 && W > 0 && sigma > 0.f, "pg_cords_to_map: bad arguments");
+  int bx = (H * W + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(cords_to_map_kernel, dim3(bx, P, N), dim3(256), 0, (hipStream_t)stream, cords, P, H, W,
+                     1.0 / (2.0 * (double)sigma * (double)sigma), out, (long)oN, (long)oC, (long)oH, (long)oW);
+  PG_LAUNCH_OK("pg_cords_to_map");
+  return 0;
+}
+
 
 extern "C" int pg_mask_pyramid(const void* masks, int32_t is_f64, int32_t N, int32_t T, int32_t H0, int32_t W0,
                                int32_t h, int32_t w, float* out, void* stream) {

@@ -32,6 +32,25 @@ def cords_to_map(cords, img_size, sigma=6):
     return result
 
 
+def cords_to_map_device(cords, img_size, sigma=6, out=None):
+    """Batched cords_to_map on the GPU: cords (N, P, 2) of (y, x) key-points (-1 = missing) -> (N, P, H, W) float32
+    heat-maps, or written into `out` — any (N, P, H, W) strided view, e.g. the pose channel slice of the NCHW network
+    input (reference Dataset.py:87,168-173 builds an HWC array on the host, transposes and uploads it)."""
+    import torch
+    from ..runtime import lib as L
+    cords = torch.as_tensor(cords)
+    assert cords.dim() == 3 and cords.shape[-1] == 2
+    n, p = cords.shape[:2]
+    h, w = img_size
+    dev = out.device if out is not None else "cuda"
+    cd = cords.to(device=dev, dtype=torch.float32).contiguous()
+    if out is None:
+        out = torch.empty(n, p, h, w, dtype=torch.float32, device=dev)
+    assert out.shape == (n, p, h, w) and out.dtype == torch.float32 and out.is_cuda
+    L.call("pg_cords_to_map", L.ptr(cd), n, p, h, w, float(sigma), L.ptr(out), *out.stride(), L.stream())
+    return out
+
+
 def get_imgpose(input, use_input_pose, pose_dim):
     """Channel slices [img | src_pose | tgt_pose] (reference pose_utils.py:227-233).  Views only."""
     inp_img = input[:, :3]

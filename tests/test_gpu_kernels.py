@@ -80,6 +80,25 @@ def test_sample_norm_forward_backward():
     assert abs(dbet.item() - db.item()) < 1e-4 * max(1, abs(db.item()))
 
 
+def test_cords_to_map_vs_reference_golden():
+    """SURVEY.md §8f row 1 (first widening step): key-point heat-maps, pinned on the reference's own cords_to_map."""
+    from pose_transfer_amd.utils import pose_utils as PU
+    g = np.load(os.path.join(GOLDEN, "heatmaps.npz"))
+    for tag in ("a", "b"):
+        cords, ref = g[tag + "_cords"], g[tag + "_maps"]                 # (2, P, 2) int64, (2, H, W, P) float32
+        h, w = ref.shape[1:3]
+        got = PU.cords_to_map_device(cords, (h, w))
+        # float64 exp rounded to float32 on both sides: at most 1 ulp apart
+        assert np.allclose(got.cpu().numpy(), ref.transpose(0, 3, 1, 2), rtol=2e-7, atol=1e-30)
+        # in place into a channel slice of an NCHW input tensor, as the training driver uses it
+        p = cords.shape[1]
+        inp = torch.full((2, 3 + 2 * p, h, w), 7.0, device=DEV)
+        PU.cords_to_map_device(cords, (h, w), out=inp[:, 3:3 + p])
+        assert torch.equal(inp[:, 3:3 + p], got) and float(inp[:, :3].min()) == 7.0 and float(inp[:, 3 + p:].max()) == 7.0
+        # the host function kept for the reference's numpy callers agrees as well
+        assert np.array_equal(PU.cords_to_map(cords[0], (h, w)), ref[0])
+
+
 # ----------------------------------------------------------------------------------------- warp
 WARP_CASES = [("w256s4", (256, 256), 4, 8), ("w128x64s2", (128, 64), 2, 8), ("w224s8", (224, 224), 8, 8),
               ("w64s1", (64, 64), 1, 4), ("w96x80s2", (96, 80), 2, 4)]

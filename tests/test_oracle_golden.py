@@ -223,3 +223,15 @@ def test_aten_warp_matches_closed_form():
     a = R.warp_mask_max(feat, t(wr), t(mk), (128, 96))
     b = R.warp_mask_max(feat, t(wr), t(mk), (128, 96), aten=True)
     assert np.abs(a.numpy() - b.numpy()).max() < 3e-4
+
+
+def test_host_cords_to_map_vs_reference_golden():
+    """Host-side mirror of the reference's cords_to_map (kept for numpy callers) against the captured reference maps."""
+    import pta_bootstrap
+    pta_bootstrap.load()
+    from pose_transfer_amd.utils import pose_utils as PU
+    g = np.load(os.path.join(GOLDEN, "heatmaps.npz"))
+    for tag in ("a", "b"):
+        cords, ref = g[tag + "_cords"], g[tag + "_maps"]
+        for n in range(cords.shape[0]):
+            assert np.array_equal(PU.cords_to_map(cords[n], ref.shape[1:3]), ref[n])
