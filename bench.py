@@ -208,7 +208,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
