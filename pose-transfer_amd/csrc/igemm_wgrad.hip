@@ -555,12 +555,45 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dY, long ro
   const float t = block_sum_256(acc, red);
   if (threadIdx.x == 0) atomicAdd(db + c, t);
 }
+// channel-contiguous (NHWC) gradient with C % 4 == 0 and 256 % (C/4) == 0: every lane streams float4s of its channel
+// quad over the pixels (fully coalesced, each byte read once); the generic kernel above reads 4 useful bytes per
+// 64-byte sector and every channel block re-reads the same lines
+__global__ __launch_bounds__(256) void bias_grad_nhwc_kernel(const float* dY, long npix, int C, float* db) {
+  __shared__ float4 red[256];
+  const int cq = C >> 2;                       // float4 chunks per pixel
+  const int chunk = threadIdx.x % cq, prow = threadIdx.x / cq, ppb = 256 / cq;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long pix = (long)blockIdx.x * ppb + prow; pix < npix; pix += (long)gridDim.x * ppb) {
+    const float4 v = *reinterpret_cast<const float4*>(dY + pix * C + chunk * 4);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < cq) {
+    float4 t = red[threadIdx.x];
+    for (int r = 1; r < ppb; ++r) {
+      const float4 u = red[r * cq + threadIdx.x];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    atomicAdd(db + threadIdx.x * 4 + 0, t.x); atomicAdd(db + threadIdx.x * 4 + 1, t.y);
+    atomicAdd(db + threadIdx.x * 4 + 2, t.z); atomicAdd(db + threadIdx.x * 4 + 3, t.w);
+  }
+}
 }  // namespace pg
 
 extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,
                             int64_t s_inner, int64_t sC, float* db, void* stream) {
   PG_REQUIRE(C > 0 && rows_outer > 0 && rows_inner > 0, "pg_bias_grad: empty");
   const long rows = rows_outer * rows_inner;
+  const bool dense_rows = (rows_inner == 1 && s_outer == C) || (s_inner == C && s_outer == rows_inner * (long)C);
+  if (sC == 1 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && dense_rows && ((size_t)dY & 15) == 0) {                 // dense NHWC: the streaming kernel
+    const int ppb = 256 / (C / 4);
+    long blocks = (rows + (long)ppb * 32 - 1) / ((long)ppb * 32);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
+    PG_LAUNCH_OK("pg_bias_grad");
+    return 0;
+  }
   int slices = (int)((rows + 256 * 16 - 1) / (256 * 16));
   if (slices > 64) slices = 64;
   if (slices < 1) slices = 1;

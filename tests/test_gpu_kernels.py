@@ -288,6 +288,11 @@ def test_bias_grad():
     gd = g.to(DEV)
     L.call("pg_bias_grad", L.ptr(gd), 3 * 5 * 7, 1, 64, 64, 0, 1, L.ptr(db), L.stream())
     assert rel(db.cpu(), g.sum((0, 1, 2))) < 1e-5
+    g3 = t(synth.normal(8, "bg3", (2, 37, 41, 64)))            # large enough for several blocks of the NHWC kernel
+    db3 = torch.full((64,), 0.25, device=DEV)                  # accumulates onto existing values
+    g3d = g3.to(DEV)
+    L.call("pg_bias_grad", L.ptr(g3d), 2, 37 * 41, 64, 37 * 41 * 64, 64, 1, L.ptr(db3), L.stream())
+    assert rel(db3.cpu() - 0.25, g3.sum((0, 1, 2))) < 1e-5
     g2 = t(synth.normal(8, "bg2", (3, 3, 9, 11)))
     db2 = torch.zeros(3, device=DEV)
     g2d = g2.to(DEV)
