@@ -14,6 +14,7 @@
 //   Global->register prefetch of tile t+1 overlaps the 16 MFMA k-steps of tile t (64 cycles each per SIMD).
 // Split-K (atomic accumulate) fills the 256 CUs on the deep, small-M layers.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 // -DPG_ABLATE=n builds diagnostic variants of the K loop (tools/ablate.sh): 1 = no global loads, 2 = no LDS stores,
@@ -64,6 +65,7 @@ struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wc99-designator"
 __device__ __attribute__((aligned(16))) const float kOnes[2048] = {[0 ... 2047] = 1.0f};
+__device__ __attribute__((aligned(16))) const float kZeros[4096] = {};      // source of zero rows for the LDS-DMA loaders
 __device__ __attribute__((aligned(16))) const float kIdentAff[2] = {1.0f, 0.0f};
 #pragma clang diagnostic pop
 
@@ -99,7 +101,7 @@ __device__ __noinline__ void stat_spill(double* stats, int n, float g) {
   atomicAdd(&stats[(long)n * PG_STAT_SLOTS * 2 + 1], (double)g * (double)g);
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 0>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 0, int DMA = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   // LDS layouts: A is [m][k] (row = 32 k's + 4 pad floats): the K-contiguous global float4 lands with ONE ds_write_b128
@@ -558,6 +560,143 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   };
   static_assert(BK == 32, "the K loop below is written for 4 k-groups per tile");
 
+  if constexpr (DMA != 0) {
+    // -------- fp32 K loop with LDS-DMA loaders (global_load_lds_dwordx4: global -> LDS, no register round trip, no
+    // ds_write, no prologue math).  Usable when the A operand needs no prologue — the upstream gradient of a
+    // data-gradient launch (one source, no deferred affine, no mask, no activation) — and for the weights.
+    // A wave instruction moves 64 x 16 B = 1 KB into CONTIGUOUS LDS, so tiles are unpadded and bank conflicts are
+    // avoided by permuting which global chunk a lane moves: A [m][32 k] keeps chunk c of row r in slot c ^ ((r>>1)&7)
+    // (conflict-free ds_read_b128 fragments); B [k][BN] keeps row k's 32-float halves swapped when (k>>2)&1 (the two
+    // k's an MFMA lane pair reads sit 4 rows apart).  Zero rows (padding taps, N tail) are read from a zero page.
+    // Tile t+1 is DMA'd into the other stage while tile t is multiplied; vmcnt(0) + one barrier per tile publish it.
+    static_assert(AMODE == A_VEC && BMODE == B_NN && PREC == 0, "DMA loaders: data-gradient operands only");
+    if (kt0 >= kt1) return;
+    constexpr int A_SZD = BM * BK, B_SZD = BK * BN;              // floats, unpadded
+    float* const AsD = smem;
+    float* const BsD = smem + 2 * A_SZ;
+    const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
+    const char* const srcp = uniform_ptr(reinterpret_cast<const char*>(p.src[0].ptr));
+    const char* const wp = uniform_ptr(reinterpret_cast<const char*>(p.W));
+    const int srcC = p.src[0].C;
+    const int achunk = (tid & 7) ^ ((tid >> 4) & 7);             // swizzled 16-byte chunk of the row this lane moves
+    const char* pa[A_ROWS];
+    const char* pb[NN_PASS];
+    int ld_kt = kt0, ld_tap = kt0 / cpt, ld_ci = kt0 - (kt0 / cpt) * cpt;
+    auto rebuild = [&]() {                                       // (tap, channel tile) -> per-row global pointers
+      const int tp = taps_l[ld_tap];
+      const int dyv = (int)(signed char)(tp & 0xff), dxv = (int)(signed char)((tp >> 8) & 0xff);
+      const int cc = ld_ci * BK;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
+        const bool ok = (a_n[i] >= 0) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+        const long off = ((long)((a_n[i] * p.Hi + iy) * p.Wi + ix) * srcC + cc + achunk * 4) * 4;
+        pa[i] = ok ? srcp + off : zero_pg + (tid & 7) * 16;
+      }
+      const int base = (tp >> 16) * p.wCout;
+#pragma unroll
+      for (int i = 0; i < NN_PASS; ++i) {
+        const int kr = tid / NN_CPR + i * (256 / NN_CPR);
+        const int nchunk = (tid % NN_CPR) ^ (((kr >> 2) & 1) << 3);
+        const int n = nb0 + nchunk * 4;
+        const long off = ((long)(base + cc + kr) * p.wCin + p.n_off + n) * 4;
+        pb[i] = (n < p.n_cnt) ? wp + off : zero_pg + (tid & 31) * 16;
+      }
+    };
+    auto advance = [&]() {
+      if (ld_kt + 1 < kt1) {
+        ++ld_kt;
+        if (++ld_ci == cpt) { ld_ci = 0; ++ld_tap; rebuild(); }
+        else {
+#pragma unroll
+          for (int i = 0; i < A_ROWS; ++i) pa[i] += BK * 4;
+#pragma unroll
+          for (int i = 0; i < NN_PASS; ++i) pb[i] += (long)BK * p.wCin * 4;
+        }
+      }
+    };
+    auto issue_a = [&](int stage) {
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pa[i]), AsD + stage * A_SZD + (i * 4 + wave) * 256, 16, 0, 0);
+    };
+    auto issue_b = [&](int stage) {
+#pragma unroll
+      for (int i = 0; i < NN_PASS; ++i)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pb[i]), BsD + stage * B_SZD + (i * 4 + wave) * 256, 16, 0, 0);
+    };
+    // operand fetch addresses (per lane): A slot of chunk 2G+lhi in row wm0+l31 (+32 rows per i); B column position
+    const int swr = (l31 >> 1) & 7;
+    unsigned faD[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      faD[g] = (unsigned)(size_t)AsD + (unsigned)((wm0 + l31) * BK * 4) + (unsigned)((((2 * g + lhi) ^ swr)) * 16);
+    unsigned fbD[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      fbD[j] = (unsigned)(size_t)BsD + (unsigned)((lhi * 4) * BN + ((wn0 + j * 32 + l31) ^ (lhi << 5))) * 4u;
+    auto fetch_d = [&](int stage, auto gc, float (&fa)[TM][4], float (&fb)[TN][4]) {
+      constexpr int G = decltype(gc)::value;
+      const unsigned aa = faD[G] + (unsigned)(stage * A_SZD) * 4u;
+      f32x4 v;
+      lds_read128<0>(v, aa);
+      fa[0][0] = v[0]; fa[0][1] = v[1]; fa[0][2] = v[2]; fa[0][3] = v[3];
+      if constexpr (TM > 1) {
+        f32x4 w2;
+        lds_read128<32 * BK * 4>(w2, aa);
+        fa[TM - 1][0] = w2[0]; fa[TM - 1][1] = w2[1]; fa[TM - 1][2] = w2[2]; fa[TM - 1][3] = w2[3];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned bb = fbD[j] + (unsigned)(stage * B_SZD) * 4u;
+        lds_read32<((G * 8 + 0) * BN) * 4>(fb[j][0], bb);
+        lds_read32<((G * 8 + 1) * BN) * 4>(fb[j][1], bb);
+        lds_read32<((G * 8 + 2) * BN) * 4>(fb[j][2], bb);
+        lds_read32<((G * 8 + 3) * BN) * 4>(fb[j][3], bb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    float fa[2][TM][4] = {}, fb[2][TN][4] = {};
+    rebuild();
+    issue_a(0); issue_b(0);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_d(0, G0{}, fa[0], fb[0]);
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = kt + 1 < kt1;
+      // the next tile goes into the other stage (past the end: the last tile again, into a stage nobody reads)
+      issue_a(stage ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_d(stage, G1{}, fa[1], fb[1]);
+      PG_LDS_WAIT(NRD);
+      __builtin_amdgcn_s_setprio(1);
+      mfma_group(fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_b(stage ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_d(stage, G2{}, fa[0], fb[0]);
+      PG_LDS_WAIT(NRD);
+      mfma_group(fa[1], fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      advance();
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_d(stage, G3{}, fa[1], fb[1]);
+      PG_LDS_WAIT(NRD);
+      mfma_group(fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // DMA of the next tile landed; own LDS reads done
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) fetch_d(stage ^ 1, G0{}, fa[0], fb[0]);
+      mfma_group(fa[1], fb[1]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      stage ^= 1;
+    }
+  } else {
   constexpr bool PIPE = !LP && AMODE == A_VEC && BMODE != B_SCALAR && (PG_ABLATE & 127) == 0;
   if constexpr (PIPE) {
     // -------- software-pipelined fp32 K loop (vector loaders).
@@ -853,6 +992,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     stage ^= 1;
   }
   }   // fp32 K loop
+  }   // !DMA
   if (kt0 >= kt1) return;   // empty split: contributes nothing
 
   // ------------------------------------------------------------------ epilogue
@@ -1022,10 +1162,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
 // ------------------------------------------------------------------------------------------- host side
 template <int BM, int BN, int WGM, int WGN>
-static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, dim3 grid, hipStream_t st) {
+static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma, dim3 grid, hipStream_t st) {
 #define PG_LAUNCH(A, B) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B>), grid, dim3(256), 0, st, k)
 #define PG_LAUNCH_LP(A, B, P) \
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B, P>), grid, dim3(256), 0, st, k)
+  if constexpr (WGN == 2) {
+    if (dma && prec == PG_PREC_F32 && amode == A_VEC && bmode == B_NN) {     // LDS-DMA loaders (pure operands)
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NN, 0, 1>), grid, dim3(256), 0, st, k);
+      return;
+    }
+  }
   if constexpr (WGN == 2) {   // low-precision operand modes: the three big vector-loader tiles only
     if (prec != PG_PREC_F32 && amode == A_VEC && bmode != B_SCALAR) {
       if (prec == PG_PREC_BF16 && bmode == B_NT) PG_LAUNCH_LP(A_VEC, B_NT, 1);
@@ -1155,14 +1301,14 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   int ks = d->ksplit;
   if (ks <= 0) {
     // Split K so that (a) there are >= 2 workgroups per CU to overlap each other's barriers and (b) the grid is
-    // close to a multiple of the 256 CUs (MFMA throughput is per CU: 384 blocks on 256 CUs would idle 25 %).
+    // close to a multiple of the 512 workgroup slots (two per CU): 768 blocks would leave the second round half empty.
     const long blocks = (long)mt * nt * k.nphase;
     const int kmax = ktot_min / 8 > 0 ? ktot_min / 8 : 1;
     ks = 1;
     double best = -1.0;
     for (int c = 1; c <= 32 && c <= kmax; ++c) {
       const long b = blocks * c;
-      const double eff = (double)b / (double)(((b + 255) / 256) * 256);
+      const double eff = (double)b / (double)(((b + 511) / 512) * 512);     // 2 co-resident workgroups x 256 CUs
       const double score = (b >= 512 ? eff : eff * (double)b / 512.0) - 0.004 * c;
       if (score > best + 1e-9) { best = score; ks = c; }
     }
@@ -1194,15 +1340,18 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
           PG_HIP(hipMemsetAsync(d->dst[j].grad, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * d->dst[j].C, st));
     }
   }
+  // LDS-DMA loaders: the A operand must need no prologue (one source, no deferred affine / mask / activation)
+  const bool dma = amode == A_VEC && bmode == B_NN && d->nsrc == 1 && d->src[0].aff == nullptr && d->src[0].mask == nullptr &&
+                   d->act == PG_ACT_NONE && d->precision == PG_PREC_F32 && cfg != 3 && getenv("PG_NO_DMA") == nullptr;
   dim3 grid(mt, nt, k.nphase * ks);
   switch (cfg) {
-    case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, grid, st); break;
-    case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, grid, st); break;
-    case 2: launch_cfg<64, 64, 2, 2>(k, amode, bmode, d->precision, grid, st); break;
-    default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, grid, st); break;
+    case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
+    case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
+    case 2: launch_cfg<64, 64, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
+    default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, dma, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
-  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16);
+  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16) | (dma ? (1 << 12) : 0);
   if (d->stats != nullptr && k.stats == nullptr)      // split-K (or scatter) launch: statistics from the stored tensor
     return pg_norm_stats(d->out, d->N, (int64_t)d->Ho * d->Wo * k.n_cnt, d->stats, stream);
   return 0;

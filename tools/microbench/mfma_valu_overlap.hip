@@ -6,7 +6,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-enum { K_NONE, K_VALU, K_PKFMA, K_SALU, K_DSR32, K_DSR128, K_DSW128, K_GLD128 };
+enum { K_NONE, K_VALU, K_PKFMA, K_SALU, K_DSR32, K_DSR128, K_DSW128, K_GLD128, K_DMA128 };
 template <int KIND, int PER>   // PER extra instructions of KIND after every MFMA
 __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters, float s) {
   __shared__ __attribute__((aligned(16))) float lds[8192];
@@ -35,10 +35,12 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters,
         if (KIND == K_DSR128) asm volatile("ds_read_b128 %0, %1" : "=v"(q4[id & 3]) : "v"(la));
         if (KIND == K_DSW128) asm volatile("ds_write_b128 %0, %1" ::"v"(la), "v"(q4[id & 3]));
         if (KIND == K_GLD128) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q4[id & 3]) : "v"(gp));
+        if (KIND == K_DMA128)     // global -> LDS without a register round trip (1 KB per wave instruction)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(gp), lds + (threadIdx.x >> 6) * 1024 + (id & 3) * 256, 16, 0, 0);
       }
     }
     if (KIND == K_DSR32 || KIND == K_DSR128 || KIND == K_DSW128) asm volatile("s_waitcnt lgkmcnt(0)");
-    if (KIND == K_GLD128) asm volatile("s_waitcnt vmcnt(0)");
+    if (KIND == K_GLD128 || KIND == K_DMA128) asm volatile("s_waitcnt vmcnt(0)");
   }
   float r = sc; for (int i = 0; i < 4; ++i) for (int q = 0; q < 16; ++q) r += acc[i][q];
   for (int i = 0; i < 8; ++i) r += v[i];
@@ -74,6 +76,7 @@ int main() {
     run<K_DSR128, 1>(d, in, bi, "ds_read_b128 x1");
     run<K_DSW128, 1>(d, in, bi, "ds_write_b128 x1");
     run<K_GLD128, 1>(d, in, bi, "global_load_dwordx4 x1");
+    run<K_DMA128, 1>(d, in, bi, "global_load_lds_x4 x1");
   }
   return 0;
 }
