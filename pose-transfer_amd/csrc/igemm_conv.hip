@@ -1309,7 +1309,7 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
     for (int c = 1; c <= 32 && c <= kmax; ++c) {
       const long b = blocks * c;
       const double eff = (double)b / (double)(((b + 511) / 512) * 512);     // 2 co-resident workgroups x 256 CUs
-      const double score = (b >= 512 ? eff : eff * (double)b / 512.0) - 0.004 * c;
+      const double score = (b >= 512 ? eff - 0.004 * c : (double)b / 512.0 - 0.002 * c);    // fill fraction below one round
       if (score > best + 1e-9) { best = score; ks = c; }
     }
   }

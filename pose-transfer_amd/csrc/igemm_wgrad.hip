@@ -563,7 +563,17 @@ __global__ __launch_bounds__(256) void bias_grad_nhwc_kernel(const float* dY, lo
   const int cq = C >> 2;                       // float4 chunks per pixel
   const int chunk = threadIdx.x % cq, prow = threadIdx.x / cq, ppb = 256 / cq;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long pix = (long)blockIdx.x * ppb + prow; pix < npix; pix += (long)gridDim.x * ppb) {
+  const long step = (long)gridDim.x * ppb;
+  long pix = (long)blockIdx.x * ppb + prow;
+  for (; pix + 3 * step < npix; pix += 4 * step) {      // four independent loads in flight per lane
+    const float4 v0 = *reinterpret_cast<const float4*>(dY + pix * C + chunk * 4);
+    const float4 v1 = *reinterpret_cast<const float4*>(dY + (pix + step) * C + chunk * 4);
+    const float4 v2 = *reinterpret_cast<const float4*>(dY + (pix + 2 * step) * C + chunk * 4);
+    const float4 v3 = *reinterpret_cast<const float4*>(dY + (pix + 3 * step) * C + chunk * 4);
+    acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+    acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+  }
+  for (; pix < npix; pix += step) {
     const float4 v = *reinterpret_cast<const float4*>(dY + pix * C + chunk * 4);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
@@ -588,8 +598,8 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
   const bool dense_rows = (rows_inner == 1 && s_outer == C) || (s_inner == C && s_outer == rows_inner * (long)C);
   if (sC == 1 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && dense_rows && ((size_t)dY & 15) == 0) {                 // dense NHWC: the streaming kernel
     const int ppb = 256 / (C / 4);
-    long blocks = (rows + (long)ppb * 32 - 1) / ((long)ppb * 32);
-    if (blocks > 1024) blocks = 1024;
+    long blocks = (rows + (long)ppb * 16 - 1) / ((long)ppb * 16);
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
     PG_LAUNCH_OK("pg_bias_grad");
     return 0;
