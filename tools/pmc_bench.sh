@@ -19,7 +19,7 @@ for f in sorted(glob.glob("$OUT/*results.db")):
 TILES = {"128, 128": "128x128", "128, 64": "128x64", "64, 64": "64x64", "128, 32": "128x32", "32, 64": "32x64"}
 out = {"note": "rocprofv3 --pmc, per-launch averages over the default bench workload (256x256, batch 4, fp32); FETCH/WRITE in KB as reported", "kernels": {}}
 for name, d in res.items():
-    m = re.match(r"void pg::(conv|wgrad)_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    m = re.match(r"void pg::(conv|wgrad)_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (\d+))?(?:, (\d+))?>", name)
     if not m:
         continue
     if m.group(1) == "conv":
@@ -32,7 +32,8 @@ for name, d in res.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e and e["GRBM_GUI_ACTIVE"] > 0:
         # 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
         e["mfma_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (e["GRBM_GUI_ACTIVE"] / 8.0)
-    out["kernels"][key] = e
+    if key not in out["kernels"] or out["kernels"][key]["launches"] < e["launches"]:    # template variants of one family
+        out["kernels"][key] = e
 json.dump(out, open("$PWD/gpurun_out/pmc_bench.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * kv[1]["launches"])[:6]:
     print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
