@@ -1,0 +1,27 @@
+"""How much host (Python + ctypes) time does one training iteration cost?  CPU time vs wall time of 20 iterations.
+    gpurun -- python tools/host_overhead.py"""
+import os, sys, time
+from types import SimpleNamespace
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (re-uses the bench's model / batch construction)
+from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
+from pose_transfer_amd.utils import synth
+
+args = SimpleNamespace(size=256, batch=4, content_loss_layer="none", nn_loss_area_size=1, l1_penalty_weight=100.0)
+opt = bench.make_opt(args)
+model = DeformablePose_GAN(opt, device="cuda:0", init_seed=0)
+od = dict(vars(opt), lazy_losses=True)
+batches = [[torch.from_numpy(a).cuda() for a in synth.batch(1234, "bench/%s" % s, 4, 18, 256, 256)] for s in "ABC"]
+for _ in range(3):
+    bench.iteration(model, batches, od)
+torch.cuda.synchronize()
+w0, c0 = time.perf_counter(), time.process_time()
+for _ in range(20):
+    bench.iteration(model, batches, od)
+w1, c1 = time.perf_counter(), time.process_time()      # enqueue finished (the GPU may still be working)
+torch.cuda.synchronize()
+w2 = time.perf_counter()
+print("per iteration: host CPU time %.2f ms, enqueue wall %.2f ms, end-to-end wall %.2f ms" %
+      ((c1 - c0) / 20 * 1e3, (w1 - w0) / 20 * 1e3, (w2 - w0) / 20 * 1e3))
