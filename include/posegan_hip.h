@@ -130,7 +130,9 @@ int pg_conv_wgrad(const pg_wgrad_t* desc, void* stream);
  * tap_gather:  out[n,co,y,x] = act(bias[co] + sum_{r,s} Y[n,y+r-pad,x+s-pad,(r*KW+s)*Co+co]) after a 1x1 pg_conv;
  * im2col_taps: G[n,y,x,(r*KW+s)*C+c] = dY[n,c,y-(r-pad),x-(s-pad)], zero padded to Cpad channels (wgrad operand);
  * small_cout_dgrad: dX[p][ci] = sum_{tap,co} dY[p-off(tap)][co]*W[tap][co][ci], split over dst[] like pg_conv's
- *              data-gradient epilogue (K = taps*Co is tiny: an HBM-bound streaming kernel).                     */
+ *              data-gradient epilogue (K = taps*Co is tiny: a streaming kernel).  The training engine computes the
+ *              same gradient as a K=32 pg_conv over the im2col_taps image (faster); this entry point stays for
+ *              callers that have no im2col image.                                                              */
 int pg_tap_gather(const float* Y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co,
                   const float* bias, int32_t out_act, float* out, int64_t oN, int64_t oC, int64_t oH, int64_t oW,
                   void* stream);
