@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--content_loss_layer", default="none")
     ap.add_argument("--nn_loss_area_size", type=int, default=1)
     ap.add_argument("--l1_penalty_weight", type=float, default=100.0)
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "bf16_data"],
                     help="MFMA operand format of the fwd/dgrad contractions (default f32 = the reference's arithmetic; "
                          "the other modes are extra, non-headline measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,7 +131,7 @@ def main():
     args = ap.parse_args()
     global P
     P = args.pose_dim
-    E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2}[args.precision]
+    E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[args.precision]
 
     world = dp.init_from_env()
     rank = dp.rank()

@@ -98,8 +98,19 @@ typedef struct {
 #define PG_PREC_F32 0
 #define PG_PREC_BF16 1
 #define PG_PREC_BF16X3 2
+#define PG_PREC_BF16_DATA 3   /* src[].ptr and W point to bf16 TENSORS (pg_materialise_bf16 / pg_weights_to_bf16): no
+                               prologue, w_transposed must be 0, every source C % 64 == 0; fp32 accumulate + outputs */
 
 int pg_conv(const pg_conv_t* desc, void* stream);
+
+/* bf16 data path helpers.  materialise: out[n,p,c] = bf16(act((aff[n].a * x + aff[n].b) * mask[n,c])) over an NHWC fp32
+ * tensor (aff / mask may be NULL) — the pre-activation input of the reference's Block (networks.py:142-172) written
+ * once, so that the contraction can DMA its tiles.  weights_to_bf16: packed fp32 [taps][Cout][Cin] -> bf16 in the same
+ * layout (`nt`, forward operand) and/or per-tap transposed [taps][Cin][Cout] (`t`, data-gradient operand). */
+int pg_materialise_bf16(const float* x, const float* aff, const float* mask, int32_t act, int32_t N, int64_t HW,
+                        int32_t C, void* out_bf16, void* stream);
+int pg_weights_to_bf16(const float* W, int32_t taps, int32_t Cout, int32_t Cin, void* nt_bf16, void* t_bf16,
+                       void* stream);
 
 /* Weight gradient of the same relation (torch autograd of conv2d / conv_transpose2d wrt weight):
  *   dW[r][s][co][ci] += sum_{n,qy,qx} dY_small/large[...,co] * X_large/small[...,ci]

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   // two LDS stages: tile t+1 is written while tile t is being multiplied -> ONE barrier per K tile, and a wave's
   // loader work is followed directly by its own MFMAs (the co-resident workgroup fills the MFMA pipe meanwhile)
-  constexpr bool LP = PREC != 0;                 // bf16 operand tiles in LDS
+  constexpr bool LP = (PREC == 1 || PREC == 2);  // bf16 operand tiles converted in the loaders (fp32 storage)
+  constexpr int BKE = (PREC == 3) ? 64 : BK;     // K elements per tile: PREC 3 moves 64 bf16 (128 bytes) per row
   constexpr int NPART = (PREC == 2) ? 2 : 1;     // hi (+ lo) parts
   constexpr int ASB = 40;                        // bf16 row stride: 32 k's + 8 pad = 80 bytes (conflict-free b128 reads)
   static_assert(!LP || (AMODE == A_VEC && BMODE != B_SCALAR), "low-precision modes exist for the vector loaders only");
@@ -184,11 +185,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   __syncthreads();
 
   // K range of this block
-  const int ktot = (AMODE == A_VEC) ? ntap * (p.Ctot / BK) : (ntap * p.Ctot + BK - 1) / BK;
+  const int ktot = (AMODE == A_VEC) ? ntap * (p.Ctot / BKE) : (ntap * p.Ctot + BK - 1) / BK;
   const int kper = (ktot + p.ksplit - 1) / p.ksplit;
   const int kt0 = split * kper;
   const int kt1 = min(ktot, kt0 + kper);
-  const int cpt = p.Ctot / BK;  // chunks per tap (vec mode)
+  const int cpt = p.Ctot / BKE;  // chunks per tap (vec mode)
 
   // ---- per-thread loader state
   int a_n[A_ROWS], a_iy[A_ROWS], a_ix[A_ROWS];
@@ -560,7 +561,125 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   };
   static_assert(BK == 32, "the K loop below is written for 4 k-groups per tile");
 
-  if constexpr (DMA != 0) {
+  if constexpr (PREC == 3) {
+    // -------- bf16 DATA path: both operands are bf16 tensors in HBM (activations already normalised / activated /
+    // masked by pg_materialise_bf16, weights converted by pg_weights_to_bf16), K-contiguous, and go global -> LDS by
+    // DMA exactly like the fp32 data-gradient loaders: rows of 64 bf16 = 128 bytes, 16-byte chunks XOR-swizzled,
+    // zero page for padding taps and the N tail, multi-source (virtual concat) A.  v_mfma_f32_32x32x16_bf16: a lane
+    // supplies 8 consecutive k's = ONE ds_read_b128 per operand and k-step, 4 k-steps per tile, fp32 accumulators
+    // and the same epilogues (raw fp32 output, fused statistics, data-gradient scatter) as the fp32 kernel.
+    static_assert(AMODE == A_VEC && BMODE == B_NT && DMA == 0, "bf16 data path: K-contiguous operands only");
+    if (kt0 >= kt1) return;
+    constexpr int A_SZ3 = BM * 32, B_SZ3 = BN * 32;              // floats (128-byte rows)
+    static_assert(A_SZ3 <= A_SZ && B_SZ3 <= B_SZ, "bf16 tiles must fit the fp32 staging area");
+    float* const As3 = smem;
+    float* const Bs3 = smem + 2 * A_SZ;
+    const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
+    const char* const wp = uniform_ptr(reinterpret_cast<const char*>(p.W));
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const char* pa[A_ROWS];
+    const char* pb[B_ROWS];
+    int ld_kt = kt0, ld_tap = kt0 / cpt, ld_ci = kt0 - (kt0 / cpt) * cpt;
+    auto rebuild = [&]() {
+      const int tp = taps_l[ld_tap];
+      const int dyv = (int)(signed char)(tp & 0xff), dxv = (int)(signed char)((tp >> 8) & 0xff);
+      const int cc = ld_ci * 64;
+      const char* sp = reinterpret_cast<const char*>(p.src[0].ptr);
+      int sC = p.src[0].C, cs = 0;
+#pragma unroll
+      for (int q = 1; q < PG_MAX_SRC; ++q)
+        if (q < p.nsrc && cc >= p.cstart[q]) { sp = reinterpret_cast<const char*>(p.src[q].ptr); sC = p.src[q].C; cs = p.cstart[q]; }
+      sp = uniform_ptr(sp);
+      const int cl = cc - cs + chunk * 8;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int iy = a_iy[i] + dyv, ix = a_ix[i] + dxv;
+        const bool ok = (a_n[i] >= 0) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+        const long off = ((long)((a_n[i] * p.Hi + iy) * p.Wi + ix) * sC + cl) * 2;
+        pa[i] = ok ? sp + off : zero_pg + (tid & 7) * 16;
+      }
+      const int base = (tp >> 16) * p.wCout;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int n = nb0 + (tid >> 3) + 32 * i;
+        const long off = ((long)(base + p.n_off + n) * p.wCin + cc + chunk * 8) * 2;
+        pb[i] = (n < p.n_cnt) ? wp + off : zero_pg + (tid & 7) * 16;
+      }
+    };
+    auto advance = [&]() {
+      if (ld_kt + 1 < kt1) {
+        ++ld_kt;
+        if (++ld_ci == cpt) { ld_ci = 0; ++ld_tap; rebuild(); }
+        else {
+          bool src_edge = false;
+#pragma unroll
+          for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && ld_ci * 64 == p.cstart[q]) src_edge = true;
+          if (src_edge) rebuild();
+          else {
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) pa[i] += 128;
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) pb[i] += 128;
+          }
+        }
+      }
+    };
+    auto issue = [&](int stage) {
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pa[i]), As3 + stage * A_SZ3 + (i * 4 + wave) * 256, 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pb[i]), Bs3 + stage * B_SZ3 + (i * 4 + wave) * 256, 16, 0, 0);
+    };
+    const int swr = (l31 >> 1) & 7;
+    unsigned fa3[4], fb3[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fa3[ks] = (unsigned)(size_t)As3 + (unsigned)((wm0 + l31) * 128) + (unsigned)(((2 * ks + lhi) ^ swr) * 16);
+      fb3[ks] = (unsigned)(size_t)Bs3 + (unsigned)((wn0 + l31) * 128) + (unsigned)(((2 * ks + lhi) ^ swr) * 16);
+    }
+    rebuild();
+    issue(0);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      issue(stage ^ 1);                     // next tile (past the end: the last one again, into a stage nobody reads)
+      advance();
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 va[4][TM], vb[4][TN];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const unsigned aa = fa3[ks] + (unsigned)(stage * A_SZ3) * 4u, bb = fb3[ks] + (unsigned)(stage * B_SZ3) * 4u;
+        lds_read128<0>(va[ks][0], aa);
+        if constexpr (TM > 1) lds_read128<32 * 128>(va[ks][TM - 1], aa);
+        lds_read128<0>(vb[ks][0], bb);
+        if constexpr (TN > 1) lds_read128<32 * 128>(vb[ks][TN - 1], bb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        // operands of k-step ks have landed when at most the reads of the later k-steps are outstanding
+        if (ks == 0) PG_LDS_WAIT(3 * (TM + TN)); else if (ks == 1) PG_LDS_WAIT(2 * (TM + TN));
+        else if (ks == 2) PG_LDS_WAIT(TM + TN); else PG_LDS_WAIT(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va[ks][i]),
+                                                                 __builtin_bit_cast(bf16x8, vb[ks][j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's DMA has landed
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      stage ^= 1;
+    }
+  } else if constexpr (DMA != 0) {
     // -------- fp32 K loop with LDS-DMA loaders (global_load_lds_dwordx4: global -> LDS, no register round trip, no
     // ds_write, no prologue math).  Usable when the A operand needs no prologue — the upstream gradient of a
     // data-gradient launch (one source, no deferred affine, no mask, no activation) — and for the weights.
@@ -1167,6 +1286,10 @@ static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma,
 #define PG_LAUNCH_LP(A, B, P) \
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B, P>), grid, dim3(256), 0, st, k)
   if constexpr (WGN == 2) {
+    if (prec == PG_PREC_BF16_DATA) {                                        // bf16 tensors, DMA loaders
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NT, 3>), grid, dim3(256), 0, st, k);
+      return;
+    }
     if (dma && prec == PG_PREC_F32 && amode == A_VEC && bmode == B_NN) {     // LDS-DMA loaders (pure operands)
       hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NN, 0, 1>), grid, dim3(256), 0, st, k);
       return;
@@ -1201,7 +1324,9 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   PG_REQUIRE(d->nsrc >= 1 && d->nsrc <= PG_MAX_SRC, "pg_conv: nsrc=%d", d->nsrc);
   PG_REQUIRE(d->KH * d->KW <= MAXTAP && d->stride >= 1 && d->stride <= 2, "pg_conv: unsupported kernel %dx%d s%d",
              d->KH, d->KW, d->stride);
-  PG_REQUIRE(d->precision >= PG_PREC_F32 && d->precision <= PG_PREC_BF16X3, "pg_conv: precision=%d", d->precision);
+  PG_REQUIRE(d->precision >= PG_PREC_F32 && d->precision <= PG_PREC_BF16_DATA, "pg_conv: precision=%d", d->precision);
+  const bool bf16_data = d->precision == PG_PREC_BF16_DATA;
+  const int bke = bf16_data ? 64 : BK;            // K elements per tile
   ConvK k;
   memset(&k, 0, sizeof(k));
   k.nsrc = d->nsrc;
@@ -1276,7 +1401,14 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   int amode = d->scalar_in ? A_SCALAR : A_VEC;
   if (amode == A_VEC) {
     for (int j = 0; j < d->nsrc; ++j)
-      PG_REQUIRE(d->src[j].C % BK == 0, "pg_conv: vec mode needs C%%32==0 (src %d has %d)", j, d->src[j].C);
+      PG_REQUIRE(d->src[j].C % bke == 0, "pg_conv: vec mode needs C%%%d==0 (src %d has %d)", bke, j, d->src[j].C);
+  }
+  if (bf16_data) {      // operands are bf16 tensors: pre-materialised activations, K-contiguous bf16 weights
+    PG_REQUIRE(amode == A_VEC && !d->w_transposed && d->act == PG_ACT_NONE, "pg_conv: bf16 data path needs vector, "
+               "K-contiguous, already-activated operands");
+    for (int j = 0; j < d->nsrc; ++j)
+      PG_REQUIRE(d->src[j].aff == nullptr && d->src[j].mask == nullptr, "pg_conv: bf16 data path: source %d carries a "
+                 "deferred affine / mask (materialise it first)", j);
   }
   int bmode;
   const bool nvec_ok = (k.n_cnt % 4 == 0) && (k.n_off % 4 == 0);
@@ -1295,7 +1427,7 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   // ---- split-K
   int ktot_min = 1 << 30;
   for (int ph = 0; ph < k.nphase; ++ph) {
-    const int kt = (amode == A_VEC) ? k.ntap[ph] * (ctot / BK) : cdiv((long)k.ntap[ph] * ctot, BK);
+    const int kt = (amode == A_VEC) ? k.ntap[ph] * (ctot / bke) : cdiv((long)k.ntap[ph] * ctot, BK);
     if (kt < ktot_min) ktot_min = kt;
   }
   int ks = d->ksplit;

@@ -137,3 +137,82 @@ extern "C" int pg_apply_affine_act(const float* x, const float* aff, const float
   PG_LAUNCH_OK("pg_apply_affine_act");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 data path helpers (include/posegan_hip.h)
+namespace pg {
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__global__ __launch_bounds__(256) void materialise_bf16_kernel(const float* x, const float* aff, const float* mask, int act,
+                                                               long HW, int C, uint4* out) {
+  const int n = blockIdx.y;
+  const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
+  const float slope = act_slope(act);
+  const long per = HW * C / 8;                       // 8 elements (one 16-byte bf16 chunk) per thread-iteration
+  const float* xb = x + (long)n * HW * C;
+  uint4* ob = out + (long)n * per;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+    const float4 v0 = reinterpret_cast<const float4*>(xb)[2 * i], v1 = reinterpret_cast<const float4*>(xb)[2 * i + 1];
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const int c = (int)((i * 8) % C);
+    float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (mask) {
+      const float4 m0 = *reinterpret_cast<const float4*>(mask + (long)n * C + c);
+      const float4 m1 = *reinterpret_cast<const float4*>(mask + (long)n * C + c + 4);
+      m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = fmaf(v[e], a, b) * m[e];
+      v[e] = fmaxf(t, slope * t);
+    }
+    ob[i] = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+  }
+}
+__global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float* W, int Cout, int Cin, unsigned short* nt,
+                                                              unsigned short* t) {
+  __shared__ float tile[32][33];
+  const long base = (long)blockIdx.z * Cout * Cin;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    const float v = (co < Cout && ci < Cin) ? W[base + (long)co * Cin + ci] : 0.f;
+    tile[r][tx] = v;
+    if (nt && co < Cout && ci < Cin) nt[base + (long)co * Cin + ci] = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu);
+  }
+  __syncthreads();
+  if (t) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      if (ci < Cin && co < Cout) t[base + (long)ci * Cout + co] = (unsigned short)(pack2_bf16(tile[tx][r], 0.f) & 0xffffu);
+    }
+  }
+}
+}  // namespace pg
+
+extern "C" int pg_materialise_bf16(const float* x, const float* aff, const float* mask, int32_t act, int32_t N, int64_t HW,
+                                   int32_t C, void* out_bf16, void* stream) {
+  PG_REQUIRE(x && out_bf16 && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "pg_materialise_bf16: bad arguments (C %% 8 == 0)");
+  long blocks = (HW * C / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pg::materialise_bf16_kernel, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
+                     (long)HW, C, reinterpret_cast<uint4*>(out_bf16));
+  PG_LAUNCH_OK("pg_materialise_bf16");
+  return 0;
+}
+
+extern "C" int pg_weights_to_bf16(const float* W, int32_t taps, int32_t Cout, int32_t Cin, void* nt_bf16, void* t_bf16,
+                                  void* stream) {
+  PG_REQUIRE(W && (nt_bf16 || t_bf16) && taps > 0 && Cout > 0 && Cin > 0, "pg_weights_to_bf16: bad arguments");
+  hipLaunchKernelGGL(pg::weights_to_bf16_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, taps), dim3(256), 0,
+                     (hipStream_t)stream, W, Cout, Cin, reinterpret_cast<unsigned short*>(nt_bf16),
+                     reinterpret_cast<unsigned short*>(t_bf16));
+  PG_LAUNCH_OK("pg_weights_to_bf16");
+  return 0;
+}

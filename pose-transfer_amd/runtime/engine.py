@@ -131,6 +131,7 @@ class ParamArena:
         return self.grads[self.off[key]:self.off[key] + self.numel[key]].view(self.pshape[key])
 
     def load_state_dict(self, sd):
+        WEIGHT_VERSION[0] += 1
         for k in self.keys:
             w = sd[k]
             if not torch.is_tensor(w):
@@ -156,6 +157,7 @@ class ParamArena:
     def adam_step(self, lr, b1=0.5, b2=0.999, eps=1e-8, grad_scale=1.0):
         """torch.optim.Adam semantics (reference models/pose_gan.py:50-51); bias corrections in double."""
         self.step += 1
+        WEIGHT_VERSION[0] += 1
         bc1 = 1.0 - b1 ** self.step
         bc2 = 1.0 - b2 ** self.step
         L.call("pg_adam", L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.total,
@@ -186,11 +188,60 @@ class Act:
 
 # MFMA operand precision of the forward / data-gradient contractions: 0 = fp32 (reference parity, default),
 # 1 = bf16 operands, 2 = bf16x3 split (include/posegan_hip.h PG_PREC_*).  Weight gradients always run in fp32.
-PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2}[os.environ.get("PG_PRECISION", "f32")]
+# 3 = bf16 DATA path: sources are materialised once as bf16 tensors (normalised, activated, masked), weights are
+# converted per optimiser step, and the contraction DMAs bf16 tiles straight into LDS (fp32 accumulate / outputs).
+PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[os.environ.get("PG_PRECISION", "f32")]
+
+WEIGHT_VERSION = [0]        # bumped whenever parameters change (optimiser step, load_state_dict): bf16 copies go stale
+_BF_SRC = {}                # device -> list of bf16 scratch buffers, one per source slot (stream-ordered reuse)
+_BF_W = {}                  # (data_ptr, numel) -> [version, nt, t]
+
+
+def _bf16_weight(W, taps, Cout, Cin, transposed):
+    key = (W.data_ptr(), W.numel())
+    ent = _BF_W.get(key)
+    if ent is None or ent[0] != WEIGHT_VERSION[0]:
+        ent = _BF_W[key] = [WEIGHT_VERSION[0], None, None]
+    idx = 2 if transposed else 1
+    if ent[idx] is None:
+        buf = torch.empty(W.numel(), dtype=torch.bfloat16, device=W.device)
+        L.call("pg_weights_to_bf16", L.ptr(W), taps, Cout, Cin, None if transposed else L.ptr(buf),
+               L.ptr(buf) if transposed else None, L.stream())
+        ent[idx] = buf
+    return ent[idx]
+
+
+def _bf16_sources(srcs, N, Hi, Wi, act, dev):
+    """Materialise every source as a bf16 NHWC tensor: bf16(act((a*x+b)*mask)); returns pure Src descriptors."""
+    pool = _BF_SRC.setdefault(dev, [None] * L.PG_MAX_SRC)
+    out = []
+    for j, s in enumerate(srcs):
+        need = N * Hi * Wi * s.C
+        if pool[j] is None or pool[j].numel() < need:
+            pool[j] = torch.empty(need, dtype=torch.bfloat16, device=dev)
+        L.call("pg_materialise_bf16", s.ptr, s.aff, s.mask, act, N, Hi * Wi, s.C, L.ptr(pool[j]), L.stream())
+        q = L.Src()
+        q.ptr, q.C = L.ptr(pool[j]), s.C
+        out.append(q)
+    return out
+
 
 
 def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, transposed=False, scalar_in=False,
           out=None, out_strides=None, bias=None, out_act=L.OUT_NONE, dsts=None, n_off=0, n_cnt=0, ksplit=0, stats=None):
+    prec = PRECISION
+    if prec == 3:
+        ncols = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
+        ok = (not scalar_in and n_off == 0 and n_cnt == 0 and ncols > 32 and all(s.C % 64 == 0 for s in srcs)
+              and isinstance(W, torch.Tensor))
+        if ok:      # bf16 tensors in, K-contiguous bf16 weights (per-tap transposed copy for the data-gradient)
+            srcs = _bf16_sources(srcs, N, Hi, Wi, act, W.device)
+            W = _bf16_weight(W, K * K, wCout, wCin, transposed)
+            if transposed:
+                wCout, wCin, transposed = wCin, wCout, False
+            act = L.ACT_NONE
+        else:
+            prec = 0
     d = L.ConvDesc()
     for i, s in enumerate(srcs):
         d.src[i] = s
@@ -215,7 +266,7 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
             d.dst[i] = t
         d.ndst = len(dsts)
     d.ksplit = ksplit
-    d.precision = PRECISION
+    d.precision = prec
     d.stats = L.ptr(stats)
     if PROFILER is not None:
         sp = (Ho * Wo) if mode == 0 else (Hi * Wi)

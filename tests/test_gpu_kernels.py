@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from gpu_util import DEV, ConvCase, E, L, R, maxdiff, nchw, nhwc, synth, t
+    from gpu_util import DEV, ConvCase, E, L, R, act_fn, maxdiff, nchw, nhwc, synth, t
 from conftest import GOLDEN
 
 
@@ -240,6 +240,56 @@ def test_conv_low_precision_modes(name, prec, ksplit, monkeypatch):
     if prec == "bf16":   # the mode must actually round operands: bit-identical-to-fp32 results would mean a silent fallback
         monkeypatch.setattr(E, "PRECISION", 0)
         assert rel(case.run_forward(ksplit), got) > 1e-5
+
+
+@pytest.mark.parametrize("name", ["down_k4", "down_k4_odd", "down_k4_big", "down_small_m", "up_3src", "up_2src"])
+@pytest.mark.parametrize("ksplit", [1, 3])
+def test_conv_bf16_data_path(name, ksplit, monkeypatch):
+    """PG_PREC_BF16_DATA: sources materialised as bf16 tensors, bf16 weight copies, tiles DMA'd into LDS, bf16 MFMA with
+    fp32 accumulation.  The arithmetic is exact up to summation order once the operands are rounded, so the check is
+    TIGHT (1e-4 of the tensor max) against the fp32 contraction of the bf16-ROUNDED operands; the loose end-to-end
+    bf16 tolerance is only needed against the un-rounded reference (test_conv_low_precision_modes, 1e-2)."""
+    case = [c for c in conv_cases() if c.name == name][0]
+    monkeypatch.setattr(E, "PRECISION", 3)
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    xs = []
+    for j in range(len(case.srcs)):
+        z = case.raw[j]
+        if case.aff[j] is not None:
+            z = torch.addcmul(case.aff[j][:, 1].view(-1, 1, 1, 1), z, case.aff[j][:, 0].view(-1, 1, 1, 1))   # fma like the kernel
+        if case.mask[j] is not None:
+            z = z * case.mask[j].view(case.N, -1, 1, 1)
+        xs.append(bf(act_fn(z, case.act)))
+    x = torch.cat(xs, 1)
+    w = bf(case.w)
+    if case.kind == "conv":
+        ref = F.conv2d(x, w, None, stride=case.stride, padding=case.pad)
+    else:
+        ref = F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:-1, 1:-1]
+    got = case.run_forward(ksplit)
+    assert (L.load().pg_last_launch_info() & 0xF) in (0, 1, 2)
+    assert rel(got, ref) < 1e-4, (name, float(rel(got, ref)))
+    # data-gradient: dX = W^T * bf16(dY), scattered with act' / mask of the (fp32) forward values
+    gy = bf(case.gout)
+    zs = []
+    for j in range(len(case.srcs)):
+        z = case.raw[j]
+        if case.aff[j] is not None:
+            z = z * case.aff[j][:, 0].view(-1, 1, 1, 1) + case.aff[j][:, 1].view(-1, 1, 1, 1)
+        zs.append(z.detach().clone().requires_grad_(True))
+    parts = []
+    for j, z in enumerate(zs):
+        v = z if case.mask[j] is None else z * case.mask[j].view(case.N, -1, 1, 1)
+        parts.append(act_fn(v, case.act))
+    xin = torch.cat(parts, 1)
+    if case.kind == "conv":
+        y = F.conv2d(xin, w, None, stride=case.stride, padding=case.pad)
+    else:
+        y = F.conv_transpose2d(xin, w, None, stride=2)[:, :, 1:-1, 1:-1]
+    dref = torch.autograd.grad((y * gy).sum(), zs)
+    dgot = case.run_dgrad(ksplit, False)
+    for g, r in zip(dgot, dref):
+        assert rel(g, r) < 1e-4, (name, float(rel(g, r)))
 
 
 @pytest.mark.parametrize("name", ["final_k3", "disc_last"])
