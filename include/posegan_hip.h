@@ -111,6 +111,12 @@ int pg_materialise_bf16(const float* x, const float* aff, const float* mask, int
                         int32_t C, void* out_bf16, void* stream);
 int pg_weights_to_bf16(const float* W, int32_t taps, int32_t Cout, int32_t Cin, void* nt_bf16, void* t_bf16,
                        void* stream);
+/* Batched NT GEMM on the bf16 data path: out[t][m][n] = sum_k A[m][a_off[t]+k] * B[n][b_off[t]+k] (A [M][K], B [N][K]
+ * bf16, row pitch K, K % 64 == 0; offsets in elements, any parity / sign as long as the reads stay inside the buffers).
+ * With A = channel-major gradient, B = channel-major activated input (pg_channel_major_bf16) and one offset per filter
+ * tap this is the weight gradient of a Block convolution (autograd of networks.py:154-157 wrt weight). */
+int pg_gemm_taps_bf16(const void* A, const void* B, int32_t M, int32_t N, int32_t K, int32_t gtaps,
+                      const int64_t* a_off, const int64_t* b_off, float* out, void* stream);
 
 /* Weight gradient of the same relation (torch autograd of conv2d / conv_transpose2d wrt weight):
  *   dW[r][s][co][ci] += sum_{n,qy,qx} dY_small/large[...,co] * X_large/small[...,ci]

@@ -52,6 +52,10 @@ struct ConvK {
   int dstart[PG_MAX_SRC + 1];
   double* stats;            // epilogue 0, ksplit 1: per-sample (sum, sum of squares) of the stored values, or null
   int dst_uniform;          // every destination's C is a multiple of 32 (wave-uniform descriptor in the scatter)
+  // batched-tap GEMM (bf16 weight gradient): blockIdx.z / ksplit selects one of `gtaps` independent products that
+  // differ only in operand / output base offsets (a_off, w_off in BYTES; o_off in floats)
+  int gtaps;
+  long a_off[MAXTAP], w_off[MAXTAP], o_off[MAXTAP];
 };
 
 struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
@@ -142,8 +146,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int phase = blockIdx.z / p.ksplit;
-  const int split = blockIdx.z - phase * p.ksplit;
+  const int zphase = blockIdx.z / p.ksplit;
+  const int split = blockIdx.z - zphase * p.ksplit;
+  const int phase = p.gtaps ? 0 : zphase;                         // sub-pixel phase (tap-table row)
+  const long a_off_g = p.gtaps ? p.a_off[zphase] : 0, w_off_g = p.gtaps ? p.w_off[zphase] : 0;
+  float* const out_g = p.out + (p.gtaps ? p.o_off[zphase] : 0);
   const int m0 = blockIdx.x * BM;
   const int nb0 = blockIdx.y * BN;
   const int ntap = p.ntap[phase];
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     float* const As3 = smem;
     float* const Bs3 = smem + 2 * A_SZ;
     const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
-    const char* const wp = uniform_ptr(reinterpret_cast<const char*>(p.W));
+    const char* const wp = uniform_ptr(reinterpret_cast<const char*>(p.W) + w_off_g);
     const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
     const char* pa[A_ROWS];
     const char* pb[B_ROWS];
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q)
         if (q < p.nsrc && cc >= p.cstart[q]) { sp = reinterpret_cast<const char*>(p.src[q].ptr); sC = p.src[q].C; cs = p.cstart[q]; }
-      sp = uniform_ptr(sp);
+      sp = uniform_ptr(sp + a_off_g);
       const int cl = cc - cs + chunk * 8;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
@@ -1144,7 +1151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           if (ri.n < 0 || !nval) continue;
           float g = acc[i][j][r] + bv;
           if (p.out_act == PG_OUT_TANH) g = tanhf(g);
-          float* o = p.out + ((long)ri.n * p.oN + (long)ri.oy * p.oH + (long)ri.ox * p.oW) + (long)ng * p.oC;
+          float* o = out_g + ((long)ri.n * p.oN + (long)ri.oy * p.oH + (long)ri.ox * p.oW) + (long)ng * p.oC;
           if (atomic) atomicAdd(o, g); else *o = g;
           // fused per-sample statistics of the following norm layer: tiles are sample-major, so a tile holds a short
           // run of consecutive samples; this lane's values go to the accumulator of their offset from the first one
@@ -1318,7 +1325,11 @@ using namespace pg;
 
 extern "C" int pg_norm_stats(const float* y, int32_t N, int64_t L, double* sums, void* stream);
 
-extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
+namespace {
+struct TapBatch { int gtaps; const long* a_off; const long* w_off; const long* o_off; };
+}
+
+static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PG_REQUIRE(d != nullptr, "pg_conv: null descriptor");
   PG_REQUIRE(d->nsrc >= 1 && d->nsrc <= PG_MAX_SRC, "pg_conv: nsrc=%d", d->nsrc);
@@ -1434,7 +1445,7 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   if (ks <= 0) {
     // Split K so that (a) there are >= 2 workgroups per CU to overlap each other's barriers and (b) the grid is
     // close to a multiple of the 512 workgroup slots (two per CU): 768 blocks would leave the second round half empty.
-    const long blocks = (long)mt * nt * k.nphase;
+    const long blocks = (long)mt * nt * (tb ? tb->gtaps : k.nphase);
     const int kmax = ktot_min / 8 > 0 ? ktot_min / 8 : 1;
     ks = 1;
     double best = -1.0;
@@ -1465,7 +1476,7 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
       PG_REQUIRE(d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
                  d->oN == (long)d->Ho * d->Wo * k.n_cnt,
                  "pg_conv: split-K needs a dense NHWC output");
-      PG_HIP(hipMemsetAsync(d->out, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * k.n_cnt, st));
+      PG_HIP(hipMemsetAsync(d->out, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * k.n_cnt * (tb ? tb->gtaps : 1), st));
     } else {
       for (int j = 0; j < d->ndst; ++j)
         if (!d->dst[j].accumulate)
@@ -1475,7 +1486,13 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   // LDS-DMA loaders: the A operand must need no prologue (one source, no deferred affine / mask / activation)
   const bool dma = amode == A_VEC && bmode == B_NN && d->nsrc == 1 && d->src[0].aff == nullptr && d->src[0].mask == nullptr &&
                    d->act == PG_ACT_NONE && d->precision == PG_PREC_F32 && cfg != 3 && getenv("PG_NO_DMA") == nullptr;
-  dim3 grid(mt, nt, k.nphase * ks);
+  if (tb) {
+    PG_REQUIRE(tb->gtaps >= 1 && tb->gtaps <= MAXTAP && k.nphase == 1 && d->precision == PG_PREC_BF16_DATA && d->epilogue == 0,
+               "batched-tap GEMM: bf16 data path, one phase, plain epilogue");
+    k.gtaps = tb->gtaps;
+    for (int t = 0; t < tb->gtaps; ++t) { k.a_off[t] = tb->a_off[t]; k.w_off[t] = tb->w_off[t]; k.o_off[t] = tb->o_off[t]; }
+  }
+  dim3 grid(mt, nt, (tb ? tb->gtaps : k.nphase) * ks);
   switch (cfg) {
     case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
     case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
@@ -1487,4 +1504,31 @@ extern "C" int pg_conv(const pg_conv_t* d, void* stream) {
   if (d->stats != nullptr && k.stats == nullptr)      // split-K (or scatter) launch: statistics from the stored tensor
     return pg_norm_stats(d->out, d->N, (int64_t)d->Ho * d->Wo * k.n_cnt, d->stats, stream);
   return 0;
+}
+
+extern "C" int pg_conv(const pg_conv_t* d, void* stream) { return conv_impl(d, nullptr, stream); }
+
+// Batched NT GEMM on the bf16 data path: out[t][m][n] = sum_k A[m][a_off[t] + k] * B[n][b_off[t] + k], t < gtaps,
+// A [M][K] and B [N][K] row-major bf16 with row pitch K (K % 64 == 0), offsets in ELEMENTS (may be negative / odd:
+// the DMA loaders take 2-byte aligned sources).  The bf16 weight gradient is this product with A = the channel-major
+// gradient, B = the channel-major activated input (or its stride-2 phase planes) and one offset per filter tap.
+extern "C" int pg_gemm_taps_bf16(const void* A, const void* B, int32_t M, int32_t N, int32_t K, int32_t gtaps,
+                                 const int64_t* a_off, const int64_t* b_off, float* out, void* stream) {
+  PG_REQUIRE(A && B && out && M > 0 && N > 32 && K > 0 && K % 64 == 0 && gtaps >= 1 && gtaps <= MAXTAP && a_off && b_off,
+             "pg_gemm_taps_bf16: bad arguments (K %% 64 == 0, N > 32, gtaps <= 16)");
+  pg_conv_t d;
+  memset(&d, 0, sizeof(d));
+  d.nsrc = 1;
+  d.src[0].ptr = reinterpret_cast<const float*>(A);
+  d.src[0].C = K;
+  d.N = 1; d.Hi = 1; d.Wi = M; d.Ho = 1; d.Wo = M;
+  d.act = PG_ACT_NONE; d.mode = 0; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+  d.W = reinterpret_cast<const float*>(B); d.wCout = N; d.wCin = K;
+  d.epilogue = 0; d.out_act = PG_OUT_NONE; d.out = out;
+  d.oN = (int64_t)M * N; d.oC = 1; d.oH = (int64_t)M * N; d.oW = N;
+  d.precision = PG_PREC_BF16_DATA;
+  long ao[MAXTAP], wo[MAXTAP], oo[MAXTAP];
+  for (int t = 0; t < gtaps; ++t) { ao[t] = a_off[t] * 2; wo[t] = b_off[t] * 2; oo[t] = (long)t * M * N; }
+  TapBatch tb{gtaps, ao, wo, oo};
+  return conv_impl(&d, &tb, stream);
 }

@@ -292,6 +292,28 @@ def test_conv_bf16_data_path(name, ksplit, monkeypatch):
         assert rel(g, r) < 1e-4, (name, float(rel(g, r)))
 
 
+def test_gemm_taps_bf16():
+    """pg_gemm_taps_bf16: batched NT GEMM with per-tap element offsets (odd / negative: 2-byte aligned DMA sources)."""
+    M, N, K, T = 96, 160, 320, 5
+    slack = 64
+    a = (torch.randn(M * K + 2 * slack) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N * K + 2 * slack) * 0.5).to(torch.bfloat16)
+    ao = torch.tensor([0, 1, -3, 17, 8], dtype=torch.int64)
+    bo = torch.tensor([0, -1, 5, -17, 2], dtype=torch.int64)
+    ad, bd = a.to(DEV), b.to(DEV)
+    out = torch.full((T, M, N), float("nan"), device=DEV)
+    L.call("pg_gemm_taps_bf16", ad.data_ptr() + 2 * slack, bd.data_ptr() + 2 * slack, M, N, K, T, ao.data_ptr(),
+           bo.data_ptr(), L.ptr(out), L.stream())
+    torch.cuda.synchronize()
+    af, bf_ = a.float(), b.float()
+    idx = torch.arange(K)
+    for t in range(T):
+        A = torch.stack([af[slack + m * K + int(ao[t]) + idx] for m in range(M)])
+        B = torch.stack([bf_[slack + n * K + int(bo[t]) + idx] for n in range(N)])
+        ref = A @ B.t()
+        assert rel(out[t].cpu(), ref) < 1e-5, (t, float(rel(out[t].cpu(), ref)))
+
+
 @pytest.mark.parametrize("name", ["final_k3", "disc_last"])
 def test_small_cout_data_gradient(name):
     """gradient through a 3- / 1-channel output: dY is a strided small-C operand (scalar A / scalar B path)."""
