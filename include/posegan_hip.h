@@ -115,6 +115,12 @@ int pg_weights_to_bf16(const float* W, int32_t taps, int32_t Cout, int32_t Cin, 
  * bf16, row pitch K, K % 64 == 0; offsets in elements, any parity / sign as long as the reads stay inside the buffers).
  * With A = channel-major gradient, B = channel-major activated input (pg_channel_major_bf16) and one offset per filter
  * tap this is the weight gradient of a Block convolution (autograd of networks.py:154-157 wrt weight). */
+/* Channel-major, zero-bordered bf16 image of an NHWC fp32 tensor (sub = 1), or of one stride-2 phase plane (sub = 2,
+ * parity (py, px)): out[c][(n*(Hq+2) + yy)*Wp + xx] = bf16(act((a*x+b)*mask)) at source pixel (sub*(yy-1)+py,
+ * sub*(xx-1)+px), zero on the border / padding / tail; channel rows K elements apart (K % 64 == 0, Wp % 8 == 0). */
+int pg_channel_major_bf16(const float* x, const float* aff, const float* mask, int32_t act, int32_t N, int32_t H,
+                          int32_t W, int32_t C, int32_t sub, int32_t py, int32_t px, int32_t Hq, int32_t Wq,
+                          int32_t Wp, int64_t K, void* out_bf16, void* stream);
 int pg_gemm_taps_bf16(const void* A, const void* B, int32_t M, int32_t N, int32_t K, int32_t gtaps,
                       const int64_t* a_off, const int64_t* b_off, float* out, void* stream);
 

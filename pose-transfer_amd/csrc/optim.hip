@@ -216,3 +216,63 @@ extern "C" int pg_weights_to_bf16(const float* W, int32_t taps, int32_t Cout, in
   PG_LAUNCH_OK("pg_weights_to_bf16");
   return 0;
 }
+
+// Channel-major, zero-bordered bf16 image of an NHWC fp32 tensor (optionally one stride-2 phase plane of it):
+//   out[c][(n * (Hq + 2) + yy) * Wp + xx] = bf16(act((a*x + b) * mask)) at source pixel (sub*(yy-1)+py, sub*(xx-1)+px)
+// for 1 <= yy <= Hq, 1 <= xx <= Wq and that pixel inside (H, W); 0 on the border, in the Wp padding and in the row tail
+// up to K.  Rows (channels) are K elements apart.  With this layout the weight gradient of a k4/s2 Block convolution
+// is 16 NT GEMMs over the pixel axis whose taps differ only by a constant element offset (pg_gemm_taps_bf16).
+namespace pg {
+__global__ __launch_bounds__(256) void channel_major_bf16_kernel(const float* x, const float* aff, const float* mask, int act,
+                                                                 int N, int H, int W, int C, int sub, int py, int px, int Hq,
+                                                                 int Wq, int Wp, long K, unsigned short* out) {
+  __shared__ float tile[64][33];
+  const long q0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const float slope = act_slope(act);
+  {
+    const int c = threadIdx.x & 31;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ql = (threadIdx.x >> 5) + 8 * j;
+      const long q = q0 + ql;
+      float v = 0.f;
+      const long plane = (long)(Hq + 2) * Wp;
+      const long n = q / plane;
+      const long r = q - n * plane;
+      const int yy = (int)(r / Wp), xx = (int)(r - (long)yy * Wp);
+      const int sy = sub * (yy - 1) + py, sx = sub * (xx - 1) + px;
+      if (n < N && yy >= 1 && yy <= Hq && xx >= 1 && xx <= Wq && sy < H && sx < W && c0 + c < C) {
+        const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
+        const float m = mask ? mask[n * C + c0 + c] : 1.f;
+        const float t = fmaf(x[((n * H + sy) * W + sx) * C + c0 + c], a, b) * m;
+        v = fmaxf(t, slope * t);
+      }
+      tile[ql][c] = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int c = threadIdx.x >> 3, qc = threadIdx.x & 7;       // 32 channels x 8 chunks of 8 q's
+    if (c0 + c < C) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[qc * 8 + e][c];
+      const uint4 pk = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+      *reinterpret_cast<uint4*>(out + (long)(c0 + c) * K + q0 + qc * 8) = pk;
+    }
+  }
+}
+}  // namespace pg
+
+extern "C" int pg_channel_major_bf16(const float* x, const float* aff, const float* mask, int32_t act, int32_t N, int32_t H,
+                                     int32_t W, int32_t C, int32_t sub, int32_t py, int32_t px, int32_t Hq, int32_t Wq,
+                                     int32_t Wp, int64_t K, void* out_bf16, void* stream) {
+  PG_REQUIRE(x && out_bf16 && N > 0 && C > 0 && (sub == 1 || sub == 2) && Wp >= Wq + 2 && Wp % 8 == 0 && K % 64 == 0 &&
+             K >= (int64_t)N * (Hq + 2) * Wp && ((size_t)out_bf16 & 15) == 0,
+             "pg_channel_major_bf16: bad geometry (Wp %% 8 == 0, K %% 64 == 0, K >= N*(Hq+2)*Wp)");
+  hipLaunchKernelGGL(pg::channel_major_bf16_kernel, dim3((unsigned)(K / 64), (C + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                     x, aff, mask, act, N, H, W, C, sub, py, px, Hq, Wq, Wp, (long)K, reinterpret_cast<unsigned short*>(out_bf16));
+  PG_LAUNCH_OK("pg_channel_major_bf16");
+  return 0;
+}

@@ -295,8 +295,72 @@ def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
            out if isinstance(out, int) else L.ptr(out), L.stream())
 
 
+_BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
+WGRAD_BF16_MIN_FLOPS = 4e9     # below this the 16 tap products are launch-bound: the fp32 kernel is faster
+
+
+def _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
+    """Weight gradient of a k4/s2/p1 Block convolution (conv: x large, dY small; conv-transpose + crop: x small, dY
+    large) on the bf16 data path: both tensors are written once as channel-major, zero-bordered bf16 images on the
+    SMALL pixel grid (the large one as its four stride-2 phase planes), after which tap (r, s) of the gradient is an NT
+    GEMM over the pixel axis whose large-side operand is only shifted by dyq*Wp + dxq elements (pg_gemm_taps_bf16)."""
+    dev = dW.device
+    Wp = (Ws + 2 + 7) // 8 * 8
+    Kp = (N * (Hs + 2) * Wp + 63) // 64 * 64
+    slack = Wp + 64
+    Cs, Cl = (Cout, Cin) if x_is_large else (Cin, Cout)
+    need = (Cs * Kp + 2 * slack, 4 * Cl * Kp + 2 * slack, 16 * Cout * Cin)
+    pool = _BF_WG.setdefault(dev, [None, None, None])
+    for i, (n_el, dt) in enumerate(zip(need, (torch.bfloat16, torch.bfloat16, torch.float32))):
+        if pool[i] is None or pool[i].numel() < n_el:
+            pool[i] = torch.zeros(n_el, dtype=dt, device=dev)
+    small = pool[0].data_ptr() + 2 * slack
+    large = pool[1].data_ptr() + 2 * slack
+    dYp = dY if isinstance(dY, int) else L.ptr(dY)
+
+    def put(ptr_x, aff, mask, a, C, H, W, sub, py, px, out_ptr):
+        L.call("pg_channel_major_bf16", ptr_x, aff, mask, a, N, H, W, C, sub, py, px, Hs, Ws, Wp, Kp, out_ptr, L.stream())
+
+    c0 = 0
+    for s_ in srcs:                      # the (virtually concatenated) input, activated like the forward prologue
+        if x_is_large:
+            for ph in range(4):
+                put(s_.ptr, s_.aff, s_.mask, act, s_.C, Hl, Wl, 2, ph >> 1, ph & 1, large + 2 * ((ph * Cin + c0) * Kp))
+        else:
+            put(s_.ptr, s_.aff, s_.mask, act, s_.C, Hs, Ws, 1, 0, 0, small + 2 * (c0 * Kp))
+        c0 += s_.C
+    if x_is_large:
+        put(dYp, None, None, L.ACT_NONE, Cout, Hs, Ws, 1, 0, 0, small)
+    else:
+        for ph in range(4):
+            put(dYp, None, None, L.ACT_NONE, Cout, Hl, Wl, 2, ph >> 1, ph & 1, large + 2 * (ph * Cout * Kp))
+    offs = []
+    for r in range(4):
+        for q in range(4):
+            py, px = (r - 1) % 2, (q - 1) % 2
+            dyq, dxq = (r - 1 - py) // 2, (q - 1 - px) // 2
+            offs.append((py * 2 + px) * Cl * Kp + dyq * Wp + dxq)
+    zero = torch.zeros(16, dtype=torch.int64)
+    shift = torch.tensor(offs, dtype=torch.int64)
+    if x_is_large:      # A = gradient [Cout][Kp] (small grid), B = input planes
+        a_ptr, b_ptr, a_off, b_off = small, large, zero, shift
+    else:               # A = gradient planes, B = input [Cin][Kp]
+        a_ptr, b_ptr, a_off, b_off = large, small, shift, zero
+    prod = pool[2][:16 * Cout * Cin]
+    L.call("pg_gemm_taps_bf16", a_ptr, b_ptr, Cout, Cin, Kp, 16, a_off.data_ptr(), b_off.data_ptr(), L.ptr(prod), L.stream())
+    dW.view(-1).add_(prod)
+
+
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
            y_strides=None, ksplit=0, cout_store=0):
+    if (PRECISION == 3 and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None and cout_store == 0
+            and Cin > 32 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor)
+            and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS):
+        if PROFILER is not None:
+            PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout,
+                            lambda: _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW))
+            return
+        return _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW)
     d = L.WgradDesc()
     for i, s in enumerate(srcs):
         d.src[i] = s

@@ -292,6 +292,33 @@ def test_conv_bf16_data_path(name, ksplit, monkeypatch):
         assert rel(g, r) < 1e-4, (name, float(rel(g, r)))
 
 
+@pytest.mark.parametrize("name", ["down_k4", "down_k4_big", "down_small_m", "up_3src", "up_2src"])
+def test_weight_gradient_bf16_data_path(name, monkeypatch):
+    """bf16 weight gradient = channel-major zero-bordered bf16 images (pg_channel_major_bf16) + 16 shifted NT GEMMs
+    (pg_gemm_taps_bf16).  Checked tightly against torch autograd on the bf16-ROUNDED operands."""
+    case = [c for c in conv_cases() if c.name == name][0]
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setattr(E, "WGRAD_BF16_MIN_FLOPS", 0.0)
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    xs = []
+    for j in range(len(case.srcs)):
+        z = case.raw[j]
+        if case.aff[j] is not None:
+            z = torch.addcmul(case.aff[j][:, 1].view(-1, 1, 1, 1), z, case.aff[j][:, 0].view(-1, 1, 1, 1))
+        if case.mask[j] is not None:
+            z = z * case.mask[j].view(case.N, -1, 1, 1)
+        xs.append(bf(act_fn(z, case.act)))
+    x = torch.cat(xs, 1)
+    w = case.w.clone().requires_grad_(True)
+    if case.kind == "conv":
+        y = F.conv2d(x, w, None, stride=case.stride, padding=case.pad)
+    else:
+        y = F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:-1, 1:-1]
+    ref = torch.autograd.grad((y * bf(case.gout)).sum(), w)[0]
+    got = case.run_wgrad()
+    assert rel(got, ref) < 1e-4, (name, float(rel(got, ref)))
+
+
 def test_gemm_taps_bf16():
     """pg_gemm_taps_bf16: batched NT GEMM with per-tap element offsets (odd / negative: 2-byte aligned DMA sources)."""
     M, N, K, T = 96, 160, 320, 5
