@@ -130,8 +130,12 @@ class ParamArena:
     def g(self, key):
         return self.grads[self.off[key]:self.off[key] + self.numel[key]].view(self.pshape[key])
 
+    def _bump_version(self):
+        key = self.params.untyped_storage().data_ptr()
+        WEIGHT_VERSION[key] = WEIGHT_VERSION.get(key, 0) + 1
+
     def load_state_dict(self, sd):
-        WEIGHT_VERSION[0] += 1
+        self._bump_version()
         for k in self.keys:
             w = sd[k]
             if not torch.is_tensor(w):
@@ -157,7 +161,7 @@ class ParamArena:
     def adam_step(self, lr, b1=0.5, b2=0.999, eps=1e-8, grad_scale=1.0):
         """torch.optim.Adam semantics (reference models/pose_gan.py:50-51); bias corrections in double."""
         self.step += 1
-        WEIGHT_VERSION[0] += 1
+        self._bump_version()
         bc1 = 1.0 - b1 ** self.step
         bc2 = 1.0 - b2 ** self.step
         L.call("pg_adam", L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.total,
@@ -192,16 +196,18 @@ class Act:
 # converted per optimiser step, and the contraction DMAs bf16 tiles straight into LDS (fp32 accumulate / outputs).
 PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[os.environ.get("PG_PRECISION", "f32")]
 
-WEIGHT_VERSION = [0]        # bumped whenever parameters change (optimiser step, load_state_dict): bf16 copies go stale
+WEIGHT_VERSION = {}         # parameter-arena storage -> version, bumped whenever its parameters change (optimiser step,
+                            # load_state_dict): the bf16 weight copies of THAT arena go stale
 _BF_SRC = {}                # device -> list of bf16 scratch buffers, one per source slot (stream-ordered reuse)
 _BF_W = {}                  # (data_ptr, numel) -> [version, nt, t]
 
 
 def _bf16_weight(W, taps, Cout, Cin, transposed):
     key = (W.data_ptr(), W.numel())
+    ver = WEIGHT_VERSION.get(W.untyped_storage().data_ptr(), 0)
     ent = _BF_W.get(key)
-    if ent is None or ent[0] != WEIGHT_VERSION[0]:
-        ent = _BF_W[key] = [WEIGHT_VERSION[0], None, None]
+    if ent is None or ent[0] != ver:
+        ent = _BF_W[key] = [ver, None, None]
     idx = 2 if transposed else 1
     if ent[idx] is None:
         buf = torch.empty(W.numel(), dtype=torch.bfloat16, device=W.device)

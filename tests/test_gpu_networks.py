@@ -293,6 +293,37 @@ def test_baseline_step_vs_golden():
     assert maxdiff(og, t(fix["out_gen"])) < 1e-3
 
 
+def test_training_iteration_bf16_data_path_vs_fp32(monkeypatch):
+    """BASELINE.json configs[2]/[4] (bf16): one full dis_update + gen_update on the bf16 DATA path (bf16 activations /
+    weights / gradients as contraction operands, fp32 accumulation, fp32 master weights and Adam) against the fp32
+    path on the same inputs, weights and dropout masks.  Stated tolerance: losses within 3e-2 relative, out_gen
+    mean-abs <= 2.6e-2 / max-abs <= 0.3 (the reference's own bf16-autocast deviation), and the
+    generator gradient arena correlates > 0.99 with the fp32 one."""
+    H = W = 128
+    N = 2
+    b = dev(*[t(a) for a in synth.batch(78, "bfstep", N, P, H, W)])
+    b2 = dev(*[t(a) for a in synth.batch(79, "bfstep2", N, P, H, W)])
+    d = dev(*[t(m) for m in synth.dropout_masks(78, "bfstep", N)])
+    res = {}
+    for mode in (0, 3):
+        monkeypatch.setattr(E, "PRECISION", mode)
+        monkeypatch.setattr(E, "WGRAD_BF16_MIN_FLOPS", 0.0)
+        opt = _opt((H, W), N=N)
+        model = DeformablePose_GAN(opt, device=DEV, init_seed=5)
+        od = vars(opt)
+        dl = model.dis_update(b[0], b[1], {"warps": b[2], "masks": b[3], "drop_masks": d}, b2[0], b2[1], od)
+        og, _, gl = model.gen_update(b[0], b[1], {"warps": b[2], "masks": b[3], "drop_masks": d}, od)
+        res[mode] = (np.array(dl), np.array(gl), og.clone(), model.gen.arena.grads.clone())
+    for k in (0, 1):
+        assert np.all(np.isfinite(res[3][k]))
+        assert np.max(np.abs(res[3][k] - res[0][k]) / np.maximum(np.abs(res[0][k]), 1e-3)) < 3e-2, (res[0][k], res[3][k])
+    dd = (res[3][2] - res[0][2]).abs()
+    assert float(dd.mean()) < 2.6e-2 and float(dd.max()) < 0.3 and float(dd.max()) > 1e-6
+    g0, g3 = res[0][3].double(), res[3][3].double()
+    corr = float((g0 * g3).sum() / (g0.norm() * g3.norm()))
+    assert corr > 0.99, corr
+
+
 def test_full_size_properties_256():
     """BASELINE.json configs[1] shape (256x256, P=18, batch 4): too big for the CPU oracle inside a test, so check
     size-independent properties: finite losses, tanh range, repeatability of the forward, masked warp output >= 0,
