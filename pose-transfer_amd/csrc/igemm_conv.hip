@@ -634,10 +634,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     auto issue = [&](int stage) {
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i)
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pa[i]), As3 + stage * A_SZ3 + (i * 4 + wave) * 256, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>((PG_ABLATE & 256) ? wp + tid * 16 : pa[i]), As3 + stage * A_SZ3 + (i * 4 + wave) * 256, 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i)
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pb[i]), Bs3 + stage * B_SZ3 + (i * 4 + wave) * 256, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>((PG_ABLATE & 256) ? wp + tid * 16 : pb[i]), Bs3 + stage * B_SZ3 + (i * 4 + wave) * 256, 16, 0, 0);
     };
     const int swr = (l31 >> 1) & 7;
     unsigned fa3[4], fb3[4];

@@ -302,7 +302,7 @@ def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
 
 
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
-WGRAD_BF16_MIN_FLOPS = 4e9     # below this the 16 tap products are launch-bound: the fp32 kernel is faster
+WGRAD_BF16_MIN_FLOPS = float(os.environ.get("PG_WG_THR", "4e9"))   # below this the tap products are launch-bound: fp32 kernel
 
 
 def _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
