@@ -231,21 +231,26 @@ __global__ __launch_bounds__(256) void channel_major_bf16_kernel(const float* x,
   const int c0 = blockIdx.y * 32;
   const float slope = act_slope(act);
   {
+    // 32-bit index math (q < 2^31 is checked on the host); the 64 q's of a block start on a multiple of 8, and Wp is a
+    // multiple of 8, so the (n, yy, xx) of a row j is found with two unsigned divisions
     const int c = threadIdx.x & 31;
+    const unsigned plane = (unsigned)(Hq + 2) * (unsigned)Wp;
+    const bool cok = c0 + c < C;
+    const float mk_ = 1.f;
+    (void)mk_;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ql = (threadIdx.x >> 5) + 8 * j;
-      const long q = q0 + ql;
+      const unsigned q = (unsigned)q0 + (unsigned)ql;
+      const unsigned n = q / plane;
+      const unsigned r = q - n * plane;
+      const unsigned yy = r / (unsigned)Wp, xx = r - yy * (unsigned)Wp;
+      const int sy = sub * ((int)yy - 1) + py, sx = sub * ((int)xx - 1) + px;
       float v = 0.f;
-      const long plane = (long)(Hq + 2) * Wp;
-      const long n = q / plane;
-      const long r = q - n * plane;
-      const int yy = (int)(r / Wp), xx = (int)(r - (long)yy * Wp);
-      const int sy = sub * (yy - 1) + py, sx = sub * (xx - 1) + px;
-      if (n < N && yy >= 1 && yy <= Hq && xx >= 1 && xx <= Wq && sy < H && sx < W && c0 + c < C) {
+      if (cok && n < (unsigned)N && yy >= 1u && yy <= (unsigned)Hq && xx >= 1u && xx <= (unsigned)Wq && sy < H && sx < W) {
         const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
         const float m = mask ? mask[n * C + c0 + c] : 1.f;
-        const float t = fmaf(x[((n * H + sy) * W + sx) * C + c0 + c], a, b) * m;
+        const float t = fmaf(x[((long)(n * H + sy) * W + sx) * C + c0 + c], a, b) * m;
         v = fmaxf(t, slope * t);
       }
       tile[ql][c] = v;
@@ -269,7 +274,7 @@ extern "C" int pg_channel_major_bf16(const float* x, const float* aff, const flo
                                      int32_t W, int32_t C, int32_t sub, int32_t py, int32_t px, int32_t Hq, int32_t Wq,
                                      int32_t Wp, int64_t K, void* out_bf16, void* stream) {
   PG_REQUIRE(x && out_bf16 && N > 0 && C > 0 && (sub == 1 || sub == 2) && Wp >= Wq + 2 && Wp % 8 == 0 && K % 64 == 0 &&
-             K >= (int64_t)N * (Hq + 2) * Wp && ((size_t)out_bf16 & 15) == 0,
+             K >= (int64_t)N * (Hq + 2) * Wp && K < (1LL << 31) && ((size_t)out_bf16 & 15) == 0,
              "pg_channel_major_bf16: bad geometry (Wp %% 8 == 0, K %% 64 == 0, K >= N*(Hq+2)*Wp)");
   hipLaunchKernelGGL(pg::channel_major_bf16_kernel, dim3((unsigned)(K / 64), (C + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                      x, aff, mask, act, N, H, W, C, sub, py, px, Hq, Wq, Wp, (long)K, reinterpret_cast<unsigned short*>(out_bf16));
