@@ -226,45 +226,51 @@ namespace pg {
 __global__ __launch_bounds__(256) void channel_major_bf16_kernel(const float* x, const float* aff, const float* mask, int act,
                                                                  int N, int H, int W, int C, int sub, int py, int px, int Hq,
                                                                  int Wq, int Wp, long K, unsigned short* out) {
-  __shared__ float tile[64][33];
+  // block tile: 64 q (pixel positions of the padded grid) x 64 channels; 16-byte loads along the channels (NHWC),
+  // transpose through LDS, 16-byte stores along q (channel-major)
+  __shared__ float tile[64][65];
   const long q0 = (long)blockIdx.x * 64;
-  const int c0 = blockIdx.y * 32;
+  const int c0 = blockIdx.y * 64;
   const float slope = act_slope(act);
   {
-    // 32-bit index math (q < 2^31 is checked on the host); the 64 q's of a block start on a multiple of 8, and Wp is a
-    // multiple of 8, so the (n, yy, xx) of a row j is found with two unsigned divisions
-    const int c = threadIdx.x & 31;
+    const int c4 = (threadIdx.x & 15) * 4;
     const unsigned plane = (unsigned)(Hq + 2) * (unsigned)Wp;
-    const bool cok = c0 + c < C;
-    const float mk_ = 1.f;
-    (void)mk_;
+    const bool cok = c0 + c4 < C;            // C % 4 == 0 (host)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ql = (threadIdx.x >> 5) + 8 * j;
+    for (int j = 0; j < 4; ++j) {
+      const int ql = (threadIdx.x >> 4) + 16 * j;
       const unsigned q = (unsigned)q0 + (unsigned)ql;
       const unsigned n = q / plane;
       const unsigned r = q - n * plane;
       const unsigned yy = r / (unsigned)Wp, xx = r - yy * (unsigned)Wp;
       const int sy = sub * ((int)yy - 1) + py, sx = sub * ((int)xx - 1) + px;
-      float v = 0.f;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (cok && n < (unsigned)N && yy >= 1u && yy <= (unsigned)Hq && xx >= 1u && xx <= (unsigned)Wq && sy < H && sx < W) {
         const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
-        const float m = mask ? mask[n * C + c0 + c] : 1.f;
-        const float t = fmaf(x[((long)(n * H + sy) * W + sx) * C + c0 + c], a, b) * m;
-        v = fmaxf(t, slope * t);
+        const float4 xv = *reinterpret_cast<const float4*>(x + ((long)(n * H + sy) * W + sx) * C + c0 + c4);
+        float4 mv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (mask) mv = *reinterpret_cast<const float4*>(mask + n * C + c0 + c4);
+        const float in[4] = {xv.x, xv.y, xv.z, xv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = fmaf(in[e], a, b) * mm[e];
+          v[e] = fmaxf(t, slope * t);
+        }
       }
-      tile[ql][c] = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[ql][c4 + e] = v[e];
     }
   }
   __syncthreads();
   {
-    const int c = threadIdx.x >> 3, qc = threadIdx.x & 7;       // 32 channels x 8 chunks of 8 q's
+    const int c = threadIdx.x >> 2, qc = threadIdx.x & 3;       // 64 channels x 4 chunks of 16 q's
     if (c0 + c < C) {
-      float v[8];
+      float v[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tile[qc * 8 + e][c];
-      const uint4 pk = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-      *reinterpret_cast<uint4*>(out + (long)(c0 + c) * K + q0 + qc * 8) = pk;
+      for (int e = 0; e < 16; ++e) v[e] = tile[qc * 16 + e][c];
+      uint4* o = reinterpret_cast<uint4*>(out + (long)(c0 + c) * K + q0 + qc * 16);
+      o[0] = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+      o[1] = make_uint4(pack2_bf16(v[8], v[9]), pack2_bf16(v[10], v[11]), pack2_bf16(v[12], v[13]), pack2_bf16(v[14], v[15]));
     }
   }
 }
@@ -273,10 +279,10 @@ __global__ __launch_bounds__(256) void channel_major_bf16_kernel(const float* x,
 extern "C" int pg_channel_major_bf16(const float* x, const float* aff, const float* mask, int32_t act, int32_t N, int32_t H,
                                      int32_t W, int32_t C, int32_t sub, int32_t py, int32_t px, int32_t Hq, int32_t Wq,
                                      int32_t Wp, int64_t K, void* out_bf16, void* stream) {
-  PG_REQUIRE(x && out_bf16 && N > 0 && C > 0 && (sub == 1 || sub == 2) && Wp >= Wq + 2 && Wp % 8 == 0 && K % 64 == 0 &&
+  PG_REQUIRE(x && out_bf16 && N > 0 && C > 0 && C % 4 == 0 && (sub == 1 || sub == 2) && Wp >= Wq + 2 && Wp % 8 == 0 && K % 64 == 0 &&
              K >= (int64_t)N * (Hq + 2) * Wp && K < (1LL << 31) && ((size_t)out_bf16 & 15) == 0,
              "pg_channel_major_bf16: bad geometry (Wp %% 8 == 0, K %% 64 == 0, K >= N*(Hq+2)*Wp)");
-  hipLaunchKernelGGL(pg::channel_major_bf16_kernel, dim3((unsigned)(K / 64), (C + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(pg::channel_major_bf16_kernel, dim3((unsigned)(K / 64), (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      x, aff, mask, act, N, H, W, C, sub, py, px, Hq, Wq, Wp, (long)K, reinterpret_cast<unsigned short*>(out_bf16));
   PG_LAUNCH_OK("pg_channel_major_bf16");
   return 0;
