@@ -56,6 +56,7 @@ struct ConvK {
   // differ only in operand / output base offsets (a_off, w_off in BYTES; o_off in floats)
   int gtaps;
   long a_off[MAXTAP], w_off[MAXTAP], o_off[MAXTAP];
+  int xcd_swizzle;          // bf16 data path: the N tiles of one M tile run back-to-back on ONE XCD (shared L2)
 };
 
 struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
@@ -151,8 +152,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int phase = p.gtaps ? 0 : zphase;                         // sub-pixel phase (tap-table row)
   const long a_off_g = p.gtaps ? p.a_off[zphase] : 0, w_off_g = p.gtaps ? p.w_off[zphase] : 0;
   float* const out_g = p.out + (p.gtaps ? p.o_off[zphase] : 0);
-  const int m0 = blockIdx.x * BM;
-  const int nb0 = blockIdx.y * BN;
+  // Workgroups are dealt round-robin to the 8 XCDs (one L2 each) in dispatch order (x fastest).  Remapped, the N
+  // tiles that share an M tile's activation rows are 8 dispatches apart on the SAME XCD instead of gridDim.x apart on
+  // any XCD: the bf16 data path is bound by operand traffic, the fp32 kernels are not (measured: no effect there).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.xcd_swizzle) {
+    const int L = bx + by * (int)gridDim.x, nt = (int)gridDim.y;
+    const int g = L / (8 * nt), r = L - g * 8 * nt;
+    by = r >> 3;
+    bx = g * 8 + (r & 7);
+  }
+  const int m0 = bx * BM;
+  const int nb0 = by * BN;
   const int ntap = p.ntap[phase];
   const bool b_edge = nb0 + BN > p.n_cnt;     // uniform: only edge tiles pay for zeroing rows beyond N
 
@@ -653,9 +664,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     __syncthreads();
     int stage = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      issue(stage ^ 1);                     // next tile (past the end: the last one again, into a stage nobody reads)
-      advance();
-      __builtin_amdgcn_sched_barrier(0);
+      // this tile's operand reads go first (their latency runs under the DMA issue), then the next tile's DMA into
+      // the other stage (past the end: the last tile again, into a stage nobody reads), then the MFMAs
       f32x4 va[4][TM], vb[4][TN];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -665,6 +675,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         lds_read128<0>(vb[ks][0], bb);
         if constexpr (TN > 1) lds_read128<32 * 128>(vb[ks][TN - 1], bb);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      issue(stage ^ 1);
+      advance();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1492,6 +1505,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     k.gtaps = tb->gtaps;
     for (int t = 0; t < tb->gtaps; ++t) { k.a_off[t] = tb->a_off[t]; k.w_off[t] = tb->w_off[t]; k.o_off[t] = tb->o_off[t]; }
   }
+  k.xcd_swizzle = (bf16_data && mt % 8 == 0 && nt > 1 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
   dim3 grid(mt, nt, (tb ? tb->gtaps : k.nphase) * ks);
   switch (cfg) {
     case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
