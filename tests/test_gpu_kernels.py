@@ -319,6 +319,37 @@ def test_weight_gradient_bf16_data_path(name, monkeypatch):
     assert rel(got, ref) < 1e-4, (name, float(rel(got, ref)))
 
 
+def test_bf16_materialisation_kernels():
+    """pg_materialise_bf16 / pg_weights_to_bf16 / pg_channel_major_bf16 against torch (round-to-nearest-even bf16)."""
+    N, H, W, C = 2, 6, 10, 64
+    x = torch.randn(N, H, W, C, device=DEV)
+    aff = torch.rand(N, 2, device=DEV) + 0.5
+    mask = (torch.rand(N, C, device=DEV) > 0.5).float() * 2.0
+    ref = F.leaky_relu((x * aff[:, 0].view(N, 1, 1, 1) + aff[:, 1].view(N, 1, 1, 1)) * mask.view(N, 1, 1, C), 0.2)
+    out = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=DEV)
+    L.call("pg_materialise_bf16", L.ptr(x), L.ptr(aff), L.ptr(mask), L.ACT_LEAKY, N, H * W, C, L.ptr(out), L.stream())
+    # fma vs mul+add may differ in the last fp32 bit before rounding: allow one bf16 ulp on isolated elements
+    d = (out.float() - ref.to(torch.bfloat16).float()).abs()
+    assert float((d > 0).float().mean()) < 1e-2 and float((d / ref.abs().clamp_min(1e-6)).max()) < 2 ** -7
+    w = torch.randn(9, 40, 72, device=DEV)
+    nt = torch.empty(9, 40, 72, dtype=torch.bfloat16, device=DEV)
+    tt = torch.empty(9, 72, 40, dtype=torch.bfloat16, device=DEV)
+    L.call("pg_weights_to_bf16", L.ptr(w), 9, 40, 72, L.ptr(nt), L.ptr(tt), L.stream())
+    assert torch.equal(nt, w.to(torch.bfloat16)) and torch.equal(tt, w.transpose(1, 2).contiguous().to(torch.bfloat16))
+    # channel-major zero-bordered image: full resolution (sub 1) and one stride-2 phase plane (sub 2, parity (1, 0))
+    for sub, py, px in ((1, 0, 0), (2, 1, 0)):
+        Hq, Wq = H // sub, W // sub
+        Wp = (Wq + 2 + 7) // 8 * 8
+        K = (N * (Hq + 2) * Wp + 63) // 64 * 64
+        cm = torch.full((C, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.call("pg_channel_major_bf16", L.ptr(x), None, None, L.ACT_NONE, N, H, W, C, sub, py, px, Hq, Wq, Wp, K, L.ptr(cm),
+               L.stream())
+        want = torch.zeros(C, N, Hq + 2, Wp, device=DEV)
+        want[:, :, 1:Hq + 1, 1:Wq + 1] = x[:, py::sub, px::sub, :].permute(3, 0, 1, 2)
+        want = torch.cat([want.reshape(C, -1), torch.zeros(C, K - N * (Hq + 2) * Wp, device=DEV)], 1)
+        assert torch.equal(cm, want.to(torch.bfloat16))
+
+
 def test_gemm_taps_bf16():
     """pg_gemm_taps_bf16: batched NT GEMM with per-tap element offsets (odd / negative: 2-byte aligned DMA sources)."""
     M, N, K, T = 96, 160, 320, 5
