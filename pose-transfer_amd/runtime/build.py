@@ -12,7 +12,10 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.environ.get("PG_LIB") or os.path.join(LIBDIR, "libposegan_hip.so")
 SOURCES = ["api.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "edge.hip", "igemm_conv.hip", "igemm_wgrad.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+# -pragma-unroll-threshold: the epilogue loops over a wave's MFMA tiles MUST be fully unrolled (a rolled loop indexes the
+# accumulator array at run time and the compiler moves it to scratch memory); the 4x2-tile bf16 kernel exceeds the default
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1000000",
+         "-I" + INCLUDE, "-I" + CSRC]
 
 
 def _hipcc():
