@@ -36,6 +36,8 @@ def synthetic_batch(opt, it, tag, device):
 
 def main(argv=None):
     opt = opts().parse(argv)
+    from pose_transfer_amd.runtime import engine as _E
+    _E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[opt.precision]
     dp.init_from_env()
     device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(device)

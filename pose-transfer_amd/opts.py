@@ -42,6 +42,9 @@ class opts():
         p.add_argument("--vgg_weights", default=None, help="torchvision vgg19 state_dict for the content loss")
         p.add_argument("--steps", default=0, type=int, help="stop after this many iterations (0 = full schedule)")
         p.add_argument("--seed", default=1234, type=int)
+        p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "bf16_data"],
+                       help="contraction operand format: f32 = the reference's arithmetic (default); bf16_data = bf16 data path "
+                            "(fp32 master weights / accumulation; stated bf16 tolerance, DESIGN.md)")
 
     def parse(self, argv=None):
         self.init()
