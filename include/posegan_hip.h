@@ -171,6 +171,15 @@ int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int64_t yH, int
 int pg_repack_small_cin(const float* W, int32_t KH, int32_t KW, int32_t Cout, int32_t Cin, float* Wt, void* stream);
 int pg_small_cin_conv(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                       int32_t pad, const float* Wt, const float* bias, float* out, void* stream);
+/* their weight gradient (autograd of the same two layers): dW packed [KH][KW][64][Cin] += sum over pixels of
+ * dY[n,oy,ox,co] * x[n,ci,oy*stride+r-pad,ox*stride+s-pad]; dY NHWC [N][Ho][Wo][64].  All taps share one pass over dY,
+ * the input patch of a pixel tile is gathered from LDS (csrc/small_cin_wgrad.hip).  k3s1: Cin <= 21; k4s2: Cin <= 44.
+ * `workspace` (optional, PG_SMALL_CIN_WGRAD_WS floats cover every supported shape): per-workgroup partial results that
+ * a second kernel reduces; without it the workgroups add into dW with float atomics (slower). */
+#define PG_SMALL_CIN_WGRAD_WS (768L * 64 * 704)
+int pg_small_cin_wgrad(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                       int32_t pad, const float* dY, float* dW, float* workspace, int64_t workspace_floats,
+                       void* stream);
 
 /* db[c] += sum over rows of a strided [rows][C] view (bias gradient; torch autograd of conv bias). */
 int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,

@@ -245,31 +245,55 @@ __global__ __launch_bounds__(256) void small_cin_conv_kernel(const SmallCinK p) 
 
   for (int c0 = 0; c0 < p.Ctot; c0 += CCH) {
     __syncthreads();
-    // ---- stage the input patch of channels c0..c0+7 (zero outside the image / beyond Ctot)
-    for (int e = tid; e < CCH * PH * PWU; e += 256) {
+    // ---- stage the input patch of channels c0..c0+7 (zero outside the image / beyond Ctot) and the weight chunk
+    //      [(cl*T + tap)][co] (contiguous in the repacked layout).  All loads of the chunk are issued branch-free
+    //      (clamped address + select) before the first LDS store: one memory latency per chunk, not one per element.
+    constexpr int NP = (CCH * PH * PWU + 255) / 256;
+    constexpr int NW = (KC * 16 + 255) / 256;
+    float pv[NP];
+    float4 wv[NW];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int e = tid + 256 * u;
+      const int col = e % PWU;
+      const int rr = (e / PWU) % PH;
+      const int c = c0 + e / (PWU * PH);
+      const int iy = iy0 + rr, ix = ix0 + col;
+      const bool ok = (e < CCH * PH * PWU) & (c < p.Ctot) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      const float* ptr = p.src[0].ptr + (long)n * p.src[0].sN;
+      int sC = (int)p.src[0].sC, sH = (int)p.src[0].sH, sW = (int)p.src[0].sW, cb = 0;
+#pragma unroll
+      for (int q = 1; q < PG_MAX_SRC; ++q) {
+        const bool sel = (q < p.nsrc) & (c >= p.cstart[q]);
+        ptr = sel ? p.src[q].ptr + (long)n * p.src[q].sN : ptr;
+        sC = sel ? (int)p.src[q].sC : sC; sH = sel ? (int)p.src[q].sH : sH; sW = sel ? (int)p.src[q].sW : sW;
+        cb = sel ? p.cstart[q] : cb;
+      }
+      const int off = ok ? (c - cb) * sC + iy * sH + ix * sW : 0;
+      pv[u] = ldg32(reinterpret_cast<const char*>(ptr), (long)off * 4);
+      if (!ok) pv[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int e = (tid + 256 * u) * 4;
+      const bool ok = (e < KC * 64) & (c0 + e / (T * 64) < p.Ctot);
+      wv[u] = *reinterpret_cast<const float4*>(p.Wt + (ok ? (long)c0 * T * 64 + e : 0));
+      if (!ok) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int e = tid + 256 * u;
       const int col = e % PWU;
       const int rr = (e / PWU) % PH;
       const int cl = e / (PWU * PH);
-      const int c = c0 + cl;
-      float v = 0.f;
-      const int iy = iy0 + rr, ix = ix0 + col;
-      if (c < p.Ctot && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) {
-        int j = 0;
-#pragma unroll
-        for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && c >= p.cstart[q]) j = q;
-        const pg_src_t& s = p.src[j];
-        v = s.ptr[(long)n * s.sN + (long)(c - p.cstart[j]) * s.sC + (long)iy * s.sH + (long)ix * s.sW];
-      }
       const int dst = (S == 1) ? ((cl * PH + rr) * ROWF + col)
                                : ((cl * PH + rr) * ROWF + (col & 1) * PWS + (col >> 1));
-      patch[dst] = v;
+      if (e < CCH * PH * PWU) patch[dst] = pv[u];
     }
-    // ---- stage the weight chunk [(cl*T + tap)][co] (contiguous in the repacked layout)
-    for (int e = tid * 4; e < KC * 64; e += 256 * 4) {
-      const int cl = e / (T * 64);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + cl < p.Ctot) v = *reinterpret_cast<const float4*>(p.Wt + (long)c0 * T * 64 + e);
-      *reinterpret_cast<float4*>(&wl[e]) = v;
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int e = (tid + 256 * u) * 4;
+      if (e < KC * 64) *reinterpret_cast<float4*>(&wl[e]) = wv[u];
     }
     __syncthreads();
     // ---- MFMA over the chunk: k = cl*T + r*K + s, pairs (kk, kk+1) on the two lane halves

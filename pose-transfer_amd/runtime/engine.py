@@ -25,7 +25,7 @@ class KernelProfiler:
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
     CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32"}
-    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32"}
+    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin"}
 
     def __init__(self):
         self.records = []
@@ -302,6 +302,9 @@ def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
 
 
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
+SMALL_CIN_WGRAD = os.environ.get("PG_NO_SMALL_CIN_WGRAD") is None   # ablation switch: generic per-tap kernel
+SMALL_CIN_WGRAD_WS = 512 * 64 * 704     # floats: per-workgroup partials of the first-layer weight gradient (<= PG_SMALL_CIN_WGRAD_WS)
+_SCW_WS = {}
 WGRAD_BF16_MIN_FLOPS = float(os.environ.get("PG_WG_THR", "4e9"))   # below this the tap products are launch-bound: fp32 kernel
 
 
@@ -367,6 +370,22 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
                             lambda: _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW))
             return
         return _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW)
+    if (scalar_x and x_is_large and Cout == 64 and y_strides is None and cout_store == 0 and ksplit == 0
+            and act == L.ACT_NONE and SMALL_CIN_WGRAD
+            and ((K == 3 and stride == 1 and Cin <= 21) or (K == 4 and stride == 2 and Cin <= 44))):
+        # first layers (raw NCHW inputs): all taps in one pass over dY, patch gathered from LDS
+        arr = (L.Src * len(srcs))(*srcs)
+        dYp = dY if isinstance(dY, int) else L.ptr(dY)
+        ws = _SCW_WS.get(dW.device)
+        if ws is None:
+            ws = _SCW_WS[dW.device] = torch.empty(SMALL_CIN_WGRAD_WS, dtype=torch.float32, device=dW.device)
+        run = lambda: L.call("pg_small_cin_wgrad", arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, L.ptr(dW), L.ptr(ws),
+                             ws.numel(), L.stream())
+        if PROFILER is not None:
+            PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
+        else:
+            run()
+        return
     d = L.WgradDesc()
     for i, s in enumerate(srcs):
         d.src[i] = s

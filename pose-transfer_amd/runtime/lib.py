@@ -67,6 +67,7 @@ _PROTOS = {
     "pg_small_cout_dgrad": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, C.POINTER(Dst), _i32, _vp],
     "pg_repack_small_cin": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_small_cin_conv": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "pg_small_cin_wgrad": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
     "pg_bias_grad": [_vp, _i64, _i64, _i32, _i64, _i64, _i64, _vp, _vp],
     "pg_cords_to_map": [_vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _i64, _i64, _i64, _i64, _vp],
     "pg_materialise_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],

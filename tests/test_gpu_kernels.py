@@ -538,6 +538,38 @@ def test_output_conv_reassociated():
 
 
 @pytest.mark.parametrize("name", ["first_k3", "stem_k4p0"])
+@pytest.mark.parametrize("srcs", [None, [(18, False, False)], [(3, False, False), (16, False, False), (3, False, False), (16, False, False)]])
+def test_small_cin_patch_wgrad(name, srcs):
+    """First-layer weight gradients through the all-taps LDS-patch kernel (csrc/small_cin_wgrad.hip) vs autograd, incl.
+    ragged tiles, several persistent tiles per workgroup and other channel counts; must agree with the generic kernel."""
+    base = [c for c in conv_cases() if c.name == name][0]
+    if srcs is not None and name == "first_k3" and sum(c[0] for c in srcs) > 21:
+        pytest.skip("k3 patch kernel covers Cin <= 21")
+    for hw, n in (((12, 10), 2), ((24, 40), 3), ((33, 19), 1), ((96, 160), 2)):
+        case = ConvCase(name + "%dx%d" % hw, "conv", srcs or base.srcs, 64, n, hw[0], hw[1], base.K, base.stride, base.pad,
+                        L.ACT_NONE, bias=True, scalar=True)
+        _, _, dw_ref, _ = case.reference()
+        assert E.SMALL_CIN_WGRAD
+        dw = case.run_wgrad()
+        assert rel(dw, dw_ref) < 2e-5, hw
+        E.SMALL_CIN_WGRAD = False
+        try:
+            dw_generic = case.run_wgrad()
+        finally:
+            E.SMALL_CIN_WGRAD = True
+        assert rel(dw, dw_generic) < 2e-5, hw
+        # no workspace: the float-atomics fallback of the same kernel
+        acts = case.device_sources()
+        arr = (L.Src * len(acts))(*[a_.src() for a_ in acts])
+        dW = torch.zeros(case.K, case.K, 64, case.cin, device=DEV)
+        gy = nhwc(case.gout).to(DEV)
+        L.call("pg_small_cin_wgrad", arr, len(acts), case.N, case.H, case.W, case.K, case.stride, case.pad, L.ptr(gy),
+               L.ptr(dW), None, 0, L.stream())
+        torch.cuda.synchronize()
+        assert rel(E._unpack("w", dW).cpu(), dw_ref) < 2e-5, hw
+
+
+@pytest.mark.parametrize("name", ["first_k3", "stem_k4p0"])
 def test_small_cin_patch_conv(name):
     """First-layer convolutions through the LDS-patch MFMA kernel (csrc/edge.hip) vs F.conv2d, incl. ragged tiles."""
     for hw in ((12, 10), (24, 40), (33, 19)):
