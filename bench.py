@@ -129,6 +129,7 @@ def main():
                          "the other modes are extra, non-headline measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--launch-table", default=None, help="write one line per contraction launch of the profiled iteration here")
     args = ap.parse_args()
     global P
     P = args.pose_dim
@@ -174,8 +175,14 @@ def main():
         E.PROFILER = E.KernelProfiler()
         iteration(model, batches, od)
         torch.cuda.synchronize()
-        fam = E.PROFILER.summary()
+        launches = [] if args.launch_table else None
+        fam = E.PROFILER.summary(launches)
         E.PROFILER = None
+        if launches is not None and rank == 0:
+            with open(args.launch_table, "w") as f:
+                f.write("# idx family kind GFLOP ksplit us TFLOP/s\n")
+                for i, (nm, kind, fl, ks, ms) in enumerate(launches):
+                    f.write("%3d %-34s %-5s %8.2f %3d %8.1f %7.1f\n" % (i, nm, kind, fl * 1e-9, ks, ms * 1e3, fl / max(ms, 1e-9) * 1e-9))
         if fam:
             name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12

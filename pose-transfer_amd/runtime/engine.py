@@ -46,7 +46,8 @@ class KernelProfiler:
             name = "conv_igemm<%s,A%d,B%d>" % (self.CONV_TILES[info & 15], (info >> 4) & 15, (info >> 8) & 15)
         self.records.append((name, kind, flops, (info >> 16) & 0x3FFF, e0, e1))
 
-    def summary(self):
+    def summary(self, per_launch=None):
+        """Per-family totals; `per_launch` (a list) additionally receives one (name, kind, flops, ksplit, ms) per launch."""
         import ctypes
         lib = L.load()
         out = {}
@@ -55,6 +56,8 @@ class KernelProfiler:
             L.check(lib.pg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "pg_event_elapsed_ms")
             lib.pg_event_destroy(e0)
             lib.pg_event_destroy(e1)
+            if per_launch is not None:
+                per_launch.append((name, kind, flops, ks, ms.value))
             d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             d["launches"] += 1
             d["ms"] += ms.value
