@@ -565,13 +565,15 @@ __global__ __launch_bounds__(256) void bias_grad_nhwc_kernel(const float* dY, lo
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const long step = (long)gridDim.x * ppb;
   long pix = (long)blockIdx.x * ppb + prow;
-  for (; pix + 3 * step < npix; pix += 4 * step) {      // four independent loads in flight per lane
-    const float4 v0 = *reinterpret_cast<const float4*>(dY + pix * C + chunk * 4);
-    const float4 v1 = *reinterpret_cast<const float4*>(dY + (pix + step) * C + chunk * 4);
-    const float4 v2 = *reinterpret_cast<const float4*>(dY + (pix + 2 * step) * C + chunk * 4);
-    const float4 v3 = *reinterpret_cast<const float4*>(dY + (pix + 3 * step) * C + chunk * 4);
-    acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
-    acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+  for (; pix + 7 * step < npix; pix += 8 * step) {      // eight independent loads in flight per lane
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dY + (pix + u * step) * C + chunk * 4);
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc.x += v[u].x + v[u + 1].x; acc.y += v[u].y + v[u + 1].y;
+      acc.z += v[u].z + v[u + 1].z; acc.w += v[u].w + v[u + 1].w;
+    }
   }
   for (; pix < npix; pix += step) {
     const float4 v = *reinterpret_cast<const float4*>(dY + pix * C + chunk * 4);
@@ -599,7 +601,9 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
   if (sC == 1 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && dense_rows && ((size_t)dY & 15) == 0) {                 // dense NHWC: the streaming kernel
     const int ppb = 256 / (C / 4);
     long blocks = (rows + (long)ppb * 16 - 1) / ((long)ppb * 16);
-    if (blocks > 2048) blocks = 2048;
+    // every workgroup ends with C float atomics on the SAME C addresses: measured ~90 ns per workgroup, serialised
+    // (2048 workgroups: 106 us for a 67 MB tensor; 96: 21 us = 3.2 TB/s with eight 16-byte loads in flight per lane)
+    if (blocks > 96) blocks = 96;
     hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
     PG_LAUNCH_OK("pg_bias_grad");
     return 0;

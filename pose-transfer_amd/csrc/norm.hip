@@ -63,7 +63,23 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* dz, c
   const float* by = y + (long)n * L;
   float s = 0.f, q = 0.f;
   const long L4 = L >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L4; i += (long)gridDim.x * 256) {
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < L4; i += 4 * stride) {           // eight independent 16-byte loads in flight per lane
+    float4 d[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      d[u] = reinterpret_cast<const float4*>(bd)[i + u * stride];
+      v[u] = reinterpret_cast<const float4*>(by)[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += (d[u].x + d[u].y) + (d[u].z + d[u].w);
+      q += (d[u].x * ((v[u].x - mean) * rstd) + d[u].y * ((v[u].y - mean) * rstd)) +
+           (d[u].z * ((v[u].z - mean) * rstd) + d[u].w * ((v[u].w - mean) * rstd));
+    }
+  }
+  for (; i < L4; i += stride) {
     const float4 d = reinterpret_cast<const float4*>(bd)[i];
     const float4 v = reinterpret_cast<const float4*>(by)[i];
     s += (d.x + d.y) + (d.z + d.w);
@@ -114,6 +130,16 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* dz, const fl
   }
 }
 
+// norm_bwd_reduce ends every workgroup with two double atomics on ONE 64-byte line (bsums [N][2]); same-address
+// atomics serialise (measured on the bias gradient: ~90 ns per workgroup), so that kernel gets few, deep workgroups
+static int norm_blocks_bwd(long L, int N) {
+  long b = (L / 4 + 256 * 16 - 1) / (256 * 16);
+  const long cap = N >= 4 ? 64 : N == 3 ? 96 : N == 2 ? 128 : 256;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
 static int norm_blocks(long L) {
   long b = (L / 4 + 256 * 8 - 1) / (256 * 8);
   if (b < 1) b = 1;
@@ -145,7 +171,7 @@ extern "C" int pg_norm_finalize(const double* sums, const float* gamma, const fl
 extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t N, int64_t L,
                                   double* bsums, void* stream) {
   PG_REQUIRE(dz && y && mr && bsums && N > 0 && L > 0 && L % 4 == 0, "pg_norm_bwd_reduce: bad arguments");
-  hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, dz, y, mr,
+  hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(norm_blocks_bwd(L, N), N), dim3(256), 0, (hipStream_t)stream, dz, y, mr,
                      (long)L, bsums);
   PG_LAUNCH_OK("pg_norm_bwd_reduce");
   return 0;
