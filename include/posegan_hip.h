@@ -90,6 +90,11 @@ typedef struct {
   double* stats;            /* optional [N][PG_STAT_SLOTS][2], caller-zeroed: per-sample (sum, sum of squares) of the stored output =
                                pg_norm_stats of `out` (the following per-sample norm, models/networks.py:159), fused
                                into the epilogue when the launch is not split-K; epilogue 0, dense NHWC only        */
+  void* workspace;          /* optional scratch for split-K launches (16-byte aligned): when it holds ksplit x the output,
+                               every split stores its partial tile there and one fix-up kernel reduces them and applies
+                               the epilogue (bias / statistics, or the data-gradient scatter); otherwise split-K adds
+                               into the zero-filled destination with float atomics (slower, order-dependent rounding) */
+  int64_t workspace_bytes;
 } pg_conv_t;
 
 /* MFMA operand precision of pg_conv.  F32 is the reference-parity path and the default everywhere; BF16X3 splits

@@ -57,6 +57,8 @@ struct ConvK {
   int gtaps;
   long a_off[MAXTAP], w_off[MAXTAP], o_off[MAXTAP];
   int xcd_swizzle;          // bf16 data path: the N tiles of one M tile run back-to-back on ONE XCD (shared L2)
+  float* part;              // split-K with a workspace: split s stores its plain partial tile at part + s*part_stride,
+  long part_stride;         // laid out [pixel = (n*Ho+oy)*Wo+ox][n_cnt]; splitk_fixup_kernel reduces and applies the epilogue
 };
 
 struct RowInfo {   // per M-row of the block tile, built once in LDS (12 bytes)
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       stage ^= 1;
     }
   } else {
-  constexpr bool PIPE = !LP && AMODE == A_VEC && BMODE != B_SCALAR && (PG_ABLATE & 127) == 0;
+  constexpr bool PIPE = !LP && AMODE == A_VEC && BMODE != B_SCALAR && (PG_ABLATE & 127) == 0;   // bits >= 1024: epilogue diagnostics
   if constexpr (PIPE) {
     // -------- software-pipelined fp32 K loop (vector loaders).
     // The loader work of a tile is cut into 4 chunks (thread rows i with i % 4 == c) and chunk c travels with one of
@@ -1135,6 +1137,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   if (kt0 >= kt1) return;   // empty split: contributes nothing
 
   // ------------------------------------------------------------------ epilogue
+  if constexpr ((PG_ABLATE & 4096) != 0) { if (acc[0][0][0] != 12345.678f) return; }   // diagnostic: K loop only
+  if (p.part != nullptr) {
+    // split-K with a workspace: plain stores of this split's partial sums; bias / activation derivative / masks /
+    // statistics are applied once by splitk_fixup_kernel.  (Float atomics into the destination cost ~30 us per launch
+    // on the small deep layers — every split hammers the same few hundred KB — plus a memset and, for layers followed
+    // by a norm, a separate statistics pass.)
+    float* pp = p.part + (long)split * p.part_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ng = nb0 + wn0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const RowInfo ri = rows[row];
+          if (ri.n >= 0 && ng < p.n_cnt) pp[(long)((ri.n * p.Ho + ri.oy) * p.Wo + ri.ox) * p.n_cnt + ng] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   const bool atomic = p.ksplit > 1;
   const bool do_stats = p.stats != nullptr && p.epilogue == 0;      // host: only with ksplit == 1
   int stat_n0 = 0;
@@ -1215,6 +1238,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           ok[r] = ri.n >= 0;
           const int nn = ok[r] ? ri.n : 0;
           idx[r] = ok[r] ? (unsigned)((nn * p.Ho + ri.oy) * p.Wo + ri.ox) * (unsigned)C + (unsigned)c : (unsigned)c;
+          if constexpr ((PG_ABLATE & 1024) != 0) { fz[r] = 1.f; ab[r] = make_float2(1.f, 0.f); mk[r] = 1.f; old[r] = 0.f; continue; }
           fz[r] = fwdp[idx[r]];
           ab[r] = *reinterpret_cast<const float2*>(affp + affmul * nn);
           mk[r] = maskp[fm_ ? nn * C + c : (c & 511)];
@@ -1228,6 +1252,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         for (int r = 0; r < 16; ++r) {
           const float z = fmaf(fz[r], ab[r].x, ab[r].y) * mk[r];
           const float g = fmaf(acc[i][j][r] * mk[r], act_grad_s(z, dslope), old[r]);
+          if constexpr ((PG_ABLATE & 2048) != 0) { if (g == 12345.678f) gradp[idx[r]] = g; continue; }
           if (ok[r]) {
             if (atomic) atomicAdd(gradp + idx[r], g); else gradp[idx[r]] = g;
           }
@@ -1295,6 +1320,94 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           atomicAdd(&p.stats[((long)n * PG_STAT_SLOTS + slot) * 2 + 1], dq);
         }
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- split-K fixup
+struct FixupK {
+  const float* part; long stride; int ks;
+  int ppix;                 // pixels per sample (Ho*Wo)
+  int n_cnt;
+  int epilogue;
+  const float* bias; float* out; double* stats;
+  pg_dst_t dst[PG_MAX_SRC];
+  int ndst;
+  int dstart[PG_MAX_SRC + 1];
+};
+
+// grid (workgroups per sample, N): every lane owns 4 consecutive columns of one pixel, sums the ks partial tiles and
+// applies the epilogue of the launch: 0 = + bias, dense NHWC store, optional per-sample statistics for the following
+// norm; 1 = the data-gradient scatter (act'(fwd) / masks / accumulate), same arithmetic as the in-kernel scatter.
+__global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
+  const int n = blockIdx.y;
+  const int q4 = p.n_cnt >> 2;
+  const int items = p.ppix * q4;
+  float st_s = 0.f, st_q = 0.f;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int pl = it / q4, col = (it - pl * q4) * 4;
+    const long pixel = (long)n * p.ppix + pl;
+    const long off = pixel * p.n_cnt + col;
+    float4 v = *reinterpret_cast<const float4*>(p.part + off);
+    int s = 1;
+    for (; s + 3 < p.ks; s += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(p.part + s * p.stride + off);
+      const float4 b = *reinterpret_cast<const float4*>(p.part + (s + 1) * p.stride + off);
+      const float4 c = *reinterpret_cast<const float4*>(p.part + (s + 2) * p.stride + off);
+      const float4 d = *reinterpret_cast<const float4*>(p.part + (s + 3) * p.stride + off);
+      v.x += (a.x + b.x) + (c.x + d.x); v.y += (a.y + b.y) + (c.y + d.y);
+      v.z += (a.z + b.z) + (c.z + d.z); v.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; s < p.ks; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(p.part + s * p.stride + off);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (p.epilogue == 0) {
+      if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+      *reinterpret_cast<float4*>(p.out + off) = v;
+      st_s += (v.x + v.y) + (v.z + v.w);
+      st_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    } else {
+      float* gradp = p.dst[0].grad;
+      const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
+      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0;
+#pragma unroll
+      for (int q = 1; q < PG_MAX_SRC; ++q)
+        if (q < p.ndst && col >= p.dstart[q]) {
+          gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
+          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q];
+        }
+      const int c = col - cst;
+      const long idx = pixel * C + c;
+      float g4[4] = {v.x, v.y, v.z, v.w};
+      float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (mask0) { const float4 m = *reinterpret_cast<const float4*>(mask0 + (long)n * C + c); m4[0] = m.x; m4[1] = m.y; m4[2] = m.z; m4[3] = m.w; }
+      if (fwd0) {
+        const float4 f = *reinterpret_cast<const float4*>(fwd0 + idx);
+        const float a = aff0 ? aff0[2 * n] : 1.f, b = aff0 ? aff0[2 * n + 1] : 0.f;
+        const float f4[4] = {f.x, f.y, f.z, f.w};
+        const float slope = act_slope(dact);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g4[e] = (g4[e] * m4[e]) * act_grad_s(fmaf(f4[e], a, b) * m4[e], slope);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g4[e] *= m4[e];
+      }
+      float4* o = reinterpret_cast<float4*>(gradp + idx);
+      if (dacc) { const float4 old = *o; g4[0] += old.x; g4[1] += old.y; g4[2] += old.z; g4[3] += old.w; }
+      *o = make_float4(g4[0], g4[1], g4[2], g4[3]);
+    }
+  }
+  if (p.stats != nullptr) {
+    __shared__ double red[8];
+    const double ds = wave_sum_d((double)st_s), dq = wave_sum_d((double)st_q);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[w] = ds; red[4 + w] = dq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* slot = p.stats + ((long)n * PG_STAT_SLOTS + (blockIdx.x % PG_STAT_SLOTS)) * 2;
+      atomicAdd(&slot[0], red[0] + red[1] + red[2] + red[3]);
+      atomicAdd(&slot[1], red[4] + red[5] + red[6] + red[7]);
     }
   }
 }
@@ -1476,6 +1589,17 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     if (!dense) ks = 1;
   }
   if (ks < 1) ks = 1;
+  // the workspace path needs every split of every phase to own at least one K tile (an empty split returns before it
+  // stores its partial tile); the kernel gives split s the tiles [s*ceil(kt/ks), (s+1)*ceil(kt/ks))
+  auto splits_nonempty = [&](int c) {
+    for (int ph = 0; ph < k.nphase; ++ph) {
+      const int kt = (amode == A_VEC) ? k.ntap[ph] * (ctot / bke) : cdiv((long)k.ntap[ph] * ctot, BK);
+      if ((long)(c - 1) * cdiv(kt, c) >= kt) return false;
+    }
+    return true;
+  };
+  if (d->ksplit <= 0 && d->workspace != nullptr)
+    while (ks > 1 && !splits_nonempty(ks)) --ks;
   k.ksplit = ks;
   k.stats = nullptr;
   if (d->stats != nullptr) {
@@ -1484,7 +1608,25 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
                "pg_conv: fused statistics need a dense NHWC output without output activation");
     if (ks == 1) k.stats = d->stats;
   }
-  if (ks > 1) {   // atomic accumulation needs zero-initialised destinations
+  // split-K through the caller's workspace (plain partial stores + splitk_fixup_kernel) when it is big enough
+  bool use_part = false;
+  const double out_elems = (double)d->N * d->Ho * d->Wo * k.n_cnt;
+  if (ks > 1 && d->workspace != nullptr && tb == nullptr && k.n_cnt % 4 == 0 && splits_nonempty(ks) &&
+      ((size_t)d->workspace & 15) == 0 && out_elems < 2147483648.0 && (double)ks * out_elems * 4.0 <= (double)d->workspace_bytes &&
+      getenv("PG_NO_SPLITK_WS") == nullptr) {
+    use_part = true;
+    if (d->epilogue == 0) {
+      if (((size_t)d->out & 15) != 0 || (d->bias && ((size_t)d->bias & 15) != 0)) use_part = false;
+    } else {
+      for (int j = 0; j < d->ndst; ++j)
+        if (d->dst[j].C % 4 != 0 || ((size_t)d->dst[j].grad & 15) != 0 || ((size_t)d->dst[j].fwd & 15) != 0 ||
+            ((size_t)d->dst[j].mask & 15) != 0)
+          use_part = false;
+    }
+  }
+  k.part = use_part ? reinterpret_cast<float*>(d->workspace) : nullptr;
+  k.part_stride = (long)out_elems;
+  if (ks > 1 && !use_part) {   // atomic accumulation needs zero-initialised destinations
     if (d->epilogue == 0) {
       PG_REQUIRE(d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
                  d->oN == (long)d->Ho * d->Wo * k.n_cnt,
@@ -1514,7 +1656,24 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, dma, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
-  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16) | (dma ? (1 << 12) : 0);
+  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16) | (dma ? (1 << 12) : 0) | (use_part ? (1 << 13) : 0);
+  if (use_part) {
+    FixupK f;
+    memset(&f, 0, sizeof(f));
+    f.part = k.part; f.stride = k.part_stride; f.ks = ks;
+    f.ppix = d->Ho * d->Wo; f.n_cnt = k.n_cnt; f.epilogue = d->epilogue;
+    f.bias = d->bias; f.out = d->out; f.stats = (d->epilogue == 0) ? d->stats : nullptr;
+    for (int j = 0; j < PG_MAX_SRC; ++j) f.dst[j] = k.dst[j];
+    f.ndst = k.ndst;
+    for (int j = 0; j <= PG_MAX_SRC; ++j) f.dstart[j] = k.dstart[j];
+    const long items = (long)f.ppix * (k.n_cnt / 4);
+    long bx = (items + 511) / 512;
+    if (bx < 1) bx = 1;
+    if (bx > 128) bx = 128;
+    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)bx, (unsigned)d->N), dim3(256), 0, st, f);
+    PG_LAUNCH_OK("pg_conv (split-K fixup)");
+    return 0;
+  }
   if (d->stats != nullptr && k.stats == nullptr)      // split-K (or scatter) launch: statistics from the stored tensor
     return pg_norm_stats(d->out, d->N, (int64_t)d->Ho * d->Wo * k.n_cnt, d->stats, stream);
   return 0;

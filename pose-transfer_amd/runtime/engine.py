@@ -277,6 +277,12 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
     d.ksplit = ksplit
     d.precision = prec
     d.stats = L.ptr(stats)
+    if SPLITK_WS_BYTES > 0:
+        dev_ = W.device if isinstance(W, torch.Tensor) else torch.device("cuda", torch.cuda.current_device())
+        ws = _SPLITK_WS.get(dev_)
+        if ws is None:
+            ws = _SPLITK_WS[dev_] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev_)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
     if PROFILER is not None:
         sp = (Ho * Wo) if mode == 0 else (Hi * Wi)
         ncnt_ = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
@@ -304,6 +310,9 @@ def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
            out if isinstance(out, int) else L.ptr(out), L.stream())
 
 
+# scratch of split-K pg_conv launches (ksplit partial tiles + one fix-up kernel instead of float atomics); 0 disables
+SPLITK_WS_BYTES = int(os.environ.get("PG_SPLITK_WS_MB", "256")) << 20
+_SPLITK_WS = {}
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
 SMALL_CIN_WGRAD = os.environ.get("PG_NO_SMALL_CIN_WGRAD") is None   # ablation switch: generic per-tap kernel
 SMALL_CIN_WGRAD_WS = 512 * 64 * 704     # floats: per-workgroup partials of the first-layer weight gradient (<= PG_SMALL_CIN_WGRAD_WS)

@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
                 ("oN", C.c_int64), ("oC", C.c_int64), ("oH", C.c_int64), ("oW", C.c_int64),
                 ("dst", Dst * PG_MAX_SRC),
                 ("ndst", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32),
-                ("stats", C.c_void_p)]
+                ("stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class WgradDesc(C.Structure):

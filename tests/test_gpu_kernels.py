@@ -217,6 +217,34 @@ def test_conv_fused_norm_statistics(name, ksplit):
     assert float(((st[:, 1] - ref[:, 1]).abs() / ref[:, 1]).max()) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["down_k4", "down_k4_odd", "down_k4_big", "down_small_m", "up_3src", "up_2src"])
+@pytest.mark.parametrize("path", ["workspace", "atomics"])
+def test_conv_split_k_paths(name, path, monkeypatch):
+    """Split-K launches: through the workspace (partial tiles + fix-up kernel applying bias / statistics / the
+    data-gradient scatter; pg_conv_t.workspace) and without one (float atomics into the zero-filled destination):
+    both against autograd, forward (+ fused statistics) and data-gradient (fresh and accumulating destinations)."""
+    if path == "atomics":
+        monkeypatch.setattr(E, "SPLITK_WS_BYTES", 0)
+    case = [c for c in conv_cases() if c.name == name][0]
+    out, dzs, _, _ = case.reference()
+    stats = torch.zeros(case.N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
+    got = case.run_forward(3, stats=stats)
+    info = L.load().pg_last_launch_info()
+    assert ((info >> 16) & 0x3FFF) == 3 and bool(info & (1 << 13)) == (path == "workspace"), hex(info)
+    assert rel(got, out) < 1e-5
+    o64 = out.double().reshape(case.N, -1)
+    st = stats.cpu().sum(1)
+    assert float(((st[:, 0] - o64.sum(1)).abs() / o64.abs().sum(1)).max()) < 1e-6
+    assert float(((st[:, 1] - (o64 * o64).sum(1)).abs() / (o64 * o64).sum(1)).max()) < 1e-6
+    if case.cout >= 32:
+        for ks, acc in ((3, False), (2, True)):
+            gd = case.run_dgrad(ks, acc)
+            info = L.load().pg_last_launch_info()
+            assert ((info >> 16) & 0x3FFF) == ks and bool(info & (1 << 13)) == (path == "workspace"), hex(info)
+            for g, r in zip(gd, dzs):
+                assert rel(g, r) < 1e-5, (ks, acc)
+
+
 # Operand-precision modes of pg_conv (include/posegan_hip.h PG_PREC_*).  fp32 is the parity path (tolerance 1e-5
 # above); bf16x3 (hi+lo split, 3 bf16 MFMAs per product) must stay fp32-class: relative error of the whole tensor
 # <= 5e-5 (product error ~2^-16 per term, random signs); plain bf16 is a mixed-precision option: <= 1e-2.
