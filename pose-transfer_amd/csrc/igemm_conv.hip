@@ -1578,7 +1578,8 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     for (int c = 1; c <= 32 && c <= kmax; ++c) {
       const long b = blocks * c;
       const double eff = (double)b / (double)(((b + 511) / 512) * 512);     // 2 co-resident workgroups x 256 CUs
-      const double score = (b >= 512 ? eff - 0.004 * c : (double)b / 512.0 - 0.002 * c);    // fill fraction below one round
+      // per-split cost (partial tile traffic + fix-up work); swept 0.0003 .. 0.008 on the full iteration: flat below 0.004
+      const double score = (b >= 512 ? eff - 0.002 * c : (double)b / 512.0 - 0.001 * c);    // fill fraction below one round
       if (score > best + 1e-9) { best = score; ks = c; }
     }
   }

@@ -445,6 +445,9 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     }
   }
 
+#ifdef PG_ABLATE_WG
+  if (acc[0][0][0] != 12345.678f) return;   // diagnostic build (tools/ablate.sh): K loop only
+#endif
   const bool atomic = (p.ksplit > 1) || (WGK > 1);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
