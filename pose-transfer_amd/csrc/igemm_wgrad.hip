@@ -89,7 +89,12 @@ __device__ __forceinline__ Pix pix_of(const WgradK& p, const PixState& st, int r
   return q;
 }
 
-template <int BM, int BN, int WGM, int WGN, int WGK, int XS, int YS>
+// XL / HM >= 0 (pipelined vector kernels only) fix `x_is_large` / "the X source has a dropout mask" at compile time and
+// read the per-sample deferred-norm affine from an LDS table (host: N <= WG_AFF_TAB): the selects between the two
+// geometries, the mask offset / multiplies and 8 of the 16 global loads a thread issues per K tile disappear.
+// -1 = decided at run time (generic instantiation).
+constexpr int WG_AFF_TAB = 64;
+template <int BM, int BN, int WGM, int WGN, int WGK, int XS, int YS, int XL = -1, int HM = -1>
 __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int AS = BM + (YS ? 1 : 4);
@@ -310,9 +315,19 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     // launch-uniform flags held in VGPRs on purpose: selects on them compile to v_cndmask instead of scalar branches,
     // which would cut the regions below into several basic blocks (nothing is interleaved across a branch)
     int xl_v = p.x_is_large, hm_v = has_mask ? 1 : 0;
-    asm volatile("" : "+v"(xl_v), "+v"(hm_v));
-    const bool xl = xl_v != 0, hm = hm_v != 0;
+    if constexpr (XL < 0) asm volatile("" : "+v"(xl_v));
+    if constexpr (HM != 0) asm volatile("" : "+v"(hm_v));      // HM = 1: SOME source has a mask; this block's may not
+    const bool xl = XL >= 0 ? (XL != 0) : (xl_v != 0), hm = HM == 0 ? false : (hm_v != 0);
     const unsigned affmul = has_aff ? 8u : 0u;
+    __shared__ float2 aff_tab[XL >= 0 ? WG_AFF_TAB : 1];
+    if constexpr (XL >= 0) {
+      if (tid < WG_AFF_TAB) {
+        float2 ab = make_float2(1.f, 0.f);
+        if (has_aff && tid < p.N) ab = make_float2(xa[2 * tid], xa[2 * tid + 1]);
+        aff_tab[tid] = ab;
+      }
+      __syncthreads();
+    }
     int kc[4] = {kt0, kt0, kt0, kt0};           // tile each pass loads next (clamped at the last tile)
     const int hw3 = p.Hs * p.Ws;
     const int advn3 = WBK / hw3, advy3 = (WBK - advn3 * hw3) / p.Ws, advx3 = WBK - advn3 * hw3 - advy3 * p.Ws;
@@ -323,11 +338,20 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
       const bool adv = !first && kc[i] + 1 < kt1;
       if (adv) ++kc[i];
       const int an = adv ? advn3 : 0, ay = adv ? advy3 : 0, ax = adv ? advx3 : 0;
+      // 128x128 tile: a thread's A row and B row of pass i are the SAME pixel, so one walk (b_st) serves both operands
+      // (two walks were ~30 VALU each per pass: 120 of the ~250 VALU a thread spends per K tile)
+      constexpr bool SHARED_PIX = (A_CPR == B_CPR) && (i < A_PASS) && (i < B_PASS);
+      Pix qb;
+      if constexpr (i < B_PASS) {
+        pix_advance3(p, b_st[i], an, ay, ax);
+        qb = pix_of(p, b_st[i], r, s);
+      }
       if constexpr (i < A_PASS) {
         // x_is_large: dY is the small tensor, dense [pixel][co]; otherwise dY is addressed through the tap geometry
         const int k = kc[i] * WBK + tid / A_CPR + i * (256 / A_CPR);
-        pix_advance3(p, a_st[i], an, ay, ax);
-        const Pix q = pix_of(p, a_st[i], r, s);
+        Pix q;
+        if constexpr (SHARED_PIX) q = qb;
+        else { pix_advance3(p, a_st[i], an, ay, ax); q = pix_of(p, a_st[i], r, s); }
         const bool ok = cok & ((xl & (k < p.Kpix)) | (!xl & (q.n >= 0) & q.lok));   // bitwise on purpose
         const unsigned pixa = xl ? (unsigned)k : (unsigned)((q.n * p.Hl + q.ly) * p.Wl + q.lx);
         const unsigned off = ok ? (pixa * (unsigned)p.Cout + (unsigned)co) * 4u : 0u;
@@ -335,17 +359,19 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
         ra[i] = ldg128(y_base, off);
       }
       if constexpr (i < B_PASS) {
-        pix_advance3(p, b_st[i], an, ay, ax);
-        const Pix q = pix_of(p, b_st[i], r, s);
+        const Pix q = qb;
         const bool ok = (q.n >= 0) & (q.lok | !xl);
         b_ok = (b_ok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
         const int nn = ok ? q.n : 0;
         const int pixl = (q.n * p.Hl + q.ly) * p.Wl + q.lx, pixs = kc[i] * WBK + tid / B_CPR + i * (256 / B_CPR);
         const int pixidx = ok ? (xl ? pixl : pixs) : 0;
         rb[i] = ldg128(x_base, ((unsigned)pixidx * (unsigned)xC + (unsigned)cl) * 4u);
-        rab2[i] = ldg64(aff_base, (unsigned)nn * affmul);
-        const unsigned mo1 = ((unsigned)nn * (unsigned)xC + (unsigned)cl) * 4u, mo0 = (unsigned)(cl & 511) * 4u;
-        rbm[i] = ldg128(m_base, hm ? mo1 : mo0);
+        if constexpr (XL >= 0) rab2[i] = aff_tab[nn];
+        else rab2[i] = ldg64(aff_base, (unsigned)nn * affmul);
+        if constexpr (HM != 0) {
+          const unsigned mo1 = ((unsigned)nn * (unsigned)xC + (unsigned)cl) * 4u, mo0 = (unsigned)(cl & 511) * 4u;
+          rbm[i] = ldg128(m_base, hm ? mo1 : mo0);
+        }
       }
     };
     auto store_pass = [&](int stage, auto ic) {
@@ -361,10 +387,12 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
         const int pr = tid / B_CPR + i * (256 / B_CPR);
         const bool ok = (b_ok >> i) & 1u;
         float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
-        const float mk[4] = {rbm[i].x, rbm[i].y, rbm[i].z, rbm[i].w};
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (HM != 0) { mk[0] = rbm[i].x; mk[1] = rbm[i].y; mk[2] = rbm[i].z; mk[3] = rbm[i].w; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float t = fmaf(v[e], rab2[i].x, rab2[i].y) * mk[e];
+          float t = fmaf(v[e], rab2[i].x, rab2[i].y);
+          if constexpr (HM != 0) t *= mk[e];
           v[e] = ok ? fmaxf(t, slope * t) : 0.f;
         }
         *reinterpret_cast<float4*>(&Bs[pr * BS + (tid % B_CPR) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
@@ -522,8 +550,27 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   dim3 grid(nt, mt, k.ntaps * ks);
 #define PG_WG(BM, WGM, WGN, WGK, XS, YS) \
   hipLaunchKernelGGL((wgrad_igemm_kernel<BM, 64, WGM, WGN, WGK, XS, YS>), grid, dim3(256), 0, st, k)
+  // compile-time geometry / mask variants of the pipelined kernels (per-sample affines from an LDS table)
+  bool any_mask = false;
+  for (int j = 0; j < d->nsrc; ++j) any_mask |= d->src[j].mask != nullptr;
+  // (workgroups with only a few K tiles keep the generic kernel: the table fill + barrier in front of the pipeline
+  //  prologue costs them ~2 us each — measured +10-16 us on launches with 16 tiles per workgroup, -40 us with 32)
+  const bool spec = d->N <= WG_AFF_TAB && !xs && !ys && nkt / ks >= 24 && getenv("PG_WG_GENERIC") == nullptr;
+#define PG_WG_SPEC(BM, BN)                                                                                             \
+  do {                                                                                                                 \
+    if (d->x_is_large) {                                                                                               \
+      if (any_mask) hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 1, 1>), grid, dim3(256), 0, st, k);  \
+      else hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 1, 0>), grid, dim3(256), 0, st, k);           \
+    } else {                                                                                                           \
+      if (any_mask) hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 0, 1>), grid, dim3(256), 0, st, k);  \
+      else hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 0, 0>), grid, dim3(256), 0, st, k);           \
+    }                                                                                                                  \
+  } while (0)
   if (cfg == 3) {
-    hipLaunchKernelGGL((wgrad_igemm_kernel<128, 128, 2, 2, 1, 0, 0>), grid, dim3(256), 0, st, k);
+    if (spec) PG_WG_SPEC(128, 128);
+    else hipLaunchKernelGGL((wgrad_igemm_kernel<128, 128, 2, 2, 1, 0, 0>), grid, dim3(256), 0, st, k);
+  } else if (cfg == 0 && spec) {
+    PG_WG_SPEC(128, 64);
   } else if (cfg == 0) {
     PG_REQUIRE(!xs && !ys, "pg_conv_wgrad: scalar operands need Cout<=64");
     PG_WG(128, 2, 2, 1, 0, 0);
@@ -537,6 +584,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
     if (ys) PG_WG(32, 1, 2, 2, 0, 1); else PG_WG(32, 1, 2, 2, 0, 0);
   }
 #undef PG_WG
+#undef PG_WG_SPEC
   PG_LAUNCH_OK("pg_conv_wgrad");
   last_info() = (narrow ? 4 : cfg) | (xs << 4) | (ys << 8) | (ks << 16) | (1 << 30);
   return 0;
