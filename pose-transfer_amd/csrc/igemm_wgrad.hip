@@ -332,12 +332,69 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     const int hw3 = p.Hs * p.Ws;
     const int advn3 = WBK / hw3, advy3 = (WBK - advn3 * hw3) / p.Ws, advx3 = WBK - advn3 * hw3 - advy3 * p.Ws;
     float2 rab2[B_PASS];
+    // FAST (compile-time geometry, 128x128 tile): the byte offset of the LARGE operand's pixel row is carried along the
+    // pixel walk instead of being rebuilt — off is linear in (n, sy, sx), so a step adds a tile-uniform constant plus
+    // one correction per wrapped coordinate (no integer multiplies: v_mul_lo_u32 / v_mad_u64_u32 are quarter rate and
+    // there were 19 of them per K tile); the dense operand's offset is (uniform tile base) + (per-thread constant);
+    // an invalid X row gets the affine (0, 0) instead of a flag that is tested again at the LDS store.
+    constexpr bool FAST = XL >= 0 && A_CPR == B_CPR && A_PASS == B_PASS;
+    const int CL = (XL == 1) ? xC : p.Cout;                       // channels of the large operand
+    const int sshift = p.stride == 2 ? 1 : 0;                    // host: stride 1 or 2 for the FAST variants
+    const unsigned c_x = (unsigned)(p.stride * CL * 4), c_y = (unsigned)(p.stride * p.Wl * CL * 4),
+                   c_n = (unsigned)(p.Hl * p.Wl * CL * 4);
+    const unsigned Dfull = (unsigned)advx3 * c_x + (unsigned)advy3 * c_y + (unsigned)advn3 * c_n;
+    const unsigned K1 = c_y - (unsigned)p.Ws * c_x, K2 = c_n - (unsigned)p.Hs * c_y;
+    unsigned offL[FAST ? 4 : 1];
+    unsigned dense_a = 0, dense_b = 0;                            // per-thread parts of the dense offsets (pass 0 row)
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) {
+        const int ly = b_st[i].sy * p.stride + r - p.pad, lx = b_st[i].sx * p.stride + s - p.pad;
+        offL[i] = (unsigned)(((b_st[i].n * p.Hl + ly) * p.Wl + lx) * CL + ((XL == 1) ? cl : co)) * 4u;
+      }
+      dense_a = (unsigned)((tid / A_CPR) * p.Cout + co) * 4u;
+      dense_b = (unsigned)((tid / B_CPR) * xC + cl) * 4u;
+    }
 
     auto load_pass = [&](auto ic, bool first) {
       constexpr int i = decltype(ic)::value;
       const bool adv = !first && kc[i] + 1 < kt1;
       if (adv) ++kc[i];
       const int an = adv ? advn3 : 0, ay = adv ? advy3 : 0, ax = adv ? advx3 : 0;
+      if constexpr (FAST) {
+        PixState& st = b_st[i];
+        st.sx += ax;
+        const bool cx = st.sx >= p.Ws;
+        st.sx -= cx ? p.Ws : 0;
+        st.sy += ay + (cx ? 1 : 0);
+        const bool cy = st.sy >= p.Hs;
+        st.sy -= cy ? p.Hs : 0;
+        st.n += an + (cy ? 1 : 0);
+        offL[i] += (adv ? Dfull : 0u) + (cx ? K1 : 0u) + (cy ? K2 : 0u);
+        const int ly = (st.sy << sshift) + r - p.pad, lx = (st.sx << sshift) + s - p.pad;
+        const bool nok = st.n < p.N;
+        const bool inr = nok & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl);
+        const unsigned rowk = (unsigned)(kc[i] * WBK + i * (256 / A_CPR));            // wave-uniform
+        {   // A = dY
+          const bool ok = cok & ((XL == 1) ? nok : inr);
+          const unsigned off = (XL == 1) ? rowk * (unsigned)(p.Cout * 4) + dense_a : offL[i];
+          a_ok = (a_ok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          ra[i] = ldg128(y_base, ok ? off : 0u);
+        }
+        {   // B = X
+          const bool ok = (XL == 1) ? inr : nok;
+          const unsigned off = (XL == 1) ? offL[i] : rowk * (unsigned)(xC * 4) + dense_b;
+          rb[i] = ldg128(x_base, ok ? off : 0u);
+          const int nn = ok ? st.n : 0;
+          const float2 ab = aff_tab[nn];
+          rab2[i] = make_float2(ok ? ab.x : 0.f, ok ? ab.y : 0.f);
+          if constexpr (HM != 0) {
+            const unsigned mo1 = ((unsigned)nn * (unsigned)xC + (unsigned)cl) * 4u, mo0 = (unsigned)(cl & 511) * 4u;
+            rbm[i] = ldg128(m_base, hm ? mo1 : mo0);
+          }
+        }
+        return;
+      }
       // 128x128 tile: a thread's A row and B row of pass i are the SAME pixel, so one walk (b_st) serves both operands
       // (two walks were ~30 VALU each per pass: 120 of the ~250 VALU a thread spends per K tile)
       constexpr bool SHARED_PIX = (A_CPR == B_CPR) && (i < A_PASS) && (i < B_PASS);
@@ -393,7 +450,8 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
         for (int e = 0; e < 4; ++e) {
           float t = fmaf(v[e], rab2[i].x, rab2[i].y);
           if constexpr (HM != 0) t *= mk[e];
-          v[e] = ok ? fmaxf(t, slope * t) : 0.f;
+          if constexpr (FAST) v[e] = fmaxf(t, slope * t);          // invalid rows carry the affine (0, 0): t == 0
+          else v[e] = ok ? fmaxf(t, slope * t) : 0.f;
         }
         *reinterpret_cast<float4*>(&Bs[pr * BS + (tid % B_CPR) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -555,7 +613,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   for (int j = 0; j < d->nsrc; ++j) any_mask |= d->src[j].mask != nullptr;
   // (workgroups with only a few K tiles keep the generic kernel: the table fill + barrier in front of the pipeline
   //  prologue costs them ~2 us each — measured +10-16 us on launches with 16 tiles per workgroup, -40 us with 32)
-  const bool spec = d->N <= WG_AFF_TAB && !xs && !ys && nkt / ks >= 24 && getenv("PG_WG_GENERIC") == nullptr;
+  const bool spec = d->N <= WG_AFF_TAB && !xs && !ys && (d->stride == 1 || d->stride == 2) && nkt / ks >= 24 && getenv("PG_WG_GENERIC") == nullptr;
 #define PG_WG_SPEC(BM, BN)                                                                                             \
   do {                                                                                                                 \
     if (d->x_is_large) {                                                                                               \
