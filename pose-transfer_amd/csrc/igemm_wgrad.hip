@@ -320,13 +320,11 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
     const bool xl = XL >= 0 ? (XL != 0) : (xl_v != 0), hm = HM == 0 ? false : (hm_v != 0);
     const unsigned affmul = has_aff ? 8u : 0u;
     __shared__ float2 aff_tab[XL >= 0 ? WG_AFF_TAB : 1];
-    if constexpr (XL >= 0) {
-      if (tid < WG_AFF_TAB) {
-        float2 ab = make_float2(1.f, 0.f);
-        if (has_aff && tid < p.N) ab = make_float2(xa[2 * tid], xa[2 * tid + 1]);
-        aff_tab[tid] = ab;
-      }
-      __syncthreads();
+    float2 ab_pre = make_float2(1.f, 0.f);                      // table entry `tid`: loaded here, published below —
+    if constexpr (XL >= 0) {                                    // the setup in between hides most of the latency
+      const int tn = (has_aff && tid < p.N && tid < WG_AFF_TAB) ? tid : 0;
+      const float2 t2 = ldg64(aff_base, (unsigned)tn * affmul);
+      if (has_aff && tid < p.N) ab_pre = t2;
     }
     int kc[4] = {kt0, kt0, kt0, kt0};           // tile each pass loads next (clamped at the last tile)
     const int hw3 = p.Hs * p.Ws;
@@ -481,6 +479,10 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
+    if constexpr (XL >= 0) {
+      if (tid < WG_AFF_TAB) aff_tab[tid] = ab_pre;
+      __syncthreads();
+    }
     // the pixel states were initialised AT tile kt0: the first load of every pass must not advance them
     load_pass(I0{}, true); load_pass(I1{}, true); load_pass(I2{}, true); load_pass(I3{}, true);
     store_pass(0, I0{}); store_pass(0, I1{}); store_pass(0, I2{}); store_pass(0, I3{});
@@ -613,7 +615,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   for (int j = 0; j < d->nsrc; ++j) any_mask |= d->src[j].mask != nullptr;
   // (workgroups with only a few K tiles keep the generic kernel: the table fill + barrier in front of the pipeline
   //  prologue costs them ~2 us each — measured +10-16 us on launches with 16 tiles per workgroup, -40 us with 32)
-  const bool spec = d->N <= WG_AFF_TAB && !xs && !ys && (d->stride == 1 || d->stride == 2) && nkt / ks >= 24 && getenv("PG_WG_GENERIC") == nullptr;
+  const bool spec = d->N <= WG_AFF_TAB && !xs && !ys && (d->stride == 1 || d->stride == 2) && nkt / ks >= 8 && getenv("PG_WG_GENERIC") == nullptr;
 #define PG_WG_SPEC(BM, BN)                                                                                             \
   do {                                                                                                                 \
     if (d->x_is_large) {                                                                                               \
