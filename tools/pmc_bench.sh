@@ -26,6 +26,8 @@ for name, d in res.items():
         key = "conv_igemm<%sx%s,A%s,B%s>" % (m.group(2), m.group(3), m.group(6), m.group(7))
     else:
         key = "wgrad_igemm<%sx%s,xs%s,ys%s>" % (m.group(2), m.group(3), m.group(7), m.group(8))
+        if m.group(9) is not None:          # compile-time geometry / mask variants: x_is_large, has-mask
+            key = key[:-1] + ",xl%s,hm%s>" % (m.group(9), m.group(10))
     e = {"launches": max(v["launches"] for v in d.values())}
     for ctr, v in d.items():
         e[ctr + ("_KB" if ctr in ("FETCH_SIZE", "WRITE_SIZE") else "")] = v["avg"]
