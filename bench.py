@@ -173,8 +173,10 @@ def main():
     roof = None
     if not args.no_kernel_profile:
         E.PROFILER = E.KernelProfiler()
+        side, E.SIDE_STREAM = E.SIDE_STREAM, False      # per-kernel durations: no concurrent weight-gradient stream
         iteration(model, batches, od)
         torch.cuda.synchronize()
+        E.SIDE_STREAM = side
         launches = [] if args.launch_table else None
         fam = E.PROFILER.summary(launches)
         E.PROFILER = None

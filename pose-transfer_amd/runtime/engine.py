@@ -313,6 +313,30 @@ def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
 # scratch of split-K pg_conv launches (ksplit partial tiles + one fix-up kernel instead of float atomics); 0 disables
 SPLITK_WS_BYTES = int(os.environ.get("PG_SPLITK_WS_MB", "256")) << 20
 _SPLITK_WS = {}
+# Weight gradients are off the critical path of a backward pass (only the optimiser needs them), so they are enqueued
+# on a SIDE stream: the small deep layers leave most CUs idle (one short round of workgroups), and the weight-gradient
+# of layer l then overlaps the data-gradient of layer l and the norm backward of layer l-1 on the main stream
+# (+1.4 % fp32, +3 % on the bf16 data path; running the two encoders of the forward pass on two streams: +-0).
+# Order: the side stream waits for the main stream at the call (dz complete); the main stream waits for the side
+# stream before a gradient range is reported ready to the data-parallel reducer and at the end of the pass.
+SIDE_STREAM = os.environ.get("PG_NO_SIDE_STREAM") is None
+_SIDE = {}
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _join_side():
+    """main stream waits for everything enqueued on the side stream so far."""
+    if SIDE_STREAM and _SIDE.get(torch.cuda.current_device()) is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
+
+
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
 SMALL_CIN_WGRAD = os.environ.get("PG_NO_SMALL_CIN_WGRAD") is None   # ablation switch: generic per-tap kernel
 SMALL_CIN_WGRAD_WS = 512 * 64 * 704     # floats: per-workgroup partials of the first-layer weight gradient (<= PG_SMALL_CIN_WGRAD_WS)
@@ -374,6 +398,18 @@ def _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
 
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
            y_strides=None, ksplit=0, cout_store=0):
+    if not SIDE_STREAM or not torch.cuda.is_available():
+        return _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x,
+                           y_strides, ksplit, cout_store)
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x, y_strides,
+                    ksplit, cout_store)
+
+
+def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
+                y_strides=None, ksplit=0, cout_store=0):
     if (PRECISION == 3 and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None and cout_store == 0
             and Cin > 32 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor)
             and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS):
@@ -542,6 +578,7 @@ class GeneratorEngine:
     # -------------------------------------------------------------------------------- helpers
     def _ready(self, *prefixes):
         if self.grad_ready_cb is not None:
+            _join_side()          # the reducer's all-reduce orders against the MAIN stream only
             self.grad_ready_cb([k for k in self.A.keys if k.startswith(prefixes)])
 
     def _enc_in_src(self, e, inp):
@@ -667,6 +704,12 @@ class GeneratorEngine:
         return dsts
 
     def backward(self, dpre):
+        try:
+            return self._backward(dpre)
+        finally:
+            _join_side()
+
+    def _backward(self, dpre):
         """dpre: gradient wrt the pre-tanh output, NCHW (N,3,H,W), contiguous.  Accumulates into arena.grads."""
         A, N, H, W = self.A, self.N, self.H, self.W
         assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
@@ -780,6 +823,7 @@ class DiscriminatorEngine:
 
     def _ready(self, *prefixes):
         if self.grad_ready_cb is not None:
+            _join_side()          # the reducer's all-reduce orders against the MAIN stream only
             self.grad_ready_cb([k for k in self.A.keys if k.startswith(prefixes)])
 
     def _stem_srcs(self, pair):
@@ -827,6 +871,12 @@ class DiscriminatorEngine:
         return self.raw[-1].view(self.M, self.K)
 
     def backward(self, dlogits, need_wgrad=True, image_grad=None):
+        try:
+            return self._backward(dlogits, need_wgrad, image_grad)
+        finally:
+            _join_side()
+
+    def _backward(self, dlogits, need_wgrad=True, image_grad=None):
         """dlogits (M,K).  need_wgrad: accumulate weight grads (dis_update).  image_grad: list of NCHW (n,3,H,W)
         buffers (one per forward pair, or None) receiving d/d(judged image) (gen_update)."""
         A, M, H, W = self.A, self.M, self.H, self.W

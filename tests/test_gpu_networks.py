@@ -328,6 +328,41 @@ def test_training_iteration_bf16_data_path_vs_fp32(monkeypatch):
     assert corr > 0.99, corr
 
 
+def test_side_stream_weight_gradients_match_single_stream(monkeypatch):
+    """Weight gradients run on a side stream (engine.SIDE_STREAM).  After ONE iteration the gradient arenas of both
+    networks must equal the single-stream ones up to the float-atomics summation order (1e-4 of the arena max): a
+    missing stream dependency (gradient read before it is written, buffer reused too early) shows up here.  Two more
+    iterations must stay within the run-to-run band of the single-stream path itself (measured: identical runs differ
+    by 5e-3 on out_gen after three Adam steps — atomics noise amplified by Adam)."""
+    H = W = 64
+    N = 2
+    b = dev(*[t(a) for a in synth.batch(93, "ss", N, P, H, W)])
+    b2 = dev(*[t(a) for a in synth.batch(94, "ss2", N, P, H, W)])
+    d = dev(*[t(m) for m in synth.dropout_masks(93, "ss", N)])
+    res = {}
+    for enabled in (False, True):
+        monkeypatch.setattr(E, "SIDE_STREAM", enabled)
+        opt = _opt((H, W), N=N)
+        model = DeformablePose_GAN(opt, device=DEV, init_seed=5)
+        od = vars(opt)
+        snap = []
+        for it in range(3):
+            dl = model.dis_update(b[0], b[1], {"warps": b[2], "masks": b[3], "drop_masks": d}, b2[0], b2[1], od)
+            og, _, gl = model.gen_update(b[0], b[1], {"warps": b[2], "masks": b[3], "drop_masks": d}, od)
+            torch.cuda.synchronize()
+            snap.append((np.array(dl), np.array(gl), og.clone(), model.gen.arena.grads.clone(), model.disc.arena.grads.clone()))
+        res[enabled] = snap
+    a0, b0 = res[False][0], res[True][0]
+    for k in (0, 1):
+        np.testing.assert_allclose(b0[k], a0[k], rtol=1e-5, atol=LOSS_ATOL)
+    assert maxdiff(b0[2], a0[2]) < 1e-5
+    for k in (3, 4):
+        assert maxdiff(b0[k], a0[k]) < 1e-4 * float(a0[k].abs().max()), k
+    for it in (1, 2):
+        assert np.all(np.isfinite(res[True][it][0])) and np.all(np.isfinite(res[True][it][1]))
+        assert maxdiff(res[True][it][2], res[False][it][2]) < (1e-3 if it == 1 else 3e-2)
+
+
 def test_full_size_properties_256():
     """BASELINE.json configs[1] shape (256x256, P=18, batch 4): too big for the CPU oracle inside a test, so check
     size-independent properties: finite losses, tanh range, repeatability of the forward, masked warp output >= 0,
