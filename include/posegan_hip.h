@@ -170,6 +170,13 @@ int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int64_t yH, int
                         int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co, const float* Wt,
                         const pg_dst_t* dst, int32_t ndst, void* stream);
 
+/* data-gradient of the 256->3 output convolution from the im2col'd gradient G [N*H*W][32] (pg_im2col_taps, Cpad 32)
+ * and the weight viewed as Wt [Cin][32] ((tap, co) per input channel, 27 used): dX[p][ci] = sum_t G[p][t] * Wt[ci][t],
+ * scattered over dst[] with act'(fwd) / mask like pg_conv's data-gradient epilogue.  Streaming kernel, one wave per
+ * pixel, Cin = sum dst[].C <= 256, every dst[].C % 4 == 0 (csrc/out_conv_dgrad.hip). */
+int pg_out_conv_dgrad(const float* G, const float* Wt, int32_t N, int32_t H, int32_t W, const pg_dst_t* dst,
+                      int32_t ndst, void* stream);
+
 /* first-layer convolutions with few NCHW input channels and 64 outputs (models/networks.py:186 k3 s1 p1; :341 k4 s2 p0):
  * the input patch of an 8x16 output tile is staged in LDS and feeds the MFMA directly (csrc/edge.hip).
  * `Wt` = pg_repack_small_cin(W packed [KH][KW][64][Cin]) -> [Cin][KH*KW][64]; sources use their (sN,sC,sH,sW) strides. */

@@ -337,6 +337,7 @@ def _join_side():
         torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
 
 
+OUT_CONV_STREAM = os.environ.get("PG_NO_OUT_CONV_STREAM") is None   # ablation switch: K=32 pg_conv launch instead
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
 SMALL_CIN_WGRAD = os.environ.get("PG_NO_SMALL_CIN_WGRAD") is None   # ablation switch: generic per-tap kernel
 SMALL_CIN_WGRAD_WS = 512 * 64 * 704     # floats: per-workgroup partials of the first-layer weight gradient (<= PG_SMALL_CIN_WGRAD_WS)
@@ -732,8 +733,12 @@ class GeneratorEngine:
         # data-gradient of the 3-channel output conv = one K=32 contraction of the same im2col'd gradient with the
         # weight viewed as [27 (tap, co)][cin] (transposed, zero-padded to 32), scattered with relu' / dropout mask
         self.wt_out[:, :27].copy_(A.p(wkey).view(27, cin).t())
-        _conv([Act(self.g_taps, 32).src()], N, H, W, L.ACT_NONE, 0, 1, 1, 0, H, W, self.wt_out, cin, 32,
-              dsts=self._dsts_for(srcs, True))
+        dsts = self._dsts_for(srcs, True)
+        if cin <= 256 and all(t.C % 4 == 0 for t in dsts) and OUT_CONV_STREAM:
+            arr = (L.Dst * len(dsts))(*dsts)          # K = 27: no GEMM — the streaming kernel (one wave per pixel)
+            L.call("pg_out_conv_dgrad", L.ptr(self.g_taps), L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.stream())
+        else:
+            _conv([Act(self.g_taps, 32).src()], N, H, W, L.ACT_NONE, 0, 1, 1, 0, H, W, self.wt_out, cin, 32, dsts=dsts)
         # ---- up blocks
         for i in range(self.ndec - 2, -1, -1):
             srcs = self._dec_sources(i)

@@ -418,6 +418,33 @@ def test_small_cout_data_gradient(name):
         assert rel(nchw(g.cpu()), r) < 1e-5
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_out_conv_streaming_data_gradient(accumulate):
+    """pg_out_conv_dgrad (csrc/out_conv_dgrad.hip): data-gradient of the 3-channel output convolution from the
+    im2col'd gradient (pg_im2col_taps) and the weight viewed as [Cin][27 -> 32], scattered over three destinations with
+    relu' / deferred affine / dropout mask — vs autograd, fresh and accumulating destinations, ragged pixel count."""
+    case = [c for c in conv_cases() if c.name == "final_k3"][0]
+    _, dzs, _, _ = case.reference()
+    acts = case.device_sources()
+    N, H, W = case.N, case.H, case.W
+    gy = case.gout.to(DEV).contiguous()                                     # NCHW (N,3,H,W)
+    ystr = (3 * H * W, H * W, W, 1)
+    G = torch.full((N, H, W, 32), float("nan"), device=DEV)
+    L.call("pg_im2col_taps", L.ptr(gy), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32, L.ptr(G), L.stream())
+    wt = torch.zeros(case.cin, 32, device=DEV)
+    wt[:, :27].copy_(case.packed_weight().view(27, case.cin).t())
+    base = 0.25 if accumulate else float("nan")
+    grads = [torch.full((N, H, W, s_[0]), base, device=DEV) for s_ in case.srcs]
+    dsts = [L.make_dst(grads[j], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=case.act, accumulate=accumulate)
+            for j, a in enumerate(acts)]
+    arr = (L.Dst * len(dsts))(*dsts)
+    L.call("pg_out_conv_dgrad", L.ptr(G), L.ptr(wt), N, H, W, arr, len(dsts), L.stream())
+    torch.cuda.synchronize()
+    for g, r in zip(grads, dzs):
+        got = nchw(g.cpu()) - (0.25 if accumulate else 0.0)
+        assert rel(got, r) < 1e-5
+
+
 @pytest.mark.parametrize("case", conv_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
 @pytest.mark.parametrize("ksplit", [0, 1, 5])
 def test_conv_weight_gradient(case, ksplit):
