@@ -158,16 +158,16 @@ int pg_conv_wgrad(const pg_wgrad_t* desc, void* stream);
  * tap_gather:  out[n,co,y,x] = act(bias[co] + sum_{r,s} Y[n,y+r-pad,x+s-pad,(r*KW+s)*Co+co]) after a 1x1 pg_conv;
  * im2col_taps: G[n,y,x,(r*KW+s)*C+c] = dY[n,c,y-(r-pad),x-(s-pad)], zero padded to Cpad channels (wgrad operand);
  * small_cout_dgrad: dX[p][ci] = sum_{tap,co} dY[p-off(tap)][co]*W[tap][co][ci], split over dst[] like pg_conv's
- *              data-gradient epilogue (K = taps*Co is tiny: a streaming kernel).  The training engine computes the
- *              same gradient as a K=32 pg_conv over the im2col_taps image (faster); this entry point stays for
- *              callers that have no im2col image.                                                              */
+ *              data-gradient epilogue (K = taps*Co is tiny: a streaming kernel); p-off(tap) = (p + pad - tap)/stride
+ *              where that is an integer inside dY.  Used for the discriminator's 512->1 output convolution
+ *              (networks.py:346, k4 s2 p1); the generator's 256->3 output convolution uses pg_out_conv_dgrad.     */
 int pg_tap_gather(const float* Y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co,
                   const float* bias, int32_t out_act, float* out, int64_t oN, int64_t oC, int64_t oH, int64_t oW,
                   void* stream);
 int pg_im2col_taps(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H, int32_t W,
                    int32_t KH, int32_t KW, int32_t pad, int32_t C, int32_t Cpad, float* G, void* stream);
 int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H,
-                        int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co, const float* Wt,
+                        int32_t W, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t Co, const float* Wt,
                         const pg_dst_t* dst, int32_t ndst, void* stream);
 
 /* data-gradient of the 256->3 output convolution from the im2col'd gradient G [N*H*W][32] (pg_im2col_taps, Cpad 32)

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void im2col_taps_kernel(const float* dY, long 
 struct SmallDgradK {
   const float* dY; long yN, yC, yH, yW;
   int N, H, W, KH, KW, pad, Co, Ctot;
+  int stride, Ho, Wo;              // dY is (N,Co,Ho,Wo); input pixel (y,x) pairs with output ((y+pad-r)/stride, (x+pad-s)/stride)
   const float* Wt;                 // packed [KH][KW][Co][Ctot]
   pg_dst_t dst[PG_MAX_SRC];
   int ndst;
@@ -94,11 +95,15 @@ __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(const SmallDgradK
     const int n = (int)(r0 / p.H);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = 0; r < p.KH; ++r) {
-      const int yy = y - (r - p.pad);
-      if (yy < 0 || yy >= p.H) continue;
+      const int ty = y + p.pad - r;
+      if (ty < 0 || ty % p.stride != 0) continue;
+      const int yy = ty / p.stride;
+      if (yy >= p.Ho) continue;
       for (int s = 0; s < p.KW; ++s) {
-        const int xx = x - (s - p.pad);
-        if (xx < 0 || xx >= p.W) continue;
+        const int tx = x + p.pad - s;
+        if (tx < 0 || tx % p.stride != 0) continue;
+        const int xx = tx / p.stride;
+        if (xx >= p.Wo) continue;
         for (int co = 0; co < p.Co; ++co) {
           const float g = p.dY[(long)n * p.yN + (long)co * p.yC + (long)yy * p.yH + (long)xx * p.yW];
           const float4 w = *reinterpret_cast<const float4*>(&wl[((r * p.KW + s) * p.Co + co) * p.Ctot + cg]);
@@ -161,13 +166,14 @@ extern "C" int pg_im2col_taps(const float* dY, int64_t yN, int64_t yC, int64_t y
 }
 
 extern "C" int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H,
-                                   int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t Co, const float* Wt,
-                                   const pg_dst_t* dst, int32_t ndst, void* stream) {
-  PG_REQUIRE(dY && Wt && dst && ndst >= 1 && ndst <= PG_MAX_SRC, "pg_small_cout_dgrad: bad arguments");
+                                   int32_t W, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t Co,
+                                   const float* Wt, const pg_dst_t* dst, int32_t ndst, void* stream) {
+  PG_REQUIRE(dY && Wt && dst && ndst >= 1 && ndst <= PG_MAX_SRC && stride >= 1, "pg_small_cout_dgrad: bad arguments");
   SmallDgradK k;
   memset(&k, 0, sizeof(k));
   k.dY = dY; k.yN = yN; k.yC = yC; k.yH = yH; k.yW = yW;
   k.N = N; k.H = H; k.W = W; k.KH = KH; k.KW = KW; k.pad = pad; k.Co = Co; k.Wt = Wt;
+  k.stride = stride; k.Ho = (H + 2 * pad - KH) / stride + 1; k.Wo = (W + 2 * pad - KW) / stride + 1;
   int c = 0;
   for (int j = 0; j < ndst; ++j) {
     k.dst[j] = dst[j]; k.dstart[j] = c; c += dst[j].C;

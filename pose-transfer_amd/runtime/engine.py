@@ -894,9 +894,14 @@ class DiscriminatorEngine:
             _wgrad([xin.src()], M, L.ACT_LEAKY, dlogits, 1, self.chans[j - 1], True, self.hs[j], self.ws[j],
                    self.hs[j - 1], self.ws[j - 1], 4, 2, 1, A.g(wkey), y_strides=ystr)
             self._ready("net.%d." % j)
-        _conv([Act(dlogits, 1, strides=ystr).src()], M, self.hs[j], self.ws[j], L.ACT_NONE, 1, 4, 2, 1, self.hs[j - 1],
-              self.ws[j - 1], A.p(wkey), 1, self.chans[j - 1], transposed=True, scalar_in=True,
-              dsts=[L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)])
+        dst = L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)
+        if self.chans[j - 1] % 4 == 0 and 16 * self.chans[j - 1] * 4 <= 160 * 1024:
+            # 1 output channel: K = 16 taps, no GEMM — the streaming small-Cout kernel (6 us; 73 us as a pg_conv launch)
+            L.call("pg_small_cout_dgrad", L.ptr(dlogits), ystr[0], ystr[1], ystr[2], ystr[3], M, self.hs[j - 1],
+                   self.ws[j - 1], 4, 4, 2, 1, 1, L.ptr(A.p(wkey)), (L.Dst * 1)(dst), 1, L.stream())
+        else:
+            _conv([Act(dlogits, 1, strides=ystr).src()], M, self.hs[j], self.ws[j], L.ACT_NONE, 1, 4, 2, 1, self.hs[j - 1],
+                  self.ws[j - 1], A.p(wkey), 1, self.chans[j - 1], transposed=True, scalar_in=True, dsts=[dst])
         for j in range(self.nblk - 2, 0, -1):
             wkey = "net.%d.net.1.weight" % j
             dz = self.dz[j]

@@ -64,7 +64,7 @@ _PROTOS = {
     "pg_conv_wgrad": [C.POINTER(WgradDesc), _vp],
     "pg_tap_gather": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
     "pg_im2col_taps": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
-    "pg_small_cout_dgrad": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, C.POINTER(Dst), _i32, _vp],
+    "pg_small_cout_dgrad": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, C.POINTER(Dst), _i32, _vp],
     "pg_out_conv_dgrad": [_vp, _vp, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp],
     "pg_repack_small_cin": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_small_cin_conv": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],

@@ -418,6 +418,25 @@ def test_small_cout_data_gradient(name):
         assert rel(nchw(g.cpu()), r) < 1e-5
 
 
+def test_small_cout_streaming_data_gradient_stride2():
+    """pg_small_cout_dgrad with stride 2 (the discriminator's 512 -> 1 output convolution, k4 s2 p1; reference
+    models/networks.py:346): dX[p] = sum over the taps whose (p + pad - tap) is even and inside dY — vs autograd."""
+    case = [c for c in conv_cases() if c.name == "disc_last"][0]
+    _, dzs, _, _ = case.reference()
+    acts = case.device_sources()
+    N = case.N
+    gy = case.gout.to(DEV).contiguous()                                     # NCHW (N,1,Ho,Wo)
+    ystr = (case.cout * case.Ho * case.Wo, case.Ho * case.Wo, case.Wo, 1)
+    grads = [torch.full((N, case.H, case.W, s_[0]), float("nan"), device=DEV) for s_ in case.srcs]
+    dsts = [L.make_dst(grads[j], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=case.act) for j, a in enumerate(acts)]
+    arr = (L.Dst * len(dsts))(*dsts)
+    L.call("pg_small_cout_dgrad", L.ptr(gy), ystr[0], ystr[1], ystr[2], ystr[3], N, case.H, case.W, case.K, case.K,
+           case.stride, case.pad, case.cout, L.ptr(case.packed_weight()), arr, len(dsts), L.stream())
+    torch.cuda.synchronize()
+    for g, r in zip(grads, dzs):
+        assert rel(nchw(g.cpu()), r) < 1e-5
+
+
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_out_conv_streaming_data_gradient(accumulate):
     """pg_out_conv_dgrad (csrc/out_conv_dgrad.hip): data-gradient of the 3-channel output convolution from the
@@ -585,7 +604,7 @@ def test_output_conv_reassociated():
     grads = [torch.full((N, H, W, s[0]), float("nan"), device=DEV) for s in case.srcs]
     dsts = [L.make_dst(grads[j], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=case.act) for j, a in enumerate(acts)]
     arr = (L.Dst * len(dsts))(*dsts)
-    L.call("pg_small_cout_dgrad", L.ptr(gy), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, L.ptr(wp), arr,
+    L.call("pg_small_cout_dgrad", L.ptr(gy), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 1, 3, L.ptr(wp), arr,
            len(dsts), L.stream())
     torch.cuda.synchronize()
     for g, r in zip(grads, dz_ref):
