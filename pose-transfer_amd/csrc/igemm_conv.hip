@@ -1350,6 +1350,16 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
     const long off = pixel * p.n_cnt + col;
     float4 v = *reinterpret_cast<const float4*>(p.part + off);
     int s = 1;
+    for (; s + 7 < p.ks; s += 8) {                      // eight independent 16-byte loads in flight (ks is 8..32 on the deep layers)
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(p.part + (s + u) * p.stride + off);
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        v.x += t[u].x + t[u + 1].x; v.y += t[u].y + t[u + 1].y;
+        v.z += t[u].z + t[u + 1].z; v.w += t[u].w + t[u + 1].w;
+      }
+    }
     for (; s + 3 < p.ks; s += 4) {
       const float4 a = *reinterpret_cast<const float4*>(p.part + s * p.stride + off);
       const float4 b = *reinterpret_cast<const float4*>(p.part + (s + 1) * p.stride + off);
