@@ -108,7 +108,9 @@ __device__ __noinline__ void stat_spill(double* stats, int n, float g) {
   atomicAdd(&stats[(long)n * PG_STAT_SLOTS * 2 + 1], (double)g * (double)g);
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 0, int DMA = 0>
+// NOMASK = 1 (pipelined fp32 vector kernels): no source carries a dropout mask — no mask load / multiply in the loader
+// (otherwise rows without a mask read a table of ones: 4 of the 12 global loads per K tile and thread).
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 0, int DMA = 0, int NOMASK = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   // LDS layouts: A is [m][k] (row = 32 k's + 4 pad floats): the K-contiguous global float4 lands with ONE ds_write_b128
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
           rmask[i] = ldg128(m_base, (unsigned)(tid & 31) * 16u);
         } else {
           ra[i] = ldg128(a_base, aoff[i]);
-          if constexpr (!(PG_ABLATE & 512)) rmask[i] = ldg128(m_base, moff[i]);
+          if constexpr (!(PG_ABLATE & 512) && !NOMASK) rmask[i] = ldg128(m_base, moff[i]);
         }
       }
 #pragma unroll
@@ -960,7 +962,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if constexpr ((PG_ABLATE & 512) != 0) { v[e] = fmaxf(fmaf(v[e], raa[i], rab[i]), 0.f); continue; }
-          const float t = fmaf(v[e], raa[i], rab[i]) * mk[e];
+          float t = fmaf(v[e], raa[i], rab[i]);
+          if constexpr (!NOMASK) t *= mk[e];
           v[e] = fmaxf(t, slope * t);          // slope 1 / 0 / 0.2 = none / relu / leaky-relu, no branch
         }
         *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * AS + (tid & 7) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1424,7 +1427,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
 
 // ------------------------------------------------------------------------------------------- host side
 template <int BM, int BN, int WGM, int WGN>
-static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma, dim3 grid, hipStream_t st) {
+static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma, bool nomask, dim3 grid, hipStream_t st) {
 #define PG_LAUNCH(A, B) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B>), grid, dim3(256), 0, st, k)
 #define PG_LAUNCH_LP(A, B, P) \
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B, P>), grid, dim3(256), 0, st, k)
@@ -1447,7 +1450,11 @@ static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma,
       return;
     }
   }
-  if (amode == A_VEC && bmode == B_NT) PG_LAUNCH(A_VEC, B_NT);
+  if (nomask && prec == PG_PREC_F32 && amode == A_VEC && bmode == B_NT)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NT, 0, 0, 1>), grid, dim3(256), 0, st, k);
+  else if (nomask && prec == PG_PREC_F32 && amode == A_VEC && bmode == B_NN)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NN, 0, 0, 1>), grid, dim3(256), 0, st, k);
+  else if (amode == A_VEC && bmode == B_NT) PG_LAUNCH(A_VEC, B_NT);
   else if (amode == A_VEC && bmode == B_NN) PG_LAUNCH(A_VEC, B_NN);
   else if (amode == A_VEC && bmode == B_SCALAR) PG_LAUNCH(A_VEC, B_SCALAR);
   else PG_LAUNCH(A_SCALAR, B_SCALAR);
@@ -1659,12 +1666,14 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     for (int t = 0; t < tb->gtaps; ++t) { k.a_off[t] = tb->a_off[t]; k.w_off[t] = tb->w_off[t]; k.o_off[t] = tb->o_off[t]; }
   }
   k.xcd_swizzle = (bf16_data && mt % 8 == 0 && nt > 1 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
+  bool nomask = getenv("PG_CONV_MASK_GENERIC") == nullptr;
+  for (int j = 0; j < d->nsrc; ++j) nomask = nomask && d->src[j].mask == nullptr;
   dim3 grid(mt, nt, (tb ? tb->gtaps : k.nphase) * ks);
   switch (cfg) {
-    case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
-    case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
-    case 2: launch_cfg<64, 64, 2, 2>(k, amode, bmode, d->precision, dma, grid, st); break;
-    default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, dma, grid, st); break;
+    case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
+    case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
+    case 2: launch_cfg<64, 64, 2, 2>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
+    default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
   last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16) | (dma ? (1 << 12) : 0) | (use_part ? (1 << 13) : 0);
