@@ -57,6 +57,7 @@ struct ConvK {
   int gtaps;
   long a_off[MAXTAP], w_off[MAXTAP], o_off[MAXTAP];
   int xcd_swizzle;          // bf16 data path: the N tiles of one M tile run back-to-back on ONE XCD (shared L2)
+  int vec_out;              // epilogue 0 / partial tiles: dense [pixel][n_cnt] rows, n_cnt % 4 == 0, 16-byte aligned base
   float* part;              // split-K with a workspace: split s stores its plain partial tile at part + s*part_stride,
   long part_stride;         // laid out [pixel = (n*Ho+oy)*Wo+ox][n_cnt]; splitk_fixup_kernel reduces and applies the epilogue
 };
@@ -108,10 +109,53 @@ __device__ __noinline__ void stat_spill(double* stats, int n, float g) {
   atomicAdd(&stats[(long)n * PG_STAT_SLOTS * 2 + 1], (double)g * (double)g);
 }
 
+// Row-major 16-byte stores of a wave's 64x64 accumulator sub-tile (2x2 MFMA tiles): the MFMA layout gives a lane ONE
+// column and 16 scattered rows per tile (4-byte stores, 64 store instructions per wave); through a wave-private LDS
+// tile (32 rows x 64 columns, pitch 68) a lane gets 4 consecutive columns of a row: 16 float4 stores per wave, a full
+// 256-byte row segment per 16 lanes.  Used for dense [pixel][n_cnt] destinations (forward output incl. bias and the
+// fused statistics, split-K partial tiles).
+__device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][2], float* T, const RowInfo* rows, int wm0, int lane,
+                                                float* obase, int n_cnt, int Ho, int Wo, int ngc, float4 bv,
+                                                bool do_stats, int stat_n0, float (&st_s)[2], float (&st_q)[2],
+                                                double* stats) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int rsel = lane >> 4, c4 = (lane & 15) * 4;
+  const bool cval = ngc < n_cnt;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 68 + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + rsel;
+      const RowInfo ri = rows[wm0 + i * 32 + row];
+      float4 v = *reinterpret_cast<const float4*>(&T[row * 68 + c4]);
+      if (ri.n >= 0 && cval) {
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        *reinterpret_cast<float4*>(obase + (long)((ri.n * Ho + ri.oy) * Wo + ri.ox) * n_cnt + ngc) = v;
+        if (do_stats) {
+          const float s4 = (v.x + v.y) + (v.z + v.w);
+          const float q4 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+          const int dn = ri.n - stat_n0;
+          if (dn == 0) { st_s[0] += s4; st_q[0] += q4; }
+          else if (dn == 1) { st_s[1] += s4; st_q[1] += q4; }
+          else { stat_spill(stats, ri.n, v.x); stat_spill(stats, ri.n, v.y); stat_spill(stats, ri.n, v.z); stat_spill(stats, ri.n, v.w); }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // NOMASK = 1 (pipelined fp32 vector kernels): no source carries a dropout mask — no mask load / multiply in the loader
 // (otherwise rows without a mask read a table of ones: 4 of the 12 global loads per K tile and thread).
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 0, int DMA = 0, int NOMASK = 0>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   // LDS layouts: A is [m][k] (row = 32 k's + 4 pad floats): the K-contiguous global float4 lands with ONE ds_write_b128
   // and an MFMA operand fetch is ONE ds_read_b128 per lane per 4 k-steps (lanes<32 take k..k+3, lanes>=32 k+4..k+7;
@@ -1147,6 +1191,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     // on the small deep layers — every split hammers the same few hundred KB — plus a memset and, for layers followed
     // by a norm, a separate statistics pass.)
     float* pp = p.part + (long)split * p.part_stride;
+    if constexpr (TM == 2 && TN == 2) {
+      if (p.vec_out) {
+        __syncthreads();                                   // every wave is done with the operand stages
+        float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f};
+        vec_store_64x64(acc, smem + wave * (32 * 68), rows, wm0, lane, pp, p.n_cnt, p.Ho, p.Wo, nb0 + wn0 + (lane & 15) * 4,
+                        make_float4(0.f, 0.f, 0.f, 0.f), false, 0, st0, st1, nullptr);
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1173,8 +1226,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   }
   float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
   const int nbw = __builtin_amdgcn_readfirstlane(nb0 + wn0);   // wave-uniform first column (SGPR: uniform scatter path)
+  bool vec_done = false;
+  if constexpr (TM == 2 && TN == 2) {
+    if (p.vec_out && p.epilogue == 0 && !atomic && p.out_act == PG_OUT_NONE) {
+      __syncthreads();                                     // every wave is done with the operand stages
+      const int ngc = nb0 + wn0 + (lane & 15) * 4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias && ngc < p.n_cnt) bv = *reinterpret_cast<const float4*>(p.bias + ngc);
+      vec_store_64x64(acc, smem + wave * (32 * 68), rows, wm0, lane, out_g, p.n_cnt, p.Ho, p.Wo, ngc, bv, do_stats, stat_n0,
+                      st_s, st_q, p.stats);
+      vec_done = true;
+    }
+  }
   // NOTE: keep this free of lambdas that capture `p` and of runtime indices into p's arrays — either makes the
   // compiler keep a scratch-memory copy of the whole kernel argument (and of acc[][] if these loops stay rolled).
+  if (!vec_done) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1290,6 +1356,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       }
     }
   }
+  }   // !vec_done
   if (do_stats) {
     // block-level reduction (the operand stages in LDS are free now), then ONE pair of double atomics per sample
     // slot and workgroup, spread over PG_STAT_SLOTS addresses per sample
@@ -1641,6 +1708,12 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
             ((size_t)d->dst[j].mask & 15) != 0)
           use_part = false;
     }
+  }
+  {
+    const bool dense0 = d->epilogue == 0 && d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
+                        d->oN == (long)d->Ho * d->Wo * k.n_cnt && ((size_t)d->out & 15) == 0 &&
+                        (d->bias == nullptr || ((size_t)d->bias & 15) == 0) && tb == nullptr;
+    k.vec_out = (k.n_cnt % 4 == 0 && out_elems < 2147483648.0 && (use_part || dense0) && getenv("PG_NO_VEC_EPILOGUE") == nullptr) ? 1 : 0;
   }
   k.part = use_part ? reinterpret_cast<float*>(d->workspace) : nullptr;
   k.part_stride = (long)out_elems;
