@@ -57,6 +57,7 @@ struct ConvK {
   int gtaps;
   long a_off[MAXTAP], w_off[MAXTAP], o_off[MAXTAP];
   int xcd_swizzle;          // bf16 data path: the N tiles of one M tile run back-to-back on ONE XCD (shared L2)
+  int vec_dst;              // epilogue 1: every destination has C % 4 == 0, 16-byte aligned pointers, < 2^32 elements
   int vec_out;              // epilogue 0 / partial tiles: dense [pixel][n_cnt] rows, n_cnt % 4 == 0, 16-byte aligned base
   float* part;              // split-K with a workspace: split s stores its plain partial tile at part + s*part_stride,
   long part_stride;         // laid out [pixel = (n*Ho+oy)*Wo+ox][n_cnt]; splitk_fixup_kernel reduces and applies the epilogue
@@ -145,6 +146,64 @@ __device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][2], float
           else if (dn == 1) { st_s[1] += s4; st_q[1] += q4; }
           else { stat_spill(stats, ri.n, v.x); stat_spill(stats, ri.n, v.y); stat_spill(stats, ri.n, v.z); stat_spill(stats, ri.n, v.w); }
         }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// The data-gradient scatter with the same row-major re-layout: a lane owns 4 consecutive columns of a row, so the forward
+// value / mask / previous gradient / result of 4 elements move as ONE 16-byte access each (the MFMA-layout version
+// issues 3 loads + 1 store of 4 bytes per element).  The destination descriptor is per LANE (a row of 64 columns may
+// cover two destinations) and is passed in already selected; absent forward / mask / accumulate inputs read a
+// per-lane-constant dummy address so that every load stays unconditional.
+struct LaneDst {
+  float* gradp; const float* fwdp; const float* affp; const float* maskp;
+  int C, c, affmul; float dslope; bool has_fwd, has_mask, accum;
+};
+__device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][2], float* T, const RowInfo* rows, int wm0, int lane,
+                                                  const LaneDst& d, bool cval, int Ho, int Wo) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int rsel = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 68 + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                        // two batches of four rows: 16 loads in flight per lane
+      float4 f[4], m[4], old[4], v[4];
+      float2 ab[4];
+      unsigned idx[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = (h * 4 + u) * 4 + rsel;
+        const RowInfo ri = rows[wm0 + i * 32 + row];
+        ok[u] = (ri.n >= 0) & cval;
+        const int nn = ok[u] ? ri.n : 0;
+        idx[u] = ok[u] ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
+        v[u] = *reinterpret_cast<const float4*>(&T[row * 68 + c4]);
+        f[u] = *reinterpret_cast<const float4*>(d.fwdp + (d.has_fwd ? idx[u] : (unsigned)d.c));
+        ab[u] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nn);
+        m[u] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nn * d.C + d.c : (d.c & 511)));
+        old[u] = *reinterpret_cast<const float4*>(d.gradp + (d.accum ? idx[u] : (unsigned)d.c));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float g4[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, f4[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+        const float m4[4] = {m[u].x, m[u].y, m[u].z, m[u].w}, o4[4] = {old[u].x, old[u].y, old[u].z, old[u].w};
+        float r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaf(f4[e], ab[u].x, ab[u].y) * m4[e];
+          r4[e] = fmaf(g4[e] * m4[e], act_grad_s(z, d.dslope), d.accum ? o4[e] : 0.f);
+        }
+        if (ok[u]) *reinterpret_cast<float4*>(d.gradp + idx[u]) = make_float4(r4[0], r4[1], r4[2], r4[3]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1238,6 +1297,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       vec_done = true;
     }
   }
+  if constexpr (TM == 2 && TN == 2 && BMODE != B_SCALAR) {
+    if (p.vec_dst && p.epilogue == 1 && !atomic) {
+      __syncthreads();                                     // every wave is done with the operand stages
+      const int ngc = nb0 + wn0 + (lane & 15) * 4;         // first of this lane's 4 columns
+      const bool cval = ngc < p.n_cnt;
+      const int ngs = cval ? ngc : 0;
+      // constant-index field picks only (a runtime index into the kernel argument would put it in scratch memory)
+      float* gradp = p.dst[0].grad;
+      const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
+      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0;
+#pragma unroll
+      for (int q = 1; q < PG_MAX_SRC; ++q)
+        if (q < p.ndst && ngs >= p.dstart[q]) {
+          gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
+          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q];
+        }
+      LaneDst ld;
+      ld.has_fwd = fwd0 != nullptr;
+      const bool fa_ = aff0 != nullptr && ld.has_fwd;
+      ld.has_mask = mask0 != nullptr;
+      ld.gradp = gradp; ld.fwdp = ld.has_fwd ? fwd0 : gradp;
+      ld.affp = fa_ ? aff0 : kIdentAff; ld.affmul = fa_ ? 2 : 0;
+      ld.maskp = ld.has_mask ? mask0 : kOnes;
+      ld.C = C; ld.c = ngs - cst;
+      ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
+      ld.accum = dacc != 0;
+      vec_scatter_64x64(acc, smem + wave * (32 * 68), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+      vec_done = true;
+    }
+  }
   // NOTE: keep this free of lambdas that capture `p` and of runtime indices into p's arrays — either makes the
   // compiler keep a scratch-memory copy of the whole kernel argument (and of acc[][] if these loops stay rolled).
   if (!vec_done) {
@@ -1614,6 +1703,11 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     k.dst_uniform = 1;
     for (int j = 0; j < d->ndst; ++j)
       if (d->dst[j].C % 32 != 0 || (double)d->N * d->Ho * d->Wo * d->dst[j].C >= 4294967296.0) k.dst_uniform = 0;
+    k.vec_dst = (k.dst_uniform && getenv("PG_NO_VEC_EPILOGUE") == nullptr) ? 1 : 0;
+    for (int j = 0; j < d->ndst; ++j)
+      if (((size_t)d->dst[j].grad & 15) != 0 || ((size_t)d->dst[j].fwd & 15) != 0 || ((size_t)d->dst[j].mask & 15) != 0 ||
+          ((size_t)d->dst[j].aff & 7) != 0)
+        k.vec_dst = 0;
     PG_REQUIRE(c == k.n_cnt, "pg_conv: dst channels %d != N %d", c, k.n_cnt);
   } else {
     PG_REQUIRE(d->out != nullptr, "pg_conv: out null");
