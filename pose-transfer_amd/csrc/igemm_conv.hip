@@ -115,26 +115,28 @@ __device__ __noinline__ void stat_spill(double* stats, int n, float g) {
 // tile (32 rows x 64 columns, pitch 68) a lane gets 4 consecutive columns of a row: 16 float4 stores per wave, a full
 // 256-byte row segment per 16 lanes.  Used for dense [pixel][n_cnt] destinations (forward output incl. bias and the
 // fused statistics, split-K partial tiles).
-__device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][2], float* T, const RowInfo* rows, int wm0, int lane,
+template <int TN_>
+__device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowInfo* rows, int wm0, int lane,
                                                 float* obase, int n_cnt, int Ho, int Wo, int ngc, float4 bv,
                                                 bool do_stats, int stat_n0, float (&st_s)[2], float (&st_q)[2],
                                                 double* stats) {
+  constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR;     // lanes per row, rows per pass
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int rsel = lane >> 4, c4 = (lane & 15) * 4;
+  const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
   const bool cval = ngc < n_cnt;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN_; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 68 + j * 32 + l31] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[i][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + rsel;
+    for (int it = 0; it < 32 / RPP; ++it) {
+      const int row = it * RPP + rsel;
       const RowInfo ri = rows[wm0 + i * 32 + row];
-      float4 v = *reinterpret_cast<const float4*>(&T[row * 68 + c4]);
+      float4 v = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
       if (ri.n >= 0 && cval) {
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         *reinterpret_cast<float4*>(obase + (long)((ri.n * Ho + ri.oy) * Wo + ri.ox) * n_cnt + ngc) = v;
@@ -162,32 +164,34 @@ struct LaneDst {
   float* gradp; const float* fwdp; const float* affp; const float* maskp;
   int C, c, affmul; float dslope; bool has_fwd, has_mask, accum;
 };
-__device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][2], float* T, const RowInfo* rows, int wm0, int lane,
+template <int TN_>
+__device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowInfo* rows, int wm0, int lane,
                                                   const LaneDst& d, bool cval, int Ho, int Wo) {
+  constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR;     // lanes per row, rows per pass
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int rsel = lane >> 4, c4 = (lane & 15) * 4;
+  const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN_; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 68 + j * 32 + l31] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[i][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {                        // two batches of four rows: 16 loads in flight per lane
+    for (int h = 0; h < 32 / RPP / 4; ++h) {             // batches of four row passes: 16 loads in flight per lane
       float4 f[4], m[4], old[4], v[4];
       float2 ab[4];
       unsigned idx[4];
       bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int row = (h * 4 + u) * 4 + rsel;
+        const int row = (h * 4 + u) * RPP + rsel;
         const RowInfo ri = rows[wm0 + i * 32 + row];
         ok[u] = (ri.n >= 0) & cval;
         const int nn = ok[u] ? ri.n : 0;
         idx[u] = ok[u] ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
-        v[u] = *reinterpret_cast<const float4*>(&T[row * 68 + c4]);
+        v[u] = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
         f[u] = *reinterpret_cast<const float4*>(d.fwdp + (d.has_fwd ? idx[u] : (unsigned)d.c));
         ab[u] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nn);
         m[u] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nn * d.C + d.c : (d.c & 511)));
@@ -1250,11 +1254,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
     // on the small deep layers — every split hammers the same few hundred KB — plus a memset and, for layers followed
     // by a norm, a separate statistics pass.)
     float* pp = p.part + (long)split * p.part_stride;
-    if constexpr (TM == 2 && TN == 2) {
+    if constexpr (TM == 2 && (TN == 1 || TN == 2)) {
       if (p.vec_out) {
         __syncthreads();                                   // every wave is done with the operand stages
         float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f};
-        vec_store_64x64(acc, smem + wave * (32 * 68), rows, wm0, lane, pp, p.n_cnt, p.Ho, p.Wo, nb0 + wn0 + (lane & 15) * 4,
+        vec_store_64x64<TN>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, pp, p.n_cnt, p.Ho, p.Wo, nb0 + wn0 + (lane % (8 * TN)) * 4,
                         make_float4(0.f, 0.f, 0.f, 0.f), false, 0, st0, st1, nullptr);
         return;
       }
@@ -1286,21 +1290,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
   float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
   const int nbw = __builtin_amdgcn_readfirstlane(nb0 + wn0);   // wave-uniform first column (SGPR: uniform scatter path)
   bool vec_done = false;
-  if constexpr (TM == 2 && TN == 2) {
+  if constexpr (TM == 2 && (TN == 1 || TN == 2)) {
     if (p.vec_out && p.epilogue == 0 && !atomic && p.out_act == PG_OUT_NONE) {
       __syncthreads();                                     // every wave is done with the operand stages
-      const int ngc = nb0 + wn0 + (lane & 15) * 4;
+      const int ngc = nb0 + wn0 + (lane % (8 * TN)) * 4;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.bias && ngc < p.n_cnt) bv = *reinterpret_cast<const float4*>(p.bias + ngc);
-      vec_store_64x64(acc, smem + wave * (32 * 68), rows, wm0, lane, out_g, p.n_cnt, p.Ho, p.Wo, ngc, bv, do_stats, stat_n0,
+      vec_store_64x64<TN>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, out_g, p.n_cnt, p.Ho, p.Wo, ngc, bv, do_stats, stat_n0,
                       st_s, st_q, p.stats);
       vec_done = true;
     }
   }
-  if constexpr (TM == 2 && TN == 2 && BMODE != B_SCALAR) {
+  if constexpr (TM == 2 && (TN == 1 || TN == 2) && BMODE != B_SCALAR) {
     if (p.vec_dst && p.epilogue == 1 && !atomic) {
       __syncthreads();                                     // every wave is done with the operand stages
-      const int ngc = nb0 + wn0 + (lane & 15) * 4;         // first of this lane's 4 columns
+      const int ngc = nb0 + wn0 + (lane % (8 * TN)) * 4;   // first of this lane's 4 columns
       const bool cval = ngc < p.n_cnt;
       const int ngs = cval ? ngc : 0;
       // constant-index field picks only (a runtime index into the kernel argument would put it in scratch memory)
@@ -1323,7 +1327,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       ld.C = C; ld.c = ngs - cst;
       ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
       ld.accum = dacc != 0;
-      vec_scatter_64x64(acc, smem + wave * (32 * 68), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+      vec_scatter_64x64<TN>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
       vec_done = true;
     }
   }
