@@ -537,6 +537,43 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(const WgradK p) {
   if (acc[0][0][0] != 12345.678f) return;   // diagnostic build (tools/ablate.sh): K loop only
 #endif
   const bool atomic = (p.ksplit > 1) || (WGK > 1);
+  if constexpr (TM == 2 && TN == 2 && WGK == 1) {
+    // un-split launches (the deep layers: few pixels, 16 MB of dW each) are bound by the read-modify-write of dW:
+    // row-major float4 accesses through a wave-private LDS tile instead of 4 bytes per lane in the MFMA layout
+    if (!atomic && (p.Ctot & 3) == 0 && ((size_t)p.dW & 15) == 0) {
+      __syncthreads();                                     // every wave is done with the operand stages
+      float* T = smem + (tid >> 6) * (32 * 68);
+      const int rsel = lane >> 4, c4 = (lane & 15) * 4;
+      const int ci = ci0 + wn0 + c4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) T[((q & 3) + 8 * (q >> 2) + 4 * lhi) * 68 + j * 32 + l31] = acc[i][j][q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 v[8], old[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int co = co0 + wm0 + i * 32 + it * 4 + rsel;
+          const bool ok = (co < p.cout_store) & (ci < p.Ctot);
+          v[it] = *reinterpret_cast<const float4*>(&T[(it * 4 + rsel) * 68 + c4]);
+          old[it] = *reinterpret_cast<const float4*>(p.dW + (ok ? ((long)tap * p.cout_store + co) * p.Ctot + ci : 0));
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int co = co0 + wm0 + i * 32 + it * 4 + rsel;
+          if ((co < p.cout_store) & (ci < p.Ctot))
+            *reinterpret_cast<float4*>(p.dW + ((long)tap * p.cout_store + co) * p.Ctot + ci) =
+                make_float4(old[it].x + v[it].x, old[it].y + v[it].y, old[it].z + v[it].z, old[it].w + v[it].w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
