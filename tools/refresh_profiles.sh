@@ -1,5 +1,7 @@
 #!/bin/bash
-# One GPU-box pass that regenerates everything kept under profiles/ (run through gpurun, then copy from gpurun_out/):
+# One GPU-box pass that regenerates everything kept under profiles/ (run through gpurun, then copy from gpurun_out/:
+# the bench lines as they are, the rocprofv3 databases gpurun_out/prof_{refresh,bf,ss}/bench_results.db through
+# tools/rocpd_summary.py, gpurun_out/pmc_bench.json as round1_pmc.json):
 #   gpurun --timeout 1500 -- bash tools/refresh_profiles.sh
 mkdir -p gpurun_out/refresh
 O=gpurun_out/refresh
@@ -17,5 +19,6 @@ python bench.py --batch 32 --steps 8 --no-cpu-baseline --precision bf16 2>/dev/n
 python bench.py --batch 32 --steps 8 --no-cpu-baseline --precision bf16_data 2>/dev/null | tail -1 > $O/round1_bench_b32_bf16_data_1gpu.json
 bash tools/profile_bench_bf16.sh > $O/profile_bf16.log 2>&1
 bash tools/profile_bench.sh refresh > $O/profile.log 2>&1
+PG_NO_SIDE_STREAM=1 bash tools/profile_bench.sh ss > $O/profile_single_stream.log 2>&1   # -> round1_kernel_stats_single_stream.csv
 bash tools/pmc_bench.sh > $O/pmc.log 2>&1
 for f in $O/*.json; do echo "$f: $(cut -c1-150 $f)"; done
