@@ -220,6 +220,27 @@ int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* 
 int pg_cords_to_map(const float* cords, int32_t N, int32_t P, int32_t H, int32_t W, float sigma, float* out,
                     int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream);
 
+/* ---- per-sample pose geometry, the CPU work right before the step (utils/pose_transform.py:94-289,
+ * executed by the reference inside Dataset.__getitem__ on the main thread: datasets/PoseTransfer_Dataset.py:89-108).
+ * kp_* [N][P][2] = (y, x) as float, -1 = missing; P = 16 (LABELS) or 18 (LABELS_PAF), pose_utils.py:25-35.
+ * pg_affine_transforms: affine_transforms(kp_from, kp_to) (pose_transform.py:213-289) -> out [N][10][8] float32
+ *   = [a0 a1 a2 b0 b1 b2 0 0] (inverse map target -> source in pixels; "no point" rows [1 0 1000 0 1 1000 0 0]).
+ *   Fit = skimage AffineTransform.estimate restated (Hartley-normalised total least squares), fp64; PARITY UNPINNED
+ *   against scikit-image itself (absent offline), pinned against oracle/pose_geometry.py.
+ * pg_pose_masks: pose_masks(kp_to, (H,W)) (pose_transform.py:143-184) -> out [N][10][H][W] float32 in {0,1}
+ *   (polygon fill = the pnpoly crossing test of skimage.measure.grid_points_in_poly restated; same caveat).
+ * A sample without the four torso joints makes the reference raise KeyError (compute_st_distance, :119-122); here it
+ * yields "no point" transforms / a body-only mask set, and the host wrapper raises.                                   */
+int pg_affine_transforms(const float* kp_from, const float* kp_to, int32_t N, int32_t P, float* out, void* stream);
+int pg_pose_masks(const float* kp_to, int32_t N, int32_t P, int32_t H, int32_t W, float* out, void* stream);
+/* estimate_uniform_transform (pose_transform.py:293-326; warp_skip='full'): one torso(+knees) fit -> out [N][1][8]. */
+int pg_uniform_transform(const float* kp_from, const float* kp_to, int32_t N, int32_t P, float* out, void* stream);
+/* _preprocess_image (utils/pose_utils.py:216-217) of a uint8 HWC batch [N][H][W][3] (DEVICE pointer, e.g. the async copy
+ * of a pinned decode buffer): out[n*oN + c*oC + y*oH + x*oW] = float32((v / 255 - 0.5) * 2) evaluated in float64 —
+ * with the strides of input[:, :3] the image lands in the network input without transpose / cat (Dataset.py:135-144,183). */
+int pg_preprocess_image(const uint8_t* img, int32_t N, int32_t H, int32_t W, float* out, int64_t oN, int64_t oC,
+                        int64_t oH, int64_t oW, void* stream);
+
 /* ---- deformable skip connection (utils/pose_transform.py:16-92)
  * mask pyramid: cv2.resize(mask_HWT,(w,h)) INTER_LINEAR (pose_transform.py:84-87) on device.
  *   masks [N][T][H0][W0] (float32, or float64 when is_f64) -> out [N][h][w][T] float32.            */
@@ -265,6 +286,25 @@ int pg_nn_loss(const float* P, const float* G, int32_t N, int32_t H, int32_t W, 
  * step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) computed by the host in double.                  */
 int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float b1, float b2, float eps,
             float step_size, float bc2_sqrt, float grad_scale, void* stream);
+/* the same step with (a) bf16 gradients `g_bf16` (NULL = read fp32 `g`): the all-reduced bf16 bucket of the data-parallel
+ * path, and (b) an optional bf16 copy `p_bf16` (NULL = none) of the UPDATED parameters written in the same pass — the
+ * K-contiguous weight operand of the bf16 data path (the arena's packed [tap][Cout][Cin] layout).  n % 4 == 0.          */
+int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m, float* v, int64_t n, float b1, float b2, float eps,
+               float step_size, float bc2_sqrt, float grad_scale, void* p_bf16, void* stream);
+
+/* ---- data-parallel gradient exchange (NEW: the reference is single-process; main.py:44-159 has no
+ * counterpart).  One process per GPU; RCCL (xGMI) is resolved at run time (dlopen librccl.so.1), the communication stream
+ * and every ordering event belong to the caller.
+ *   pg_comm_unique_id : rank 0 draws the 128-byte rendezvous token (ncclGetUniqueId); the host broadcasts it out of band
+ *   pg_comm_init      : every rank joins (ncclCommInitRank) -> opaque handle
+ *   pg_comm_allreduce_bucket : in-place SUM over ranks of `count` elements, dtype 0 = fp32 / 1 = bf16, enqueued on `stream`
+ *   pg_pack_bf16      : fp32 -> bf16 (RNE) staging of a finished gradient range before a bf16 bucket is reduced          */
+int pg_comm_unique_id(void* out128);
+int pg_comm_init(const void* unique_id128, int32_t rank, int32_t world, void** comm);
+int pg_comm_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, void* stream);
+int pg_comm_destroy(void* comm);
+int pg_pack_bf16(const float* src, void* dst, int64_t n, void* stream);
+
 /* channel-dropout multipliers in {0, 1/(1-p)} from a stateless counter hash (nn.Dropout2d, networks.py:161). */
 int pg_dropout_mask(float* out, int64_t n, uint64_t key, float p, void* stream);
 int pg_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);

@@ -211,7 +211,9 @@ def warp_mask_max(feat, warps, masks, init_size, align_corners=False, aten=False
     max over T.  reference utils/pose_transform.py:69-92.  masks: (N,T,H0,W0) at full resolution."""
     n, c, h, w = feat.shape
     warped = (affine_sample_aten if aten else affine_sample)(feat, warps, init_size, align_corners)
-    m = mask_pyramid(masks, h, w).view(n, -1, 1, h, w)
+    if masks is None:          # warp_skip 'full' / 'none': one transform, no mask (pose_transform.py:80,88)
+        return warped.max(dim=1)[0]
+    m = mask_pyramid(masks, h, w).view(n, -1, 1, h, w).to(feat.dtype)
     return (warped * m).max(dim=1)[0]
 
 
@@ -223,7 +225,8 @@ def split_input(x, pose_dim):
 
 def generator_forward(inp, warps, masks, p, pose_dim, nfilters_enc, nfilters_dec, init_size,
                       drops=None, align_corners=False, return_skips=False, aten_warp=False):
-    """Deformable_Generator.forward + concatenate_skips: reference models/networks.py:269-288."""
+    """Deformable_Generator.forward + concatenate_skips: reference models/networks.py:269-288.
+    masks=None is warp_skip 'full' / 'none': warps (N,1,>=6), a single unmasked transform (networks.py:283)."""
     img, src_pose, tgt_pose = split_input(inp, pose_dim)
     nlev = len(nfilters_enc)
     sk_app = encoder_forward(torch.cat([img, src_pose], 1), p, "encoder_app", nlev)
@@ -235,6 +238,28 @@ def generator_forward(inp, warps, masks, p, pose_dim, nfilters_enc, nfilters_dec
         skips.append(torch.cat([a, q], 1))
     out = decoder_forward(skips, p, len(nfilters_dec), drops)
     return (out, sk_app, sk_pose, skips) if return_skips else out
+
+
+def stacked_generator_forward(inp, target_pose, warps, masks, p, pose_dim, num_stacks, nfilters_enc, nfilters_dec,
+                              init_size, drops=None, align_corners=False):
+    """Stacked_Generator.forward (reference models/networks.py:306-327): the SAME generator applied num_stacks
+    times; stage i sees [previous output, pose_{i-1}, pose_i] (stage 0: [image, input pose, pose_0]).
+    target_pose (N, num_stacks*P, H, W); warps (N, num_stacks, T, 8); masks (N, num_stacks, T, H, W) | None;
+    drops: per-stage list of dropout-mask lists | None.  Returns the list of stage outputs."""
+    img, init_pose, _ = split_input(inp, pose_dim)
+    P = pose_dim
+    outs = []
+    out = None
+    for i in range(num_stacks):
+        tp = target_pose[:, i * P:(i + 1) * P]
+        if i == 0:
+            x = torch.cat([img, init_pose, tp], 1)
+        else:
+            x = torch.cat([out, target_pose[:, (i - 1) * P:i * P], tp], 1)
+        out = generator_forward(x, warps[:, i], None if masks is None else masks[:, i], p, P, nfilters_enc,
+                                nfilters_dec, init_size, None if drops is None else drops[i], align_corners)
+        outs.append(out)
+    return outs
 
 
 def baseline_generator_forward(inp, p, nfilters_enc, nfilters_dec, drops=None):
@@ -348,6 +373,11 @@ class Trainer:
 
     def gen(self, gp, inp, warps, masks, drops):
         c = self.cfg
+        if c.get("gen_type", "baseline") == "stacked":
+            # warps = {'interpol_pose', 'interpol_warps', 'interpol_masks'} (reference pose_gan.py:72-77)
+            return stacked_generator_forward(inp, warps["interpol_pose"], warps["interpol_warps"],
+                                             warps.get("interpol_masks"), gp, c["pose_dim"], c["num_stacks"], self.enc,
+                                             self.dec, c["image_size"], drops, c.get("align_corners", False))[-1]
         if c.get("deformable", True):
             return generator_forward(inp, warps, masks, gp, c["pose_dim"], self.enc, self.dec,
                                      c["image_size"], drops, c.get("align_corners", False),

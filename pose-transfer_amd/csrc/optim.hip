@@ -39,6 +39,47 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     }
 }
 
+// Adam with (a) optional bf16 gradients (the all-reduced bf16 bucket of the data-parallel path) and (b) an optional bf16
+// copy of the updated parameters written in the same pass — the K-contiguous bf16 weight operand of the bf16 data path
+// (packed [tap][Cout][Cin] is the arena layout itself), instead of a conversion pass per optimiser step.
+template <bool GBF, bool WBF>
+__global__ __launch_bounds__(256) void adam_ex_kernel(float* p, const float* g, const unsigned short* gb, float* m, float* v,
+                                                      long n, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                                                      float grad_scale, unsigned short* pb) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg;
+    if (GBF) {
+      const uint2 q = reinterpret_cast<const uint2*>(gb)[i];
+      gg = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                       __uint_as_float(q.y & 0xffff0000u));
+    } else {
+      gg = reinterpret_cast<const float4*>(g)[i];
+    }
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = ga[e] * grad_scale;
+      ma[e] = ma[e] * b1 + (1.f - b1) * gr;
+      va[e] = va[e] * b2 + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(va[e]) / bc2_sqrt + eps;
+      pa[e] = pa[e] - step_size * (ma[e] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (WBF) {
+      uint2 o;
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(pp.x), "v"(pp.y));
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(pp.z), "v"(pp.w));
+      reinterpret_cast<uint2*>(pb)[i] = o;
+    }
+  }
+}
+
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ULL;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -98,6 +139,25 @@ extern "C" int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
   hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, b1, b2,
                      eps, step_size, bc2_sqrt, grad_scale);
   PG_LAUNCH_OK("pg_adam");
+  return 0;
+}
+
+extern "C" int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m, float* v, int64_t n, float b1, float b2,
+                          float eps, float step_size, float bc2_sqrt, float grad_scale, void* p_bf16, void* stream) {
+  PG_REQUIRE(p && (g || g_bf16) && m && v && n > 0 && n % 4 == 0, "pg_adam_ex: bad arguments (n %% 4 == 0)");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const unsigned short* gb = reinterpret_cast<const unsigned short*>(g_bf16);
+  unsigned short* pb = reinterpret_cast<unsigned short*>(p_bf16);
+#define PG_ADAM_EX(G, W)                                                                                               \
+  hipLaunchKernelGGL((adam_ex_kernel<G, W>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, gb, m, v, (long)n, \
+                     b1, b2, eps, step_size, bc2_sqrt, grad_scale, pb)
+  if (gb && pb) PG_ADAM_EX(true, true);
+  else if (gb) PG_ADAM_EX(true, false);
+  else if (pb) PG_ADAM_EX(false, true);
+  else PG_ADAM_EX(false, false);
+#undef PG_ADAM_EX
+  PG_LAUNCH_OK("pg_adam_ex");
   return 0;
 }
 

@@ -1,6 +1,11 @@
 """Training driver with the reference's loop shape (reference src_deformable/main.py:44-159): per iteration
-`training_ratio` x [two batches -> dis_update] then one batch -> gen_update.  The reference's datasets are
-private, so batches come from the synthetic generator (utils/synth.py).
+`training_ratio` x [two batches -> dis_update] then one batch -> gen_update; every `display_ratio` iterations the loss
+means are printed and a test batch is run through the generator; every `checkpoint_ratio` epochs `gen_%03d.pkl` /
+`disc_%03d.pkl` are written.
+
+Batches come from `PoseTransfer_Dataset` (`--synthetic 0`, the reference's CSV / image layout under `--data_Dir`,
+datasets/PoseTransfer_Dataset.py) or from the synthetic generator (`--synthetic 1`, default: no data set ships with
+the repo; utils/synth.py).
 
 Single GPU:   python pose-transfer_amd/main.py --dataset fasion --pose_dim 18 --batch_size 4 --steps 20
 Multi GPU:    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 pose-transfer_amd/main.py ...
@@ -16,47 +21,85 @@ if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import pta_bootstrap
     pta_bootstrap.load()
-    from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
-    from pose_transfer_amd.opts import opts
-    from pose_transfer_amd.runtime import dp
-    from pose_transfer_amd.utils import synth
-else:
-    from .models.pose_gan import DeformablePose_GAN
-    from .opts import opts
-    from .runtime import dp
-    from .utils import synth
+from pose_transfer_amd.models.pose_gan import DeformablePose_GAN  # noqa: E402
+from pose_transfer_amd.opts import opts  # noqa: E402
+from pose_transfer_amd.runtime import dp  # noqa: E402
+from pose_transfer_amd.utils import synth  # noqa: E402
 
 
-def synthetic_batch(opt, it, tag, device):
-    inp, tgt, wr, mk = synth.batch(opt.seed + dp.rank(), "it%d/%s" % (it, tag), opt.batch_size, opt.pose_dim,
-                                   *opt.image_size)
-    f = lambda a: torch.from_numpy(a).to(device)
-    return f(inp), f(tgt), f(wr), f(mk)
+class SyntheticSource:
+    """Dataset-shaped batches from the counter-based generator: (input, target, warps, masks) or, for
+    gen_type=stacked, (input, target, interpol_pose, interpol_warps, interpol_masks) (reference Dataset.py:185-188)."""
+
+    def __init__(self, opt, device, split="train"):
+        self.opt, self.device, self.split, self.count = opt, device, split, 0
+
+    def next(self):
+        o = self.opt
+        tag = "%s/it%d" % (self.split, self.count)
+        self.count += 1
+        f = lambda a: torch.from_numpy(a).to(self.device)
+        H, W = o.image_size
+        if o.gen_type == "stacked":
+            S = o.num_stacks
+            inp, tgt, _, _ = synth.batch(o.seed + dp.rank(), tag, o.batch_size, o.pose_dim, H, W)
+            poses = np.concatenate([synth.heatmaps(o.seed + dp.rank(), "%s/ip%d" % (tag, s), o.batch_size, o.pose_dim, H, W)
+                                    for s in range(S)], axis=1)
+            wm = [synth.warps_and_masks(o.seed + dp.rank(), "%s/iw%d" % (tag, s), o.batch_size, H, W) for s in range(S)]
+            return (f(inp), f(tgt), f(poses), f(np.stack([w for w, _ in wm], 1)), f(np.stack([m for _, m in wm], 1)))
+        inp, tgt, wr, mk = synth.batch(o.seed + dp.rank(), tag, o.batch_size, o.pose_dim, H, W)
+        if o.warp_skip != "mask":
+            wr, mk = wr[:, :1], mk[:, :1]
+        return f(inp), f(tgt), f(wr), f(mk)
+
+
+def make_sources(opt, device):
+    if opt.synthetic:
+        return SyntheticSource(opt, device, "train"), SyntheticSource(opt, device, "test")
+    from pose_transfer_amd.datasets.PoseTransfer_Dataset import PoseTransfer_Dataset, BatchPipeline
+    train = BatchPipeline(PoseTransfer_Dataset(vars(opt), "train"), opt.batch_size, device, shuffle=True,
+                          seed=opt.seed + dp.rank(), workers=opt.num_workers, rank=dp.rank(), world=dp.world_size())
+    test = BatchPipeline(PoseTransfer_Dataset(vars(opt), "test"), opt.batch_size, device, shuffle=True,
+                         seed=opt.seed + 7919 + dp.rank(), workers=max(1, opt.num_workers // 2))
+    return train, test
+
+
+def other_inputs(opt, batch):
+    """reference main.py:81-86,104-108: what gen_update / dis_update receive besides input and target."""
+    if opt.gen_type == "stacked":
+        return {"interpol_pose": batch[2], "interpol_warps": batch[3].float(), "interpol_masks": batch[4]}
+    return {"warps": batch[2].float(), "masks": batch[3]}
+
+
+def build(opt, device):
+    from pose_transfer_amd.runtime import engine as _E
+    _E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[opt.precision]
+    return DeformablePose_GAN(opt, device=device)
 
 
 def main(argv=None):
     opt = opts().parse(argv)
-    from pose_transfer_amd.runtime import engine as _E
-    _E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[opt.precision]
     dp.init_from_env()
     device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(device)
-    model = DeformablePose_GAN(opt, device=device)
+    model = build(opt, device)
     start_epoch = model.resume(opt.checkpoints_dir) if opt.resume == 1 else 1
+    train, test = make_sources(opt, device)
     od = vars(opt)
     done = 0
+    model.iteration = (start_epoch - 1) * opt.iters_per_epoch      # dropout stream continues across a resume
     for epoch in range(start_epoch, opt.number_of_epochs + 1):
         gen_losses, disc_losses = [], []
         t0 = time.time()
         for it in range(opt.iters_per_epoch):
             for _ in range(opt.training_ratio):
-                a = synthetic_batch(opt, done, "A", device)
-                b = synthetic_batch(opt, done, "B", device)
-                disc_losses.append(model.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3]}, b[0], b[1], od))
-            c = synthetic_batch(opt, done, "C", device)
-            out, _, gl = model.gen_update(c[0], c[1], {"warps": c[2], "masks": c[3]}, od)
+                a, b = train.next(), train.next()
+                disc_losses.append(model.dis_update(a[0], a[1], other_inputs(opt, a), b[0], b[1], od))
+            c = train.next()
+            out, outputs, gl = model.gen_update(c[0], c[1], other_inputs(opt, c), od)
             gen_losses.append(gl)
             done += 1
+            model.iteration += 1
             if it % opt.display_ratio == 0 and dp.rank() == 0:
                 g = np.mean(np.array(gen_losses), axis=0)
                 d = np.mean(np.array(disc_losses), axis=0)
@@ -64,10 +107,19 @@ def main(argv=None):
                       "Disc Total {5:.3f} True {6:.3f} Fake {7:.3f} | {8:.2f} img/s".format(
                           epoch, it / opt.iters_per_epoch, g[0], g[1], g[2], d[0], d[1], d[2],
                           (it + 1) * opt.batch_size * dp.world_size() / max(time.time() - t0, 1e-9)), flush=True)
+                if getattr(opt, "save_samples", 0):
+                    # reference main.py:118-147: the current train batch and one test batch as image grids
+                    from pose_transfer_amd.test import save_grid
+                    save_grid(model, opt, c, out, outputs, os.path.join(opt.output_dir, "train", "%05d.png" % done))
+                    tb = test.next()
+                    save_grid(model, opt, tb, None, None, os.path.join(opt.output_dir, "test", "%05d.png" % done))
             if opt.steps and done >= opt.steps:
-                return
+                if getattr(opt, "save_at_end", 0) and dp.rank() == 0:
+                    model.save(opt.checkpoints_dir, epoch)
+                return model
         if epoch % opt.checkpoint_ratio == 0 and dp.rank() == 0:
             model.save(opt.checkpoints_dir, epoch)
+    return model
 
 
 if __name__ == "__main__":

@@ -57,33 +57,47 @@ class _ArenaModule(nn.Module):
 
 
 class _GenFn(torch.autograd.Function):
+    """autograd glue of the module-level API: the engine keeps the activations of ONE forward per (batch, stage), so
+    the output is saved with the node (a later forward at the same batch size overwrites `eng.out`)."""
+
     @staticmethod
-    def forward(ctx, inp, warps, masks, mod, anchor):
-        eng = mod.engine(inp.shape[0])
-        out = eng.forward(inp.contiguous(), warps, masks)
-        ctx.mod, ctx.n = mod, inp.shape[0]
-        return out.clone()
+    def forward(ctx, inp, warps, masks, mod, anchor, stage):
+        eng = mod.engine(inp.shape[0], stage)
+        out = eng.forward(inp.contiguous(), warps, masks).clone()
+        ctx.mod, ctx.n, ctx.stage = mod, inp.shape[0], stage
+        ctx.need_in = inp.requires_grad
+        ctx.save_for_backward(out)
+        return out
 
     @staticmethod
     def backward(ctx, gout):
-        eng = ctx.mod.engine(ctx.n)
+        (out,) = ctx.saved_tensors
+        eng = ctx.mod.engine(ctx.n, ctx.stage)
         g = gout.contiguous().clone()
-        L.call("pg_tanh_bwd", L.ptr(g), L.ptr(eng.out), g.numel(), L.stream())
-        eng.backward(g)
-        return None, None, None, None, None
+        L.call("pg_tanh_bwd", L.ptr(g), L.ptr(out), g.numel(), L.stream())
+        gin = None
+        if ctx.need_in:       # only the 3 image channels of `input` carry a gradient (the poses are data)
+            gin = torch.zeros(eng.N, 3 + 2 * eng.P, eng.H, eng.W, dtype=torch.float32, device=g.device)
+            gimg = torch.empty(eng.N, 3, eng.H, eng.W, dtype=torch.float32, device=g.device)
+            eng.backward(g, image_grad=gimg)
+            gin[:, :3] = gimg
+        else:
+            eng.backward(g)
+        return gin, None, None, None, None, None
 
 
 class Deformable_Generator(_ArenaModule):
-    """reference models/networks.py:252-288.  warp_skip='mask' (10 masked affine warps) is the hot path;
-    any other value than 'mask' is rejected ('full'/stacked are out of scope)."""
+    """reference models/networks.py:252-288.  warp_skip='mask' (10 masked limb warps) is the hot path; 'full' and
+    'none' build the SAME two-encoder network with ONE unmasked transform on levels 0-3, exactly as the reference does
+    (networks.py:257 compares against 'None' with a capital N, so num_skips is always 2; :283 picks 10 or 1 transforms)."""
 
     _init_tag = "gen"
 
     def __init__(self, input_nc, pose_dim, image_size, nfilters_enc, nfilters_dec, warp_skip="mask",
                  use_input_pose=True, align_corners=False, device="cuda"):
         super().__init__()
-        if warp_skip != "mask":
-            raise Exception("Invalid warp_skip for the MI355X build: only 'mask' is supported")
+        if warp_skip not in ("mask", "full", "none"):
+            raise Exception("Invalid warp_skip")
         if not use_input_pose:
             raise Exception("use_input_pose=False is not supported")
         assert input_nc == 3 + 2 * pose_dim
@@ -95,19 +109,74 @@ class Deformable_Generator(_ArenaModule):
         spec = synth.generator_spec(pose_dim, self.nfilters_enc, self.nfilters_dec)
         self._setup(spec, E.generator_param_order(spec, len(self.nfilters_enc), len(self.nfilters_dec)), device)
         self._anchor = nn.Parameter(torch.zeros(1, device=device))   # keeps autograd connected to the module
-        self.training_dropout = True
+        self.number_of_transforms = 10 if warp_skip == "mask" else 1
+        self.drop_seed = 0
 
-    def engine(self, n):
-        if n not in self._engines:
-            self._engines[n] = E.GeneratorEngine(self.arena, n, self.image_size[0], self.image_size[1], self.pose_dim,
-                                                 self.nfilters_enc, self.nfilters_dec, True, self.align_corners,
-                                                 self.device)
-        return self._engines[n]
+    def engine(self, n, stage=0):
+        """Engine (activation buffers + schedules) of one forward at batch n; `stage` separates the chained forwards
+        of the stacked generator, which must all stay alive until the backward pass."""
+        if (n, stage) not in self._engines:
+            self._engines[(n, stage)] = E.GeneratorEngine(
+                self.arena, n, self.image_size[0], self.image_size[1], self.pose_dim, self.nfilters_enc,
+                self.nfilters_dec, True, self.align_corners, self.device, n_warps=self.number_of_transforms,
+                masked=self.warp_skip == "mask")
+            self._engines[(n, stage)].drop_stream = "drop/s%d" % stage
+        return self._engines[(n, stage)]
 
-    def forward(self, input, warps, masks, drop_masks=None):
-        eng = self.engine(input.shape[0])
-        eng.set_dropout(drop_masks, train=self.training_dropout)
-        return _GenFn.apply(input, warps.float(), masks, self, self._anchor)
+    def forward(self, input, warps, masks=None, drop_masks=None, stage=0):
+        """Dropout2d follows nn.Module.train()/.eval() like the reference's blocks (networks.py:161); explicit
+        `drop_masks` (parity tests) override the device RNG."""
+        eng = self.engine(input.shape[0], stage)
+        eng.set_dropout(drop_masks, train=self.training, seed=self.drop_seed)
+        return _GenFn.apply(input, warps.float(), masks, self, self._anchor, stage)
+
+
+class Stacked_Generator(nn.Module):
+    """reference models/networks.py:290-327: ONE Deformable_Generator applied num_stacks times with shared weights;
+    stage i sees [previous output, pose_{i-1}, pose_i] (stage 0: [image, input pose, pose_0]).  state_dict keys carry
+    the reference's `generator.` prefix."""
+
+    def __init__(self, input_nc, num_stacks, image_size, pose_dim, nfilters_enc, nfilters_dec, warp_skip="mask",
+                 use_input_pose=True, align_corners=False, device="cuda"):
+        super().__init__()
+        self.input_nc, self.num_stacks, self.pose_dim, self.image_size = input_nc, num_stacks, pose_dim, tuple(image_size)
+        self.nfilters_enc, self.nfilters_dec, self.use_input_pose = tuple(nfilters_enc), tuple(nfilters_dec), use_input_pose
+        self.generator = Deformable_Generator(input_nc, pose_dim, image_size, nfilters_enc, nfilters_dec, warp_skip,
+                                              use_input_pose, align_corners, device)
+
+    @property
+    def arena(self):
+        return self.generator.arena
+
+    def zero_grad(self, set_to_none=False):
+        self.generator.zero_grad()
+
+    def state_dict(self, *a, **k):
+        return {"generator." + key: v for key, v in self.generator.state_dict().items()}
+
+    def load_state_dict(self, sd, strict=True):
+        """accepts the stacked model's own `generator.*` keys or a plain Deformable_Generator checkpoint (the reference
+        initialises the stack from `gen_090.pkl` of the single-stage model, pose_gan.py:30-32)."""
+        if any(k.startswith("generator.") for k in sd):
+            sd = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
+        self.generator.load_state_dict(sd, strict)
+
+    def stage_input(self, i, input, target_pose, prev_out):
+        """networks.py:313-323 — the torch.cat of each stage (a device copy into one NCHW tensor)."""
+        P = self.pose_dim
+        tp = target_pose[:, i * P:(i + 1) * P]
+        if i == 0:
+            return torch.cat([input[:, :3 + P], tp], dim=1)
+        return torch.cat([prev_out, target_pose[:, (i - 1) * P:i * P], tp], dim=1)
+
+    def forward(self, input, target_pose, target_warps, target_masks=None, drop_masks=None):
+        outputs, out = [], None
+        for i in range(self.num_stacks):
+            inp = self.stage_input(i, input, target_pose, out)
+            out = self.generator(inp, target_warps[:, i], None if target_masks is None else target_masks[:, i].contiguous(),
+                                 None if drop_masks is None else drop_masks[i], stage=i)
+            outputs.append(out)
+        return outputs
 
 
 class Generator(_ArenaModule):
@@ -125,19 +194,20 @@ class Generator(_ArenaModule):
         spec = synth.generator_spec(self.pose_dim, self.nfilters_enc, self.nfilters_dec, num_skips=1, deformable=False)
         self._setup(spec, E.generator_param_order(spec, len(self.nfilters_enc), len(self.nfilters_dec), False), device)
         self._anchor = nn.Parameter(torch.zeros(1, device=device))
-        self.training_dropout = True
         self.align_corners = False
+        self.drop_seed = 0
 
-    def engine(self, n):
-        if n not in self._engines:
-            self._engines[n] = E.GeneratorEngine(self.arena, n, self.image_size[0], self.image_size[1], self.pose_dim,
-                                                 self.nfilters_enc, self.nfilters_dec, False, False, self.device)
-        return self._engines[n]
+    def engine(self, n, stage=0):
+        if (n, stage) not in self._engines:
+            self._engines[(n, stage)] = E.GeneratorEngine(self.arena, n, self.image_size[0], self.image_size[1],
+                                                          self.pose_dim, self.nfilters_enc, self.nfilters_dec, False,
+                                                          False, self.device)
+        return self._engines[(n, stage)]
 
     def forward(self, input, drop_masks=None):
         eng = self.engine(input.shape[0])
-        eng.set_dropout(drop_masks, train=self.training_dropout)
-        return _GenFn.apply(input, None, None, self, self._anchor)
+        eng.set_dropout(drop_masks, train=self.training, seed=self.drop_seed)
+        return _GenFn.apply(input, None, None, self, self._anchor, 0)
 
 
 class _DiscFn(torch.autograd.Function):

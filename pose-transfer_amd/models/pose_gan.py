@@ -17,7 +17,7 @@ import torch.nn as nn
 from ..runtime import dp as DP
 from ..runtime import lib as L
 from ..utils import pose_utils, synth
-from .networks import Deformable_Generator, Discriminator, Generator, xavier_weights_init
+from .networks import Deformable_Generator, Discriminator, Generator, Stacked_Generator, xavier_weights_init
 
 
 class FusedAdam:
@@ -29,8 +29,8 @@ class FusedAdam:
     def zero_grad(self):
         self.module.arena.zero_grad()
 
-    def step(self, grad_scale=1.0):
-        self.module.arena.adam_step(self.lr, self.betas[0], self.betas[1], self.eps, grad_scale)
+    def step(self, grad_scale=1.0, grads_bf16=None):
+        self.module.arena.adam_step(self.lr, self.betas[0], self.betas[1], self.eps, grad_scale, grads_bf16)
 
     def state_dict(self):
         a = self.module.arena
@@ -49,23 +49,33 @@ class DeformablePose_GAN(nn.Module):
         self.pose_dim = opt.pose_dim
         self.image_size = tuple(opt.image_size)
         self.device = device
-        self.deformable = getattr(opt, "warp_skip", "mask") == "mask"
-        if opt.gen_type == "baseline":
-            if self.deformable:
-                self.gen = Deformable_Generator(input_nc, self.pose_dim, opt.image_size, nfilters_encoder,
-                                                nfilters_decoder, "mask", use_input_pose=True,
-                                                align_corners=bool(getattr(opt, "align_corners", 0)), device=device)
-            else:   # src_baseline Pose_GAN (reference src_baseline/models/pose_gan.py:10-52)
-                self.gen = Generator(input_nc, nfilters_encoder, nfilters_decoder, pose_dim=self.pose_dim,
-                                     image_size=opt.image_size, device=device)
-        elif opt.gen_type == "stacked":
-            raise Exception("gen_type=stacked is out of scope for the MI355X build (SURVEY.md §8f #4)")
+        self.num_stacks = getattr(opt, "num_stacks", 4)
+        self.gen_type = opt.gen_type
+        # src_baseline's single-encoder Generator (BASELINE.json configs[0]) is selected EXPLICITLY (`src_baseline`
+        # attribute / the Pose_GAN subclass), never through warp_skip: in src_deformable every warp_skip value builds
+        # the two-encoder Deformable_Generator (reference networks.py:253-288)
+        self.deformable = not getattr(opt, "src_baseline", False)
+        warp_skip = getattr(opt, "warp_skip", "mask")
+        self.warp_skip = warp_skip
+        align = bool(getattr(opt, "align_corners", 0))
+        if not self.deformable:
+            if opt.gen_type != "baseline":
+                raise Exception("Invalid gen_type")
+            self.gen = Generator(input_nc, nfilters_encoder, nfilters_decoder, pose_dim=self.pose_dim,
+                                 image_size=opt.image_size, device=device)
+        elif opt.gen_type == "baseline":
+            self.gen = Deformable_Generator(input_nc, self.pose_dim, opt.image_size, nfilters_encoder, nfilters_decoder,
+                                            warp_skip, use_input_pose=True, align_corners=align, device=device)
+        elif opt.gen_type == "stacked":     # reference pose_gan.py:28-33
+            self.gen = Stacked_Generator(input_nc, self.num_stacks, opt.image_size, self.pose_dim, nfilters_encoder,
+                                         nfilters_decoder, warp_skip, use_input_pose=True, align_corners=align,
+                                         device=device)
         else:
             raise Exception("Invalid gen_type")
         self.disc = Discriminator(input_nc + 3, use_input_pose=True, image_size=opt.image_size, device=device)
         # the reference loads a private pretrained discriminator unconditionally (pose_gan.py:40-42); here it is
         # optional and the default is the reference's own init recipe (networks.py:26-31)
-        xavier_weights_init(self.gen, init_seed)
+        xavier_weights_init(self._core, init_seed)
         xavier_weights_init(self.disc, init_seed + 1)
         pre = getattr(opt, "discriminator_checkpoint", None)
         if pre:
@@ -75,7 +85,7 @@ class DeformablePose_GAN(nn.Module):
             self.gen.load_state_dict(torch.load(pre, map_location="cpu"))
         lr = opt.learning_rate
         self.disc_opt = FusedAdam(self.disc, lr)
-        self.gen_opt = FusedAdam(self.gen, lr)
+        self.gen_opt = FusedAdam(self._core, lr)
         self.content_loss_layer = opt.content_loss_layer
         self.nn_loss_area_size = opt.nn_loss_area_size
         self.vgg_w = self.vgg_b = None
@@ -86,10 +96,19 @@ class DeformablePose_GAN(nn.Module):
         self.world = DP.world_size()
         # PG_FORCE_REDUCER=1 exercises the bucketed all-reduce path even at world size 1 (single-GPU test of the DP code)
         use_red = self.world > 1 or (os.environ.get("PG_FORCE_REDUCER") == "1" and DP.dist.is_initialized())
-        self.g_reducer = DP.GradReducer(self.gen.arena, max(self.world, 2) if use_red else 1) if use_red else None
+        self.g_reducer = DP.GradReducer(self._core.arena, max(self.world, 2) if use_red else 1) if use_red else None
         self.d_reducer = DP.GradReducer(self.disc.arena, max(self.world, 2) if use_red else 1) if use_red else None
         self._loss = torch.zeros(8, dtype=torch.float32, device=device)
         self._bufs = {}
+        # dropout RNG stream = f(opt.seed, rank, global iteration): a resumed run continues the sequence instead of
+        # replaying it (main.py sets `iteration`); engines of different batch sizes / stages use different streams
+        self.seed = int(getattr(opt, "seed", 0))
+        self.iteration = 0
+
+    @property
+    def _core(self):
+        """the module that owns the generator's parameter arena"""
+        return self.gen.generator if self.gen_type == "stacked" else self.gen
 
     # ------------------------------------------------------------------------------------------
     def set_vgg_weights(self, w, b):
@@ -102,12 +121,31 @@ class DeformablePose_GAN(nn.Module):
             self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.device)
         return self._bufs[key]
 
-    def _gen_forward(self, input, other_inputs, drop_masks):
-        eng = self.gen.engine(input.shape[0])
-        eng.set_dropout(drop_masks, train=True, seed=int(os.environ.get("RANK", "0")))
+    def _drop_setup(self, eng, drop_masks, stage, call):
+        eng.drop_stream = "drop/r%d/i%d/%s/s%d" % (DP.rank(), self.iteration, call, stage)
+        eng._drop_counter = 0
+        eng.set_dropout(drop_masks, train=True, seed=self.seed)
+
+    def _gen_forward(self, input, other_inputs, drop_masks, call="g"):
+        """One generator forward (the chained stages of the stacked generator).  Returns ([engines], out_gen)."""
+        other_inputs = other_inputs or {}
+        if self.gen_type == "stacked":       # reference pose_gan.py:72-77
+            tp, wr = other_inputs["interpol_pose"], other_inputs["interpol_warps"].float()
+            mk = other_inputs.get("interpol_masks") if self.warp_skip == "mask" else None
+            engs, out = [], None
+            for i in range(self.num_stacks):
+                eng = self._core.engine(input.shape[0], i)
+                self._drop_setup(eng, None if drop_masks is None else drop_masks[i], i, call)
+                x = self.gen.stage_input(i, input, tp, out)
+                out = eng.forward(x, wr[:, i], None if mk is None else mk[:, i].contiguous())
+                engs.append(eng)
+            return engs, out
+        eng = self._core.engine(input.shape[0])
+        self._drop_setup(eng, drop_masks, 0, call)
         if self.deformable:
-            return eng, eng.forward(input, other_inputs["warps"], other_inputs["masks"])
-        return eng, eng.forward(input)
+            return [eng], eng.forward(input, other_inputs["warps"].float(),
+                                      other_inputs.get("masks") if self.warp_skip == "mask" else None)
+        return [eng], eng.forward(input)
 
     def _losses(self, lo, lazy):
         if lazy:
@@ -121,7 +159,7 @@ class DeformablePose_GAN(nn.Module):
         input, target = input.contiguous(), target.contiguous()
         self.gen.zero_grad()
         self._loss[0:3].zero_()
-        eng, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
+        engs, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
         # discriminator on [img, src_pose, out_gen, tgt_pose] — forward + data-gradient only
         deng = self.disc.engine(n)
         logits = deng.forward([(input, out_gen)])
@@ -148,16 +186,28 @@ class DeformablePose_GAN(nn.Module):
         L.call("pg_tanh_bwd", L.ptr(gout), L.ptr(out_gen), gout.numel(), L.stream())
         if self.g_reducer is not None:
             self.g_reducer.begin()
-            eng.grad_ready_cb = self.g_reducer.mark_ready
-        eng.backward(gout)
-        scale = 1.0
+        # stacked: back through the chained stages; stage i's image input is stage i-1's output (networks.py:320).  The
+        # shared weights' gradients accumulate in the arena; only the LAST backward (stage 0) reports them ready.
+        for i in range(len(engs) - 1, -1, -1):
+            eng = engs[i]
+            eng.grad_ready_cb = self.g_reducer.mark_ready if (self.g_reducer is not None and i == 0) else None
+            if i > 0:
+                gprev = self._buf("gprev%d" % (i & 1), gout.shape)
+                eng.backward(gout, image_grad=gprev)
+                L.call("pg_tanh_bwd", L.ptr(gprev), L.ptr(engs[i - 1].out), gprev.numel(), L.stream())
+                gout = gprev
+            else:
+                eng.backward(gout)
+        scale, gb = 1.0, None
         if self.g_reducer is not None:
             self.g_reducer.finish()
-            scale = 1.0 / self.world
-        self.gen_opt.step(grad_scale=scale)
+            scale, gb = 1.0 / self.world, self.g_reducer.grad_source()[1]
+        self.gen_opt.step(grad_scale=scale, grads_bf16=gb)
         self._loss[0:1].copy_(self._loss[1:2] + self._loss[2:3])      # total = ll + ad  (pose_gan.py:109)
         losses = self._losses(0, opt.get("lazy_losses", False))
-        return out_gen, [], losses
+        # a fresh tensor like the reference's (the engine's output buffer is overwritten by the next forward)
+        outputs = [e.out.clone() for e in engs] if self.gen_type == "stacked" else []
+        return (outputs[-1] if outputs else out_gen.clone()), outputs, losses
 
     def dis_update(self, input, target, other_inputs, real_inp, real_target, opt):
         """reference pose_gan.py:117-171 (out_gen detached: SURVEY App. A.7 (i))."""
@@ -165,7 +215,7 @@ class DeformablePose_GAN(nn.Module):
         input, real_inp, real_target = input.contiguous(), real_inp.contiguous(), real_target.contiguous()
         self.disc.zero_grad()
         self._loss[4:7].zero_()
-        eng, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
+        engs, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"), call="d")
         deng = self.disc.engine(2 * n)
         logits = deng.forward([(real_inp, real_target), (input, out_gen)])     # cat((real, fake), 0) — pose_gan.py:136
         K = logits.shape[1]
@@ -178,11 +228,11 @@ class DeformablePose_GAN(nn.Module):
             self.d_reducer.begin()
             deng.grad_ready_cb = self.d_reducer.mark_ready
         deng.backward(dlog, need_wgrad=True)
-        scale = 1.0
+        scale, gb = 1.0, None
         if self.d_reducer is not None:
             self.d_reducer.finish()
-            scale = 1.0 / self.world
-        self.disc_opt.step(grad_scale=scale)
+            scale, gb = 1.0 / self.world, self.d_reducer.grad_source()[1]
+        self.disc_opt.step(grad_scale=scale, grads_bf16=gb)
         self._loss[4:5].copy_(self._loss[5:6] + self._loss[6:7])
         return self._losses(4, opt.get("lazy_losses", False))
 
@@ -203,7 +253,7 @@ class DeformablePose_GAN(nn.Module):
         return loss[0]
 
     def resume(self, save_dir):
-        """reference pose_gan.py:201-214."""
+        """reference pose_gan.py:201-214 (same file names, same return value = epoch of the last checkpoint)."""
         last = pose_utils.get_model_list(save_dir, "gen")
         if last is None:
             return 1
@@ -221,6 +271,17 @@ class DeformablePose_GAN(nn.Module):
         os.makedirs(save_dir, exist_ok=True)
         torch.save({k: v.cpu() for k, v in self.gen.state_dict().items()}, os.path.join(save_dir, "gen_{0:03d}.pkl".format(epoch)))
         torch.save({k: v.cpu() for k, v in self.disc.state_dict().items()}, os.path.join(save_dir, "disc_{0:03d}.pkl".format(epoch)))
+
+
+class Pose_GAN(DeformablePose_GAN):
+    """src_baseline trainer (reference src_baseline/models/pose_gan.py:10-142; BASELINE.json configs[0]): single-encoder
+    Generator, no warps, L1 loss; same update methods."""
+
+    def __init__(self, opt, device="cuda", init_seed=0):
+        import copy
+        opt = copy.copy(opt)
+        opt.src_baseline = True
+        super().__init__(opt, device=device, init_seed=init_seed)
 
 
 def _default_vgg_conv1(path=None):

@@ -11,7 +11,7 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.environ.get("PG_LIB") or os.path.join(LIBDIR, "libposegan_hip.so")
-SOURCES = ["api.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "edge.hip", "small_cin_wgrad.hip", "out_conv_dgrad.hip", "igemm_conv.hip", "igemm_wgrad.hip"]
+SOURCES = ["api.hip", "comm.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "pose_geom.hip", "edge.hip", "small_cin_wgrad.hip", "out_conv_dgrad.hip", "igemm_conv.hip", "igemm_wgrad.hip"]
 # -pragma-unroll-threshold: the epilogue loops over a wave's MFMA tiles MUST be fully unrolled (a rolled loop indexes the
 # accumulator array at run time and the compiler moves it to scratch memory); the 4x2-tile bf16 kernel exceeds the default
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1000000",
@@ -58,7 +58,7 @@ def build_lib(force=False, verbose=True):
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])

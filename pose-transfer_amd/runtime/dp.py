@@ -1,19 +1,29 @@
-"""Data parallelism: one process per GPU, gradients averaged with all-reduce (RCCL over xGMI; `nccl` backend
-IS RCCL on ROCm).  New in this build — the reference is single-process.
+"""Data parallelism: one process per GPU, gradients averaged with all-reduce over RCCL / xGMI.
+New in this build — the reference is single-process.
 
 Contract: every loss term is a per-sample mean and the norm is per-sample, so the AVERAGE over ranks
 of gradients computed on equal local shards equals the single-process gradient at the global batch.
 
 Overlap: parameters are laid out in the arena in backward-completion order, so "gradient ready" is a monotonically
-advancing offset.  As soon as a bucket worth of gradients is complete its all-reduce is issued with async_op=True:
-the collective waits (on the device) for the kernels enqueued so far and then runs concurrently with the rest of
-the backward pass.  The 1/world scaling is folded into the fused Adam kernel (grad_scale).
-xGMI is point-to-point (7 links x ~153 GB/s): a few large buckets keep every link busy with few launches.
+advancing offset.  As soon as a bucket worth of gradients is complete its all-reduce is enqueued on a COMMUNICATION
+stream that waits — through HIP events recorded at that moment — for exactly the work that produced the bucket: the main
+stream (data-gradient chain) and the weight-gradient side stream.  Neither of them waits for the collective; only the
+optimiser step at the end of the pass does (`finish()`).  The 1/world scaling is folded into the fused Adam kernel
+(grad_scale).  xGMI is point-to-point (7 links x ~153 GB/s): a few large buckets keep every link busy with few launches.
+
+Transport: on the device the collective is RCCL behind the C ABI (`pg_comm_*`, include/posegan_hip.h; the rendezvous
+token travels over the torch.distributed store that torch.distributed.run already set up).  `PG_DP_BACKEND=torch` or a
+CPU arena (the gloo tests) use `torch.distributed.all_reduce` instead.
+Gradient format: fp32 buckets by default; `PG_DP_GRAD_DTYPE=bf16` (default on the bf16 data path) packs each finished
+range to bf16 (pg_pack_bf16), reduces half the bytes and lets Adam read the bf16 sums (pg_adam_ex).
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
+
+from . import lib as L
 
 
 def world_size():
@@ -47,14 +57,56 @@ def shard(t, r=None, w=None):
     return t[r * (n // w):(r + 1) * (n // w)]
 
 
+_COMM = {}      # device index -> pg_comm handle (one communicator per process)
+
+
+def rccl_comm(device):
+    """The process's RCCL communicator behind the C ABI (created on first use; rendezvous over torch.distributed)."""
+    idx = torch.device(device).index or 0
+    if idx in _COMM:
+        return _COMM[idx]
+    lib = L.load()
+    w, r = world_size(), rank()
+    token = [None]
+    if r == 0:
+        buf = ctypes.create_string_buffer(128)
+        L.check(lib.pg_comm_unique_id(buf), "pg_comm_unique_id")
+        token[0] = bytes(buf.raw)
+    if w > 1:
+        dist.broadcast_object_list(token, src=0)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(idx):
+        L.check(lib.pg_comm_init(ctypes.c_char_p(token[0]), r, w, ctypes.byref(handle)), "pg_comm_init")
+    _COMM[idx] = handle
+    return handle
+
+
+def destroy_comms():
+    for h in _COMM.values():
+        L.load().pg_comm_destroy(h)
+    _COMM.clear()
+
+
 class GradReducer:
     """Bucketed SUM all-reduce of a flat gradient arena, issued as buckets complete during backward."""
 
-    def __init__(self, arena, world, bucket_bytes=64 << 20, group=None):
+    def __init__(self, arena, world, bucket_bytes=64 << 20, group=None, backend=None, grad_dtype=None):
         self.arena, self.world, self.group = arena, world, group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.keys = list(arena.keys)
         self.index = {k: i for i, k in enumerate(self.keys)}
+        self.on_device = arena.grads.is_cuda
+        if backend is None:
+            backend = os.environ.get("PG_DP_BACKEND", "rccl" if self.on_device else "torch")
+        self.backend = backend if self.on_device else "torch"
+        self.grad_dtype = grad_dtype or os.environ.get("PG_DP_GRAD_DTYPE", "f32")
+        assert self.grad_dtype in ("f32", "bf16")
+        self.bf16 = self.grad_dtype == "bf16" and self.on_device
+        self.packed = torch.empty(arena.total, dtype=torch.bfloat16, device=arena.grads.device) if self.bf16 else None
+        self.comm_stream = torch.cuda.Stream(device=arena.grads.device) if self.on_device else None
+        self.comm = rccl_comm(arena.grads.device) if (self.backend == "rccl" and world > 1 or
+                                                      (self.backend == "rccl" and os.environ.get("PG_FORCE_REDUCER") == "1")) else None
+        self.launch_count = 0
         self.begin()
 
     def begin(self):
@@ -62,6 +114,7 @@ class GradReducer:
         self.next_key = 0        # first key not yet known complete
         self.launched = 0        # arena offset up to which all-reduces were issued
         self.works = []
+        self.launch_count = 0
 
     def _end_offset(self, i):
         return self.arena.off[self.keys[i]] if i < len(self.keys) else self.arena.total
@@ -75,17 +128,54 @@ class GradReducer:
         if upto - self.launched >= self.bucket_elems:
             self._launch(upto)
 
+    def _wait_producers(self):
+        """The communication stream waits for the work enqueued SO FAR on the main stream and on the weight-gradient
+        side stream (events recorded now); the producers themselves do not wait for anything."""
+        from . import engine as E
+        dev = self.arena.grads.device
+        cs = self.comm_stream
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        cs.wait_event(ev)
+        side = E._SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        if E.SIDE_STREAM and side is not None:
+            ev2 = torch.cuda.Event()
+            ev2.record(side)
+            cs.wait_event(ev2)
+
     def _launch(self, upto):
         if upto <= self.launched:
             return
-        buf = self.arena.grads[self.launched:upto]
-        if self.world > 1:
-            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        lo, n = self.launched, upto - self.launched
         self.launched = upto
+        self.launch_count += 1
+        if not self.on_device:                      # CPU arenas (gloo tests)
+            if self.world > 1:
+                self.works.append(dist.all_reduce(self.arena.grads[lo:upto], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        self._wait_producers()
+        buf = self.arena.grads[lo:upto]
+        with torch.cuda.stream(self.comm_stream):
+            if self.bf16:
+                pk = self.packed[lo:upto]
+                L.call("pg_pack_bf16", L.ptr(buf), L.ptr(pk), n, L.stream())     # arena offsets are multiples of 64 elements
+                buf = pk
+            if self.comm is not None:
+                L.check(L.load().pg_comm_allreduce_bucket(self.comm, L.ptr(buf), n, 1 if self.bf16 else 0, L.stream()),
+                        "pg_comm_allreduce_bucket")
+            elif self.world > 1:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)      # enqueued on the current (= comm) stream
 
     def finish(self):
-        """Issue whatever is left (keys never reported count as ready: e.g. unused parameters) and wait."""
+        """Issue whatever is left (keys never reported count as ready: e.g. unused parameters) and make the optimiser's
+        stream wait for the collectives."""
         self._launch(self.arena.total)
         for w in self.works:
             w.wait()
         self.works = []
+        if self.on_device:
+            torch.cuda.current_stream(self.arena.grads.device).wait_stream(self.comm_stream)
+
+    def grad_source(self):
+        """(fp32 grads, bf16 grads or None): what the optimiser step reads after finish()."""
+        return self.arena.grads, self.packed

@@ -126,6 +126,9 @@ class ParamArena:
         self.m = torch.zeros(o, dtype=torch.float32, device=device)
         self.v = torch.zeros(o, dtype=torch.float32, device=device)
         self.step = 0
+        self.params_bf16 = None       # bf16 data path: bf16 copy of the whole arena, kept current by Adam / load_state_dict
+        self.bf16_version = -1
+        ARENAS[self.params.untyped_storage().data_ptr()] = self
 
     def p(self, key):
         return self.params[self.off[key]:self.off[key] + self.numel[key]].view(self.pshape[key])
@@ -136,6 +139,19 @@ class ParamArena:
     def _bump_version(self):
         key = self.params.untyped_storage().data_ptr()
         WEIGHT_VERSION[key] = WEIGHT_VERSION.get(key, 0) + 1
+
+    def version(self):
+        return WEIGHT_VERSION.get(self.params.untyped_storage().data_ptr(), 0)
+
+    def bf16_params(self):
+        """bf16 copy of the arena in the same packed layout ([tap][Cout][Cin] = the K-contiguous forward operand).
+        Written by the Adam launch itself (pg_adam_ex); converted here only after load_state_dict / the first use."""
+        if self.params_bf16 is None:
+            self.params_bf16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.params.device)
+        if self.bf16_version != self.version():
+            L.call("pg_pack_bf16", L.ptr(self.params), L.ptr(self.params_bf16), self.total, L.stream())
+            self.bf16_version = self.version()
+        return self.params_bf16
 
     def load_state_dict(self, sd):
         self._bump_version()
@@ -161,14 +177,25 @@ class ParamArena:
     def zero_grad(self):
         self.grads.zero_()
 
-    def adam_step(self, lr, b1=0.5, b2=0.999, eps=1e-8, grad_scale=1.0):
-        """torch.optim.Adam semantics (reference models/pose_gan.py:50-51); bias corrections in double."""
+    def adam_step(self, lr, b1=0.5, b2=0.999, eps=1e-8, grad_scale=1.0, grads_bf16=None):
+        """torch.optim.Adam semantics (reference models/pose_gan.py:50-51); bias corrections in double.
+        grads_bf16: read the (all-reduced) bf16 gradient sums instead of the fp32 arena (runtime/dp.py bf16 buckets)."""
         self.step += 1
         self._bump_version()
         bc1 = 1.0 - b1 ** self.step
         bc2 = 1.0 - b2 ** self.step
-        L.call("pg_adam", L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.total,
-               b1, b2, eps, lr / bc1, math.sqrt(bc2), grad_scale, L.stream())
+        want_bf16 = PRECISION == 3 and self.params.is_cuda
+        if grads_bf16 is None and not want_bf16:
+            L.call("pg_adam", L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.total,
+                   b1, b2, eps, lr / bc1, math.sqrt(bc2), grad_scale, L.stream())
+            return
+        if want_bf16 and self.params_bf16 is None:
+            self.params_bf16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.params.device)
+        L.call("pg_adam_ex", L.ptr(self.params), L.ptr(self.grads), L.ptr(grads_bf16), L.ptr(self.m), L.ptr(self.v),
+               self.total, b1, b2, eps, lr / bc1, math.sqrt(bc2), grad_scale, L.ptr(self.params_bf16) if want_bf16 else None,
+               L.stream())
+        if want_bf16:
+            self.bf16_version = self.version()
 
 
 # ------------------------------------------------------------------------------------------ activation handle
@@ -199,6 +226,7 @@ class Act:
 # converted per optimiser step, and the contraction DMAs bf16 tiles straight into LDS (fp32 accumulate / outputs).
 PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[os.environ.get("PG_PRECISION", "f32")]
 
+ARENAS = {}                 # parameter-arena storage pointer -> ParamArena
 WEIGHT_VERSION = {}         # parameter-arena storage -> version, bumped whenever its parameters change (optimiser step,
                             # load_state_dict): the bf16 weight copies of THAT arena go stale
 _BF_SRC = {}                # device -> list of bf16 scratch buffers, one per source slot (stream-ordered reuse)
@@ -206,6 +234,11 @@ _BF_W = {}                  # (data_ptr, numel) -> [version, nt, t]
 
 
 def _bf16_weight(W, taps, Cout, Cin, transposed):
+    arena = ARENAS.get(W.untyped_storage().data_ptr())
+    if arena is not None and not transposed:
+        # K-contiguous forward operand = the packed arena layout: a view of the arena's bf16 copy (written by pg_adam_ex)
+        off = (W.data_ptr() - arena.params.data_ptr()) // 4
+        return arena.bf16_params()[off:off + W.numel()]
     key = (W.data_ptr(), W.numel())
     ver = WEIGHT_VERSION.get(W.untyped_storage().data_ptr(), 0)
     ent = _BF_W.get(key)
@@ -534,8 +567,11 @@ class GeneratorEngine:
     (src_baseline/models/networks.py:238-253) forward + backward for a fixed (N,H,W)."""
 
     def __init__(self, arena, N, H, W, pose_dim, nfilters_enc, nfilters_dec, deformable=True, align_corners=False,
-                 device="cuda"):
+                 device="cuda", n_warps=T_WARPS, masked=True):
+        # n_warps / masked: warp_skip='mask' -> 10 masked limb transforms; 'full' / 'none' -> ONE unmasked transform
+        # (reference networks.py:283: AffineTransformLayer(10 if warp_skip == 'mask' else 1, ...))
         self.A, self.N, self.H, self.W, self.P = arena, N, H, W, pose_dim
+        self.T, self.masked = (n_warps, masked) if deformable else (0, False)
         self.enc, self.dec = tuple(nfilters_enc), tuple(nfilters_dec)
         self.nlev, self.ndec = len(self.enc), len(self.dec)
         self.deformable, self.align = deformable, 1 if align_corners else 0
@@ -556,7 +592,8 @@ class GeneratorEngine:
         self.w_out = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nwarp)]
         self.w_g = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nwarp)]
         self.w_arg = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], dtype=torch.uint8, device=device) for l in range(self.nwarp)]
-        self.lvl_masks = [torch.empty(N, hw[l][0], hw[l][1], T_WARPS, **f32) for l in range(self.nwarp)]
+        self.lvl_masks = [(torch.empty if self.masked else torch.ones)(N, hw[l][0], hw[l][1], self.T, **f32)
+                          for l in range(self.nwarp)]
         # decoder up-block outputs: block i lives at level nlev-2-i
         self.d_raw, self.d_dz, self.d_norm = [], [], []
         for i in range(self.ndec - 1):
@@ -571,15 +608,17 @@ class GeneratorEngine:
         self.y_taps = torch.empty(N, H, W, 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
         self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh): weight- and data-gradient operand
         self.wt_out = torch.zeros((2 if deformable else 1) * self.enc[0] + self.dec[-2], 32, **f32)   # [cin][(tap, co)]
-        self.warps = torch.empty(N, T_WARPS, 8, **f32)
+        self.warps = torch.empty(N, max(self.T, 1), 8, **f32)
         self.input = None
         self._drop_counter = 0
+        self.drop_stream = "drop"      # mixed into the dropout key (the trainer sets seed / rank / global iteration)
         self.grad_ready_cb = None      # DP hook: called with the parameter keys whose gradients are complete
 
     # -------------------------------------------------------------------------------- helpers
     def _ready(self, *prefixes):
+        # the reducer orders its collective against BOTH producer streams with events (runtime/dp.py: _wait_producers);
+        # the main stream keeps running the data-gradient chain, the side stream the weight gradients
         if self.grad_ready_cb is not None:
-            _join_side()          # the reducer's all-reduce orders against the MAIN stream only
             self.grad_ready_cb([k for k in self.A.keys if k.startswith(prefixes)])
 
     def _enc_in_src(self, e, inp):
@@ -624,7 +663,7 @@ class GeneratorEngine:
         elif train:
             for i, d in enumerate(self.drop):
                 self._drop_counter += 1
-                key = int(synth._stream_key(seed, "drop/%d/%d" % (self._drop_counter, i)))
+                key = int(synth._stream_key(seed, "%s/N%d/%d/%d" % (self.drop_stream, self.N, self._drop_counter, i)))
                 L.call("pg_dropout_mask", L.ptr(d), d.numel(), key, 0.5, L.stream())
 
     def forward(self, inp, warps=None, masks=None):
@@ -636,11 +675,15 @@ class GeneratorEngine:
         if not hasattr(self, "use_drop"):
             self.set_dropout(None, train=True)
         if self.deformable:
-            self.warps.copy_(warps.reshape(N, T_WARPS, 8))
-            assert masks.is_contiguous()
-            for l in range(self.nwarp):
-                L.call("pg_mask_pyramid", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T_WARPS, H, W,
-                       self.hw[l][0], self.hw[l][1], L.ptr(self.lvl_masks[l]), L.stream())
+            T = self.T
+            # (N,T,8) as the reference Dataset emits it; estimate_uniform_transform may hand over 9 values per row
+            # (pose_transform.py:322) — only the first six are ever read (pose_transform.py:28)
+            self.warps.copy_(warps.reshape(N, T, -1)[:, :, :8])
+            if self.masked:
+                assert masks.is_contiguous() and tuple(masks.shape) == (N, T, H, W)
+                for l in range(self.nwarp):
+                    L.call("pg_mask_pyramid", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W,
+                           self.hw[l][0], self.hw[l][1], L.ptr(self.lvl_masks[l]), L.stream())
         # ---- encoders (reference networks.py:193-202)
         for e in self.encs:
             s0 = self._enc_in_src(e, inp)
@@ -665,7 +708,7 @@ class GeneratorEngine:
         for l in range(self.nwarp):
             a = self._enc_act("encoder_app", l)
             L.call("pg_warp_mask_max_fwd", L.ptr(a.t), L.ptr(a.aff), L.ptr(self.warps), L.ptr(self.lvl_masks[l]), N,
-                   T_WARPS, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.w_out[l]),
+                   self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.w_out[l]),
                    L.ptr(self.w_arg[l]), L.stream())
         # ---- decoder (reference networks.py:236-250)
         for i in range(self.ndec - 1):
@@ -704,14 +747,16 @@ class GeneratorEngine:
                                        accumulate=not first_write))
         return dsts
 
-    def backward(self, dpre):
+    def backward(self, dpre, image_grad=None):
         try:
-            return self._backward(dpre)
+            return self._backward(dpre, image_grad)
         finally:
             _join_side()
 
-    def _backward(self, dpre):
-        """dpre: gradient wrt the pre-tanh output, NCHW (N,3,H,W), contiguous.  Accumulates into arena.grads."""
+    def _backward(self, dpre, image_grad=None):
+        """dpre: gradient wrt the pre-tanh output, NCHW (N,3,H,W), contiguous.  Accumulates into arena.grads.
+        image_grad: optional NCHW (N,3,H,W) buffer receiving d/d(input[:, :3]) — the stacked generator chains stage i's
+        image input to stage i-1's output (reference networks.py:320)."""
         A, N, H, W = self.A, self.N, self.H, self.W
         assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
         ystr = (3 * H * W, H * W, W, 1)
@@ -758,7 +803,7 @@ class GeneratorEngine:
         # ---- deformable skips
         for l in range(self.nwarp):
             L.call("pg_warp_mask_max_bwd", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
-                   L.ptr(self.lvl_masks[l]), N, T_WARPS, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align,
+                   L.ptr(self.lvl_masks[l]), N, self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align,
                    L.ptr(self.e_dz["encoder_app"][l]), L.stream())
         # ---- encoders
         for l in range(self.nlev - 1, 0, -1):
@@ -787,6 +832,12 @@ class GeneratorEngine:
             _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
                    A.g(e + ".net.0.weight"), scalar_x=True)
             self._ready(e + ".net.0.")
+            if image_grad is not None and e in ("encoder_app", "encoder"):
+                # data-gradient of the k3/s1/p1 first convolution restricted to its 3 image channels, written NCHW
+                assert image_grad.is_contiguous() and tuple(image_grad.shape) == (N, 3, H, W)
+                _conv([Act(dz, self.enc[0]).src()], N, H, W, L.ACT_NONE, 1, 3, 1, 1, H, W, A.p(e + ".net.0.weight"),
+                      self.enc[0], s0.C, transposed=True, out=image_grad, out_strides=(3 * H * W, H * W, W, 1),
+                      n_off=0, n_cnt=3)
 
 
 # ------------------------------------------------------------------------------------------ discriminator
@@ -827,8 +878,9 @@ class DiscriminatorEngine:
         self.grad_ready_cb = None
 
     def _ready(self, *prefixes):
+        # the reducer orders its collective against BOTH producer streams with events (runtime/dp.py: _wait_producers);
+        # the main stream keeps running the data-gradient chain, the side stream the weight gradients
         if self.grad_ready_cb is not None:
-            _join_side()          # the reducer's all-reduce orders against the MAIN stream only
             self.grad_ready_cb([k for k in self.A.keys if k.startswith(prefixes)])
 
     def _stem_srcs(self, pair):

@@ -71,6 +71,10 @@ _PROTOS = {
     "pg_small_cin_wgrad": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
     "pg_bias_grad": [_vp, _i64, _i64, _i32, _i64, _i64, _i64, _vp, _vp],
     "pg_cords_to_map": [_vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _i64, _i64, _i64, _i64, _vp],
+    "pg_affine_transforms": [_vp, _vp, _i32, _i32, _vp, _vp],
+    "pg_uniform_transform": [_vp, _vp, _i32, _i32, _vp, _vp],
+    "pg_pose_masks": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pg_preprocess_image": [_vp, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
     "pg_materialise_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
     "pg_weights_to_bf16": [_vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "pg_channel_major_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp],
@@ -89,6 +93,12 @@ _PROTOS = {
     "pg_vgg_conv1_dgrad": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pg_nn_loss": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp],
     "pg_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
+    "pg_adam_ex": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
+    "pg_comm_unique_id": [_vp],
+    "pg_comm_init": [_vp, _i32, _i32, C.POINTER(_vp)],
+    "pg_comm_allreduce_bucket": [_vp, _vp, _i64, _i32, _vp],
+    "pg_comm_destroy": [_vp],
+    "pg_pack_bf16": [_vp, _vp, _i64, _vp],
     "pg_dropout_mask": [_vp, _i64, _u64, _f32, _vp],
     "pg_nchw_to_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "pg_nhwc_to_nchw": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -39,7 +39,7 @@ def test_generator_forward_vs_golden(name, size, mode):
     gen.load_state_dict(tp(synth.init_params(21, name, synth.generator_spec(P, enc, dec), norm_jitter=0.2)))
     inp, tgt, wr, mk = synth.batch(21, name, 2, P, *size)
     drops = [t(m).to(DEV) for m in synth.dropout_masks(21, name, 2)] if mode == "train" else None
-    gen.training_dropout = mode == "train"
+    gen.train(mode == "train")
     with torch.no_grad():
         out = gen(t(inp).to(DEV), t(wr).to(DEV), t(mk).double().to(DEV), drop_masks=drops)
     assert maxdiff(out, t(g["%s_%s_out" % (name, mode)])) < 1e-3
@@ -60,7 +60,7 @@ def test_generator_forward_operand_precision_modes(prec, tol_max, tol_mean, monk
     gen = Deformable_Generator(3 + 2 * P, P, size, enc, dec, "mask")
     gen.load_state_dict(tp(synth.init_params(21, name, synth.generator_spec(P, enc, dec), norm_jitter=0.2)))
     inp, tgt, wr, mk = synth.batch(21, name, 2, P, *size)
-    gen.training_dropout = False
+    gen.eval()
     with torch.no_grad():
         out = gen(t(inp).to(DEV), t(wr).to(DEV), t(mk).double().to(DEV), drop_masks=None)
     ref = t(g["%s_eval_out" % name])
@@ -139,30 +139,31 @@ def test_generator_edge_shapes_vs_oracle(tag, n, size, pdim):
     inp, tgt, wr, mk = [t(a) for a in synth.batch(29, tag, n, pdim, *size)]
     drops = [t(m) for m in synth.dropout_masks(29, tag, n)]
     go = t(synth.normal(29, tag + "/go", (n, 3) + tuple(size)))
-    pr = {k: v.clone().requires_grad_(True) for k, v in par.items()}
-    out_ref = R.generator_forward(inp, wr, mk, pr, pdim, enc, dec, size, drops)
-    gref = dict(zip(pr.keys(), torch.autograd.grad((out_ref * go).sum(), list(pr.values()))))
+    # the ORACLE runs in float64 here (three small shapes): its own fp32 rounding (up to 2.9e-2 of a tensor's max on
+    # single conv-weight elements, 0.11 on a scalar norm bias — measured in round 1) no longer sets the tolerance
+    pr = {k: v.double().requires_grad_(True) for k, v in par.items()}
+    out_ref = R.generator_forward(inp.double(), wr.double(), mk.double(), pr, pdim, enc, dec, size, [d.double() for d in drops])
+    gref = dict(zip(pr.keys(), torch.autograd.grad((out_ref * go.double()).sum(), list(pr.values()))))
     gen = Deformable_Generator(3 + 2 * pdim, pdim, size, enc, dec, "mask")
     gen.load_state_dict(par)
     gen.zero_grad()
     out = gen(inp.to(DEV), wr.to(DEV), mk.to(DEV), drop_masks=[d.to(DEV) for d in drops])
     (out * go.to(DEV)).sum().backward()
     assert out.shape == out_ref.shape and maxdiff(out, out_ref) < 1e-3
-    # Gradient tolerances here are set by the ORACLE's own fp32 noise, measured by running it in float64 on the
-    # p18/128x128 case: fp32-vs-fp64 differs by up to 2.9e-2 of the tensor max on sparse conv-weight elements
-    # (warp arg-max near-ties flip) and by up to 0.11 on a scalar norm bias (cancelling sum over the whole tensor);
-    # the HIP gradients show the same figures against the fp32 oracle (tools/dbg_edge.py).
+    # fp32 device gradients vs the float64 oracle: 2e-3 of the tensor max.  What remains above that is the warp layer's
+    # arg-max (a discontinuous function): a near-tie decided differently in fp32 re-routes one pixel's gradient, which
+    # shows on isolated conv-weight elements — bounded in count (< 0.5 % of a tensor) and size (< 6e-2 of its max).
     got = gen.arena.grad_dict()
     bad = []
     for k in gref:
         scale = max(float(gref[k].abs().max()), 1e-8)
-        d = (got[k].cpu() - gref[k]).abs()
+        d = (got[k].cpu().double() - gref[k]).abs()
         if k.endswith("weight") and gref[k].dim() == 4:
-            ok = float(d.max()) / scale < 6e-2 and float((d > 2e-3 * scale).float().mean()) < 5e-2   # oracle fp32-vs-fp64: up to 2.3e-2
+            ok = float(d.max()) / scale < 2e-3 or (float(d.max()) / scale < 6e-2 and float((d > 2e-3 * scale).float().mean()) < 5e-3)
         else:
-            ok = float(d.max()) / scale < 0.15
+            ok = float(d.max()) / scale < 2e-2      # scalar gamma / beta / biases: cancelling fp32 sums over a whole tensor
         if not ok:
-            bad.append((k, float(d.max()) / scale))
+            bad.append((k, float(d.max()) / scale, float((d > 2e-3 * scale).float().mean())))
     assert not bad, bad
 
 
@@ -279,6 +280,7 @@ def test_baseline_step_vs_golden():
     H, W, N = 128, 64, 2
     enc, dec = synth.nfilters((H, W))
     opt = _opt((H, W), warp_skip="none")
+    opt.src_baseline = True
     model = DeformablePose_GAN(opt, device=DEV)
     gspec = synth.generator_spec(P, enc, dec, num_skips=1, deformable=False)
     model.gen.load_state_dict(tp(synth.init_params(41, "base/gen", gspec, 0.1)))
