@@ -101,6 +101,82 @@ def cpu_baseline(args):
                       "(%d threads), %.1f s" % (size, size, n, cores, dt)}
 
 
+PEAK_HBM_TBS = 8.0                # HBM3E peak, same guide (6.3 TB/s is what a float4 copy achieves)
+
+
+def _ival(a):
+    return int(getattr(a, "value", a) or 0)
+
+
+# Algorithmic HBM bytes of the memory-bound kernels (the minimum a fused kernel has to move), as a function
+# of the C-ABI call's arguments (include/posegan_hip.h).  fp32 elements unless noted.
+HBM_MODELS = {
+    # feat read + out write + level masks (66.4 MB / image at 256^2)
+    "pg_warp_mask_max_fwd": lambda a: _ival(a[4]) * _ival(a[7]) * _ival(a[8]) * (8 * _ival(a[6]) + 4 * _ival(a[5])),
+    # read grad + arg-max / masks replay + read-modify-write of the input gradient (~130 MB / image = 16.5 B / element)
+    "pg_warp_mask_max_bwd": lambda a: int(_ival(a[4]) * _ival(a[7]) * _ival(a[8]) * _ival(a[6]) * 16.5),
+    "pg_norm_stats": lambda a: 4 * _ival(a[1]) * _ival(a[2]),
+    "pg_norm_bwd_reduce": lambda a: 8 * _ival(a[3]) * _ival(a[4]),                 # dz, y
+    "pg_norm_bwd_apply": lambda a: 12 * _ival(a[5]) * _ival(a[6]),                 # dz (read + write), y
+    "pg_adam": lambda a: 28 * _ival(a[4]),                                           # p, g, m, v read; p, m, v written
+    "pg_adam_ex": lambda a: 28 * _ival(a[5]),
+    "pg_nn_loss": lambda a: 12 * _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * _ival(a[5]),       # P, G read; dP written
+    "pg_vgg_conv1_relu_fwd": lambda a: _ival(a[3]) * _ival(a[4]) * _ival(a[5]) * (12 + 256),
+    "pg_vgg_conv1_dgrad": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (256 + 24),
+    "pg_small_cin_conv": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * 4 * sum(a[0][i].C for i in range(_ival(a[1])))
+                         + 256 * _ival(a[2]) * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
+                         * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
+    "pg_small_cin_wgrad": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * 4 * sum(a[0][i].C for i in range(_ival(a[1])))
+                          + 256 * _ival(a[2]) * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
+                          * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
+    # last conv (256 -> 3): tap tensor (27 -> 32 columns) + NCHW image; data-gradient: im2col'd gradient + fwd read / grad write
+    "pg_tap_gather": lambda a: _ival(a[1]) * _ival(a[2]) * _ival(a[3]) * (27 * 4 + 12),
+    "pg_out_conv_dgrad": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (128 + 8 * sum(a[5][i].C for i in range(_ival(a[6])))),
+    "pg_materialise_bf16": lambda a: 6 * _ival(a[4]) * _ival(a[5]) * _ival(a[6]),                 # fp32 in, bf16 out
+    "pg_channel_major_bf16": lambda a: 6 * _ival(a[4]) * _ival(a[5]) * _ival(a[6]) * _ival(a[7]) // max(1, _ival(a[8]) ** 2),
+    "pg_l1_loss": lambda a: 12 * _ival(a[2]),
+    "pg_tanh_bwd": lambda a: 12 * _ival(a[2]),
+}
+
+
+class HbmProfiler:
+    """HIP events (on the launch stream) around every call of a memory-bound entry point during ONE un-timed iteration."""
+
+    def __init__(self):
+        import ctypes
+        from pose_transfer_amd.runtime import lib as L
+        self.L, self.ct, self.rec = L, ctypes, []
+
+    def hook(self, name, args, launch):
+        model = HBM_MODELS.get(name)
+        if model is None:
+            return launch()
+        L, ct = self.L, self.ct
+        lib = L.load()
+        e0, e1 = ct.c_void_p(), ct.c_void_p()
+        lib.pg_event_create(ct.byref(e0)); lib.pg_event_create(ct.byref(e1))
+        lib.pg_event_record(e0, L.stream())
+        launch()
+        lib.pg_event_record(e1, L.stream())
+        self.rec.append((name, model(args), e0, e1))
+
+    def summary(self):
+        lib, ct = self.L.load(), self.ct
+        out = {}
+        for name, nbytes, e0, e1 in self.rec:
+            ms = ct.c_float()
+            lib.pg_event_elapsed_ms(e0, e1, ct.byref(ms))
+            lib.pg_event_destroy(e0); lib.pg_event_destroy(e1)
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
+            d["calls"] += 1; d["ms"] += ms.value; d["bytes"] += nbytes
+        res = []
+        for name, d in sorted(out.items(), key=lambda kv: -kv[1]["ms"]):
+            tbs = d["bytes"] / max(d["ms"], 1e-9) * 1e-9
+            res.append({"kernel": name, "calls": d["calls"], "ms": round(d["ms"], 4), "algorithmic_MB": round(d["bytes"] / 1e6, 2),
+                        "TB_per_s": round(tbs, 3), "frac_of_hbm_peak": round(tbs / PEAK_HBM_TBS, 4)})
+        return res
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/round1_pmc.json, made by
     tools/pmc_bench.sh on the default workload): 2*FETCH_SIZE + WRITE_SIZE, in bytes (MI355X_MICROARCH.md: FETCH_SIZE
@@ -199,6 +275,20 @@ def main():
                     "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                      "tflops": round(v["flops"] / max(v["ms"], 1e-9) * 1e-9, 2)}
                                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+    # ---- HBM-bound kernels: one more un-timed, single-stream iteration with events around each memory-bound launch
+    hbm = None
+    if not args.no_kernel_profile:
+        from pose_transfer_amd.runtime import lib as _L
+        prof = HbmProfiler()
+        side, E.SIDE_STREAM = E.SIDE_STREAM, False
+        _L.CALL_HOOK = prof.hook
+        try:
+            iteration(model, batches, od)
+            torch.cuda.synchronize()
+        finally:
+            _L.CALL_HOOK = None
+            E.SIDE_STREAM = side
+        hbm = prof.summary()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -219,7 +309,7 @@ def main():
                        "precision": args.precision},
             "step_tflops": round(sf * ips / 1e12, 2),
             "step_frac_of_f32_mfma_peak": round(sf * ips / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -292,6 +292,15 @@ int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float b1, f
 int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m, float* v, int64_t n, float b1, float b2, float eps,
                float step_size, float bc2_sqrt, float grad_scale, void* p_bf16, void* stream);
 
+/* Weight gradient of a k4/s2/p1 Block convolution on the bf16 data path (autograd of nn.Conv2d / nn.ConvTranspose2d+crop
+ * weights, models/networks.py:154-157), straight from pixel-major bf16 operands with transposing LDS reads
+ * (csrc/wgrad_bf16.hip): dW[16 taps][Cout][ldw] fp32, columns [col_off, col_off + Cx) (+)= sum over pixels dY * X for ONE
+ * K-source x (already normalised / activated / masked: pg_materialise_bf16) of the virtual concat.
+ * x_is_large = 1: Conv2d (x on the 2Hs x 2Ws grid, dy on Hs x Ws); 0: ConvTranspose2d + crop (x small, dy large).
+ * Cx % 128 == 0, Cout % 128 == 0; ksplit <= 0: chosen by the library (float atomics when > 1).                          */
+int pg_wgrad_bf16(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_t Cout, int32_t x_is_large, int32_t N,
+                  int32_t Hs, int32_t Ws, float* dW, int32_t ldw, int32_t col_off, int32_t ksplit, void* stream);
+
 /* ---- data-parallel gradient exchange (NEW: the reference is single-process; main.py:44-159 has no
  * counterpart).  One process per GPU; RCCL (xGMI) is resolved at run time (dlopen librccl.so.1), the communication stream
  * and every ordering event belong to the caller.

@@ -1,0 +1,262 @@
+// Weight gradient of the k4 / s2 / p1 Block convolutions on the bf16 data path, straight from the PIXEL-MAJOR (NHWC) bf16
+// tensors the forward and data-gradient contractions already use — no channel-major copies (round 1: eight
+// `channel_major_bf16` passes per layer, 3.5 ms of a 39 ms generator forward+backward at batch 32, plus a product buffer
+// and a torch add).
+//
+//   dW[tap = (r, s)][co][ci] += sum over small-grid pixels q = (n, qy, qx) of  dY[.][co] * X[.][ci]
+//   where one operand lives on the small grid (row q) and the other on the large grid (row (n, 2 qy + r - 1, 2 qx + s - 1),
+//   zero outside): Conv2d(k4,s2,p1): X large / dY small; ConvTranspose2d(k4,s2)+crop: X small / dY large
+//   (reference models/networks.py:154-157; autograd of conv2d / conv_transpose2d weights).
+//
+// GEMM view per tap: M = Cout, N = Cin (one K-source of the virtual concat per launch), K = pixels.  Both operands are
+// K-major in memory ([pixel][channel]), the MFMA wants 8 consecutive k per lane: the tiles are DMA'd pixel-major into LDS
+// (global_load_lds_dwordx4, 16-byte channel chunks, fully coalesced) and the fragments are fetched with
+// ds_read_b64_tr_b16 — the gfx950 transposing LDS read: inside a 16-lane group lane 4 r + c supplies the address of 4
+// channels (8 B) of pixel r and receives channel (4 c' + ..) of pixels 0..3, i.e. a 4 x 16 block comes back transposed
+// (semantics probed on the box: tools/microbench/tr_probe.hip).  Two such reads = one 32x32x16 operand fragment.
+// LDS image: [64 pixels][BW channels], chunk c of pixel p stored at slot c ^ ((p & 3) << 2): the four pixel rows a
+// 32-lane half reads then cover the 256-byte bank row exactly once (un-swizzled they alias 4-way: the row pitch is a
+// multiple of 256 B).  Pipeline = igemm_bf16.hip: 8 waves, two 64 KB stages, ONE barrier per K tile placed before the last
+// k-step's MFMAs, counted lgkmcnt, operand registers double-buffered per k-step.
+// Work split: grid (M tiles, N tiles, 16 taps x ksplit); partial sums are added to dW with float atomics (ksplit > 1) or
+// a plain read-modify-write.
+#include <cstdlib>
+#include <type_traits>
+
+#include "igemm_common.h"
+
+namespace pg {
+
+struct WgBf16K {
+  const unsigned short* sm;   // small-grid operand [N][Hs][Ws][Cs]
+  const unsigned short* lg;   // large-grid operand [N][Hl][Wl][Cl]
+  int Cs, Cl;
+  int N, Hs, Ws, Hl, Wl;
+  int a_is_small;             // 1: A (rows = Cout) is the small-grid tensor (Conv2d), 0: the large-grid tensor (ConvT)
+  float* dW;                  // [16][Cout][ldw] fp32, accumulated
+  int Cout, ldw, col_off;
+  int ksplit, atomic;
+  long Q;                     // N * Hs * Ws
+};
+
+template <int OFF>
+__device__ __forceinline__ void lds_tr64(unsigned long long& v, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) {
+  constexpr int WGN = (BN == 256) ? 4 : (BM == 256 ? 2 : 4);
+  constexpr int WGM = 8 / WGN;
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  constexpr int A_ST = 64 * BM * 2, B_ST = 64 * BN * 2, STAGE = A_ST + B_ST;
+  constexpr int A_CPR = BM / 8, B_CPR = BN / 8;               // 16-byte chunks per pixel row
+  constexpr int A_RPI = 64 / A_CPR, B_RPI = 64 / B_CPR;       // pixel rows per wave DMA instruction
+  constexpr int A_PASS = 64 / (8 * A_RPI), B_PASS = 64 / (8 * B_RPI);
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tap = blockIdx.z / p.ksplit, split = blockIdx.z - tap * p.ksplit;
+  const int tr = tap >> 2, ts = tap & 3;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ktot = (int)((p.Q + 63) >> 6);
+  const int kper = (ktot + p.ksplit - 1) / p.ksplit;
+  const int kt0 = split * kper, kt1 = min(ktot, kt0 + kper);
+  if (kt0 >= kt1) return;
+
+  // operand roles
+  const unsigned short* const a_base = p.a_is_small ? p.sm : p.lg;
+  const unsigned short* const b_base = p.a_is_small ? p.lg : p.sm;
+  const int Ca = p.a_is_small ? p.Cs : p.Cl, Cb = p.a_is_small ? p.Cl : p.Cs;
+  const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- DMA: thread -> (pixel row within the tile, 16-byte slot); chunk = slot ^ ((pixel & 3) << 2)
+  const int a_row = wave * A_RPI + lane / A_CPR, a_slot = lane % A_CPR;
+  const int b_row = wave * B_RPI + lane / B_CPR, b_slot = lane % B_CPR;
+  const int a_ch = m0 + ((a_slot ^ ((a_row & 3) << 2)) << 3);        // first channel of the chunk this lane moves
+  const int b_ch = n0 + ((b_slot ^ ((b_row & 3) << 2)) << 3);
+  const int hw = p.Hs * p.Ws;
+
+  auto src_ptr = [&](bool is_small, const unsigned short* base, int C, int ch, long q) -> const char* {
+    if (q >= p.Q) return zero_pg + (lane & 7) * 16;
+    if (is_small) return reinterpret_cast<const char*>(base + q * C + ch);
+    const int n = (int)(q / hw);
+    const int rem = (int)(q - (long)n * hw);
+    const int qy = rem / p.Ws, qx = rem - qy * p.Ws;
+    const int ly = 2 * qy + tr - 1, lx = 2 * qx + ts - 1;
+    const bool ok = (ly >= 0) & (ly < p.Hl) & (lx >= 0) & (lx < p.Wl);
+    return ok ? reinterpret_cast<const char*>(base + ((long)(n * p.Hl + ly) * p.Wl + lx) * C + ch) : zero_pg + (lane & 7) * 16;
+  };
+  auto issue = [&](int stage, int kt) {
+    float* const As = reinterpret_cast<float*>(smem + stage * STAGE);
+    float* const Bs = reinterpret_cast<float*>(smem + stage * STAGE + A_ST);
+    const long q0 = (long)kt * 64;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const char* s = src_ptr(p.a_is_small != 0, a_base, Ca, a_ch, q0 + i * 8 * A_RPI + a_row);
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s), As + (i * 8 + wave) * 256, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      const char* s = src_ptr(p.a_is_small == 0, b_base, Cb, b_ch, q0 + i * 8 * B_RPI + b_row);
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s), Bs + (i * 8 + wave) * 256, 16, 0, 0);
+    }
+  };
+
+  // ---- operand fetch (transposing reads).  lane: i = l & 15 -> pixel sub-row r4 = i >> 2, channel quad cq = i & 3;
+  // 16-channel block mb = (l >> 4) & 1; k half kh = l >> 5 (pixels + 8).
+  const int wm0 = (wave / WGN) * (TM * 32), wn0 = (wave % WGN) * (TN * 32);
+  const int r4 = (lane >> 2) & 3, cq = lane & 3, mb = (lane >> 4) & 1, kh = lane >> 5;
+  unsigned fa[TM], fb[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int chunk = ((wm0 + 32 * t) >> 3) + 2 * mb + (cq >> 1);
+    fa[t] = lds0 + (unsigned)((8 * kh + r4) * (BM * 2)) + (unsigned)(((chunk ^ (r4 << 2)) << 4) + ((cq & 1) << 3));
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int chunk = ((wn0 + 32 * t) >> 3) + 2 * mb + (cq >> 1);
+    fb[t] = lds0 + A_ST + (unsigned)((8 * kh + r4) * (BN * 2)) + (unsigned)(((chunk ^ (r4 << 2)) << 4) + ((cq & 1) << 3));
+  }
+  typedef unsigned long long u64;
+  struct Frag { u64 lo, hi; };
+  auto fetch = [&](int stage, auto ksc, Frag (&va)[TM], Frag (&vb)[TN]) {
+    constexpr int KS = decltype(ksc)::value;
+    const unsigned so = (unsigned)(stage * STAGE);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      lds_tr64<KS * 16 * BM * 2>(va[t].lo, fa[t] + so);
+      lds_tr64<KS * 16 * BM * 2 + 4 * BM * 2>(va[t].hi, fa[t] + so);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      lds_tr64<KS * 16 * BN * 2>(vb[t].lo, fb[t] + so);
+      lds_tr64<KS * 16 * BN * 2 + 4 * BN * 2>(vb[t].hi, fb[t] + so);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfmas = [&](const Frag (&va)[TM], const Frag (&vb)[TN]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 a = {va[i].lo, va[i].hi}, b = {vb[j].lo, vb[j].hi};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i][j], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr int NRD = 2 * (TM + TN);
+#define PGW_WAIT(n)                                                 \
+  do {                                                              \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+
+  issue(0, kt0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  Frag va0[TM], vb0[TN], va1[TM], vb1[TN];
+  fetch(0, K0{}, va0, vb0);
+  int stage = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) issue(stage ^ 1, kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(stage, K1{}, va1, vb1);
+    PGW_WAIT(NRD);
+    mfmas(va0, vb0);
+    fetch(stage, K2{}, va0, vb0);
+    PGW_WAIT(NRD);
+    mfmas(va1, vb1);
+    fetch(stage, K3{}, va1, vb1);
+    PGW_WAIT(NRD);
+    mfmas(va0, vb0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(stage ^ 1, K0{}, va0, vb0);
+    mfmas(va1, vb1);
+    stage ^= 1;
+  }
+#undef PGW_WAIT
+
+  // ---- epilogue: dW[tap][m][col_off + n] += acc   (lanes 0..31 = 32 consecutive columns: 128-byte segments)
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* const out = p.dW + (long)tap * p.Cout * p.ldw + p.col_off;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + 32 * j + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float* o = out + (long)m * p.ldw + n;
+        if (p.atomic) atomicAdd(o, acc[i][j][r]);
+        else *o += acc[i][j][r];
+      }
+    }
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+// dW[16][Cout][ldw] (+)= weight gradient of one K-source of a k4/s2/p1 convolution (x_is_large = 1: Conv2d, X on the large
+// grid; 0: ConvTranspose2d + crop, dY on the large grid).  x / dy: bf16 NHWC tensors (already normalised / activated /
+// masked: pg_materialise_bf16).  Cx % 128 == 0, Cout % 128 == 0, Hl == 2 Hs, Wl == 2 Ws.
+extern "C" int pg_wgrad_bf16(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_t Cout, int32_t x_is_large, int32_t N,
+                             int32_t Hs, int32_t Ws, float* dW, int32_t ldw, int32_t col_off, int32_t ksplit, void* stream) {
+  PG_REQUIRE(x_bf16 && dy_bf16 && dW && N > 0 && Hs > 0 && Ws > 0, "pg_wgrad_bf16: bad arguments");
+  PG_REQUIRE(Cx % 128 == 0 && Cout % 128 == 0 && col_off >= 0 && col_off + Cx <= ldw, "pg_wgrad_bf16: channel counts must be "
+             "multiples of 128 (Cx=%d Cout=%d)", Cx, Cout);
+  WgBf16K k;
+  memset(&k, 0, sizeof(k));
+  k.N = N; k.Hs = Hs; k.Ws = Ws; k.Hl = 2 * Hs; k.Wl = 2 * Ws;
+  k.a_is_small = x_is_large ? 1 : 0;                 // A rows = Cout = the dY tensor
+  if (x_is_large) { k.sm = (const unsigned short*)dy_bf16; k.Cs = Cout; k.lg = (const unsigned short*)x_bf16; k.Cl = Cx; }
+  else { k.sm = (const unsigned short*)x_bf16; k.Cs = Cx; k.lg = (const unsigned short*)dy_bf16; k.Cl = Cout; }
+  k.dW = dW; k.Cout = Cout; k.ldw = ldw; k.col_off = col_off;
+  k.Q = (long)N * Hs * Ws;
+  PG_REQUIRE((double)N * 4.0 * Hs * Ws * (Cx > Cout ? Cx : Cout) * 2.0 < 9.0e18, "pg_wgrad_bf16: tensor too large");
+  const int bm = (Cout % 256 == 0) ? 256 : 128, bn = (Cx % 256 == 0) ? 256 : 128;
+  const int mt = Cout / bm, nt = Cx / bn;
+  const int ktot = (int)((k.Q + 63) / 64);
+  int ks = ksplit;
+  if (ks <= 0) {               // fill ~3 rounds of the 256 CUs, keep >= 16 K tiles per workgroup
+    const long base = (long)mt * nt * 16;
+    ks = (int)((768 + base - 1) / base);
+    if (ks > ktot / 16) ks = ktot / 16;
+    if (ks < 1) ks = 1;
+  }
+  if (ks > ktot) ks = ktot;
+  while (ks > 1 && (long)(ks - 1) * ((ktot + ks - 1) / ks) >= ktot) --ks;      // no empty split
+  k.ksplit = ks; k.atomic = ks > 1 ? 1 : 0;
+  dim3 grid(mt, nt, 16 * ks);
+  hipStream_t st = (hipStream_t)stream;
+  if (bm == 256 && bn == 256) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<256, 256>), grid, dim3(512), 0, st, k);
+  else if (bm == 128 && bn == 256) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<128, 256>), grid, dim3(512), 0, st, k);
+  else if (bm == 256 && bn == 128) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<256, 128>), grid, dim3(512), 0, st, k);
+  else hipLaunchKernelGGL((wgrad_bf16_tr_kernel<128, 128>), grid, dim3(512), 0, st, k);
+  PG_LAUNCH_OK("pg_wgrad_bf16");
+  last_info() = 6 | (ks << 16) | (1 << 30);
+  return 0;
+}

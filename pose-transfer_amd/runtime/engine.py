@@ -9,6 +9,7 @@ load.  Parameters live in flat arenas (params / grads / Adam m / Adam v) in pack
 """
 import os
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -24,8 +25,8 @@ class KernelProfiler:
     """Per-launch timing of the contraction kernels with HIP events recorded on the launch stream
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
-    CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32"}
-    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin"}
+    CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32", 4: "256x256", 5: "256x128"}
+    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin", 6: "bf16-tr-256"}
 
     def __init__(self):
         self.records = []
@@ -226,7 +227,7 @@ class Act:
 # converted per optimiser step, and the contraction DMAs bf16 tiles straight into LDS (fp32 accumulate / outputs).
 PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[os.environ.get("PG_PRECISION", "f32")]
 
-ARENAS = {}                 # parameter-arena storage pointer -> ParamArena
+ARENAS = weakref.WeakValueDictionary()    # parameter-arena storage pointer -> ParamArena (weak: arenas die with their model)
 WEIGHT_VERSION = {}         # parameter-arena storage -> version, bumped whenever its parameters change (optimiser step,
                             # load_state_dict): the bf16 weight copies of THAT arena go stale
 _BF_SRC = {}                # device -> list of bf16 scratch buffers, one per source slot (stream-ordered reuse)
@@ -239,8 +240,15 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
         # K-contiguous forward operand = the packed arena layout: a view of the arena's bf16 copy (written by pg_adam_ex)
         off = (W.data_ptr() - arena.params.data_ptr()) // 4
         return arena.bf16_params()[off:off + W.numel()]
+    if arena is None:
+        # a weight outside any arena (kernel tests, module-level API): convert on every call — a cache keyed by address
+        # would serve stale copies when the allocator reuses the address for a different tensor of the same size
+        buf = torch.empty(W.numel(), dtype=torch.bfloat16, device=W.device)
+        L.call("pg_weights_to_bf16", L.ptr(W), taps, Cout, Cin, None if transposed else L.ptr(buf),
+               L.ptr(buf) if transposed else None, L.stream())
+        return buf
     key = (W.data_ptr(), W.numel())
-    ver = WEIGHT_VERSION.get(W.untyped_storage().data_ptr(), 0)
+    ver = arena.version()
     ent = _BF_W.get(key)
     if ent is None or ent[0] != ver:
         ent = _BF_W[key] = [ver, None, None]
@@ -430,6 +438,37 @@ def _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
     dW.view(-1).add_(prod)
 
 
+_BF_WGT = {}       # device -> bf16 scratch of the transposing-read weight gradient: [x per source slot ..., dY]
+WGRAD_TR = os.environ.get("PG_NO_WGRAD_TR") is None        # ablation switch: channel-major copies + NT GEMMs instead
+
+
+def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
+    """Weight gradient on the bf16 data path straight from pixel-major bf16 tensors (csrc/wgrad_bf16.hip): every source
+    of the virtual concat and the gradient are materialised once as bf16 NHWC (the same pass the forward / data-gradient
+    contractions use) and pg_wgrad_bf16 adds each source's column block into dW — no channel-major copies, no product
+    buffer.  Runs on the weight-gradient side stream with its OWN scratch (the main stream's pool is busy)."""
+    dev = dW.device
+    pool = _BF_WGT.setdefault(dev, [None] * (L.PG_MAX_SRC + 1))
+    Hx, Wx = (Hl, Wl) if x_is_large else (Hs, Ws)
+    Hy, Wy = (Hs, Ws) if x_is_large else (Hl, Wl)
+
+    def buf(slot, need):
+        if pool[slot] is None or pool[slot].numel() < need:
+            pool[slot] = torch.empty(need, dtype=torch.bfloat16, device=dev)
+        return pool[slot]
+
+    dyb = buf(L.PG_MAX_SRC, N * Hy * Wy * Cout)
+    L.call("pg_materialise_bf16", dY if isinstance(dY, int) else L.ptr(dY), None, None, L.ACT_NONE, N, Hy * Wy, Cout,
+           L.ptr(dyb), L.stream())
+    c0 = 0
+    for j, s_ in enumerate(srcs):
+        xb = buf(j, N * Hx * Wx * s_.C)
+        L.call("pg_materialise_bf16", s_.ptr, s_.aff, s_.mask, act, N, Hx * Wx, s_.C, L.ptr(xb), L.stream())
+        L.call("pg_wgrad_bf16", L.ptr(xb), s_.C, L.ptr(dyb), Cout, 1 if x_is_large else 0, N, Hs, Ws, L.ptr(dW), Cin, c0, 0,
+               L.stream())
+        c0 += s_.C
+
+
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
            y_strides=None, ksplit=0, cout_store=0):
     if not SIDE_STREAM or not torch.cuda.is_available():
@@ -447,6 +486,12 @@ def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stri
     if (PRECISION == 3 and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None and cout_store == 0
             and Cin > 32 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor)
             and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS):
+        if WGRAD_TR and Cout % 128 == 0 and all(s_.C % 128 == 0 for s_ in srcs):
+            run = lambda: _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW)
+            if PROFILER is not None:
+                PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
+                return
+            return run()
         if PROFILER is not None:
             PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout,
                             lambda: _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW))

@@ -78,6 +78,7 @@ _PROTOS = {
     "pg_materialise_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
     "pg_weights_to_bf16": [_vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "pg_channel_major_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp],
+    "pg_wgrad_bf16": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "pg_gemm_taps_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pg_norm_stats": [_vp, _i32, _i64, _vp, _vp],
     "pg_norm_finalize": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
@@ -165,7 +166,12 @@ def ptr(t):
     return t.data_ptr()
 
 
+CALL_HOOK = None      # bench.py's per-kernel timing leg: callable(name, args, launch) wrapping every named entry-point call
+
+
 def call(name, *args):
+    if CALL_HOOK is not None:
+        return CALL_HOOK(name, args, lambda: check(getattr(load(), name)(*args), name))
     check(getattr(load(), name)(*args), name)
 
 

@@ -659,3 +659,99 @@ def test_small_cin_patch_conv(name):
         E._small_cin_conv(acts, case.N, case.H, case.W, case.K, case.stride, case.pad, wp, bd, wt, out)
         torch.cuda.synchronize()
         assert rel(nchw(out.cpu()), out_ref) < 1e-5, hw
+
+
+# ------------------------------------------------------------------------------------------ 256-row bf16 kernel
+def big_cases():
+    A, M = True, True
+    return [
+        ConvCase("big_down_256", "conv", [(128, A, False)], 256, 2, 24, 20, 4, 2, 1, L.ACT_LEAKY, seed=11),
+        ConvCase("big_down_128_multi_tile", "conv", [(64, A, False)], 128, 3, 40, 36, 4, 2, 1, L.ACT_LEAKY, seed=12),
+        ConvCase("big_up_3src", "convT", [(128, A, M), (128, False, False), (128, A, False)], 128, 2, 10, 9, 4, 2, 1,
+                 L.ACT_RELU, seed=13),
+        ConvCase("big_up_512", "convT", [(256, A, False), (256, False, False)], 512, 1, 12, 12, 4, 2, 1, L.ACT_RELU, seed=14),
+        ConvCase("big_k3_bias", "conv", [(128, A, False)], 256, 2, 14, 18, 3, 1, 1, L.ACT_RELU, bias=True, seed=15),
+    ]
+
+
+@pytest.mark.parametrize("case", big_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
+def test_conv_bf16_big_kernel(case, monkeypatch):
+    """igemm_bf16.hip (256 x 256 / 256 x 128 tiles, 8 waves, DMA'd operands, one barrier per K tile), forced on small
+    problems (PG_FORCE_BF16_BIG) so that partial M tiles, several N tiles, multi-source A, the four convT phases, bias,
+    the fused statistics and the data-gradient scatter (fresh and accumulating) are all exercised.  Exact up to summation
+    order against the fp32 contraction of the bf16-ROUNDED operands (1e-4 of the tensor max)."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    zs, xs = [], []
+    for j in range(len(case.srcs)):
+        z = case.raw[j]
+        if case.aff[j] is not None:
+            z = torch.addcmul(case.aff[j][:, 1].view(-1, 1, 1, 1), z, case.aff[j][:, 0].view(-1, 1, 1, 1))
+        zs.append(z.detach().clone().requires_grad_(True))
+    for j, z in enumerate(zs):
+        v = z if case.mask[j] is None else z * case.mask[j].view(case.N, -1, 1, 1)
+        xs.append(act_fn(v, case.act))
+    w = bf(case.w)
+    xq = torch.cat([bf(x.detach()) for x in xs], 1)
+    conv = (lambda x: F.conv2d(x, w, case.b, stride=case.stride, padding=case.pad)) if case.kind == "conv" else \
+           (lambda x: F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:-1, 1:-1])
+    ref = conv(xq)
+    stats = torch.zeros(case.N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
+    got = case.run_forward(1, stats=stats)
+    assert (L.load().pg_last_launch_info() & 0xF) in (4, 5), "the 256-row kernel did not run"
+    assert rel(got, ref) < 1e-4, (case.name, float(rel(got, ref)))
+    o64 = got.double().reshape(case.N, -1)          # statistics of the STORED values
+    st = stats.cpu().sum(1)
+    assert float(((st[:, 0] - o64.sum(1)).abs() / o64.abs().sum(1)).max()) < 1e-6
+    assert float(((st[:, 1] - (o64 * o64).sum(1)).abs() / (o64 * o64).sum(1)).max()) < 1e-6
+    # data-gradient: dX = W^T * bf16(dY), scattered with act' / mask of the fp32 forward values
+    y = conv(torch.cat(xs, 1))
+    dref = torch.autograd.grad((y * bf(case.gout)).sum(), zs)
+    for acc in (False, True):
+        dgot = case.run_dgrad(1, acc)
+        if case.cin % 128 == 0:          # the 256-row kernel needs >= 128 output columns (= input channels here)
+            assert (L.load().pg_last_launch_info() & 0xF) in (4, 5)
+        for g, r in zip(dgot, dref):
+            assert rel(g, r) < 1e-4, (case.name, acc, float(rel(g, r)))
+
+
+def wgrad_tr_cases():
+    A, M = True, True
+    return [
+        ConvCase("wtr_conv_128_256", "conv", [(128, A, False)], 256, 2, 24, 20, 4, 2, 1, L.ACT_LEAKY, seed=21),
+        ConvCase("wtr_conv_256_128_tail", "conv", [(256, A, False)], 128, 3, 14, 10, 4, 2, 1, L.ACT_LEAKY, seed=22),     # Q = 105: partial K tile
+        ConvCase("wtr_up_3src", "convT", [(128, A, M), (128, False, False), (256, A, False)], 128, 2, 10, 9, 4, 2, 1,
+                 L.ACT_RELU, seed=23),
+        ConvCase("wtr_up_512", "convT", [(256, A, False), (256, False, False)], 512, 1, 12, 12, 4, 2, 1, L.ACT_RELU, seed=24),
+        ConvCase("wtr_conv_splitk", "conv", [(128, A, False)], 128, 4, 64, 48, 4, 2, 1, L.ACT_LEAKY, seed=25),           # 48 K tiles, split
+    ]
+
+
+@pytest.mark.parametrize("case", wgrad_tr_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
+def test_weight_gradient_bf16_transposing_reads(case, monkeypatch):
+    """pg_wgrad_bf16 (csrc/wgrad_bf16.hip): weight gradient straight from pixel-major bf16 tensors, operand fragments by
+    ds_read_b64_tr_b16.  All tile shapes (256x256, 128x256, 256x128, 128x128), both geometries (Conv2d: x large; ConvT +
+    crop: x small), multi-source x with prologue, a partial last K tile, split-K atomics and accumulation into a non-zero
+    dW.  Tight check against torch autograd on the bf16-ROUNDED operands."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setattr(E, "WGRAD_BF16_MIN_FLOPS", 0.0)
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    xs = []
+    for j in range(len(case.srcs)):
+        z = case.raw[j]
+        if case.aff[j] is not None:
+            z = torch.addcmul(case.aff[j][:, 1].view(-1, 1, 1, 1), z, case.aff[j][:, 0].view(-1, 1, 1, 1))
+        if case.mask[j] is not None:
+            z = z * case.mask[j].view(case.N, -1, 1, 1)
+        xs.append(bf(act_fn(z, case.act)))
+    x = torch.cat(xs, 1)
+    w = case.w.clone().requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=2, padding=1) if case.kind == "conv" else F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:-1, 1:-1]
+    ref = torch.autograd.grad((y * bf(case.gout)).sum(), w)[0]
+    got = case.run_wgrad()
+    info = L.load().pg_last_launch_info()
+    assert (info & 15) == 6 and (info & (1 << 30)), hex(info)
+    assert rel(got, ref) < 1e-4, (case.name, float(rel(got, ref)))
+    if case.name == "wtr_conv_splitk":
+        assert ((info >> 16) & 0x3FFF) > 1, "expected a split-K launch"

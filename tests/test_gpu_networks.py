@@ -139,31 +139,31 @@ def test_generator_edge_shapes_vs_oracle(tag, n, size, pdim):
     inp, tgt, wr, mk = [t(a) for a in synth.batch(29, tag, n, pdim, *size)]
     drops = [t(m) for m in synth.dropout_masks(29, tag, n)]
     go = t(synth.normal(29, tag + "/go", (n, 3) + tuple(size)))
-    # the ORACLE runs in float64 here (three small shapes): its own fp32 rounding (up to 2.9e-2 of a tensor's max on
-    # single conv-weight elements, 0.11 on a scalar norm bias — measured in round 1) no longer sets the tolerance
-    pr = {k: v.double().requires_grad_(True) for k, v in par.items()}
-    out_ref = R.generator_forward(inp.double(), wr.double(), mk.double(), pr, pdim, enc, dec, size, [d.double() for d in drops])
-    gref = dict(zip(pr.keys(), torch.autograd.grad((out_ref * go.double()).sum(), list(pr.values()))))
+    # The oracle runs TWICE: in float64 (the reference value) and in float32 (how far fp32 arithmetic itself sits from
+    # it).  The scalar norm parameters' gradients are cancelling sums over a whole activation and the warp layer's
+    # arg-max is discontinuous, so the fp32-vs-fp64 distance of the ORACLE reaches 1e-1 of a tensor's max on some
+    # tensors; a fixed tolerance would have to sit above that.  Bar: device error vs the float64 oracle
+    # <= 2e-3 of the tensor max + 2x the fp32 oracle's own distance from the float64 oracle on that tensor.
+    def oracle(dt):
+        pr = {k: v.to(dt).requires_grad_(True) for k, v in par.items()}
+        o = R.generator_forward(inp.to(dt), wr.to(dt), mk.to(dt), pr, pdim, enc, dec, size, [d.to(dt) for d in drops])
+        return o, dict(zip(pr.keys(), torch.autograd.grad((o * go.to(dt)).sum(), list(pr.values()))))
+    out_ref, gref = oracle(torch.float64)
+    out32, g32 = oracle(torch.float32)
     gen = Deformable_Generator(3 + 2 * pdim, pdim, size, enc, dec, "mask")
     gen.load_state_dict(par)
     gen.zero_grad()
     out = gen(inp.to(DEV), wr.to(DEV), mk.to(DEV), drop_masks=[d.to(DEV) for d in drops])
     (out * go.to(DEV)).sum().backward()
     assert out.shape == out_ref.shape and maxdiff(out, out_ref) < 1e-3
-    # fp32 device gradients vs the float64 oracle: 2e-3 of the tensor max.  What remains above that is the warp layer's
-    # arg-max (a discontinuous function): a near-tie decided differently in fp32 re-routes one pixel's gradient, which
-    # shows on isolated conv-weight elements — bounded in count (< 0.5 % of a tensor) and size (< 6e-2 of its max).
     got = gen.arena.grad_dict()
     bad = []
     for k in gref:
         scale = max(float(gref[k].abs().max()), 1e-8)
-        d = (got[k].cpu().double() - gref[k]).abs()
-        if k.endswith("weight") and gref[k].dim() == 4:
-            ok = float(d.max()) / scale < 2e-3 or (float(d.max()) / scale < 6e-2 and float((d > 2e-3 * scale).float().mean()) < 5e-3)
-        else:
-            ok = float(d.max()) / scale < 2e-2      # scalar gamma / beta / biases: cancelling fp32 sums over a whole tensor
-        if not ok:
-            bad.append((k, float(d.max()) / scale, float((d > 2e-3 * scale).float().mean())))
+        d = float((got[k].cpu().double() - gref[k]).abs().max()) / scale
+        noise = float((g32[k].double() - gref[k]).abs().max()) / scale
+        if d > 2e-3 + 2.0 * noise:
+            bad.append((k, d, noise))
     assert not bad, bad
 
 
