@@ -252,7 +252,9 @@ int pg_mask_pyramid(const void* masks, int32_t is_f64, int32_t N, int32_t T, int
 int pg_warp_mask_max_fwd(const float* feat, const float* aff, const float* warps, const float* lvl_masks,
                          int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
                          int32_t align_corners, float* out, uint8_t* argmax, void* stream);
-/* gradient wrt the (post-affine) features: dfeat += scatter(gout * mask[t*] * bilinear weights). */
+/* gradient wrt the (post-affine) features: dfeat = sum over the output pixels whose selected transform t* samples it of
+ * gout * mask[t*] * bilinear weight.  dfeat is OVERWRITTEN (gather form: deterministic, no atomics; transforms that shrink
+ * by more than ~0.6 fall back to a float-atomic scatter on top). */
 int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, const float* warps, const float* lvl_masks,
                          int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
                          int32_t align_corners, float* dfeat, void* stream);

@@ -8,6 +8,8 @@
 //    Layout is NHWC, so the 4 bilinear taps of a pixel are 4 contiguous channel runs (coalesced float4 per lane);
 //    transforms whose mask is 0 at a pixel contribute an exact 0 to the max and are skipped without touching memory.
 //    Coordinates follow the reference's fp32 operation order (fp contraction off): SURVEY.md App. A.2.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pg {
@@ -64,7 +66,8 @@ __device__ __forceinline__ Theta make_theta(const float* wr, int h, int w, int H
 
 struct Taps { int x0, y0; float w00, w01, w10, w11; };
 
-__device__ __forceinline__ Taps make_taps(const Theta& t, int i, int j, int h, int w, int align_corners) {
+// un-floored source coordinates of output pixel (i, j) under theta — the reference's fp32 evaluation order
+__device__ __forceinline__ void make_coords(const Theta& t, int i, int j, int h, int w, int align_corners, float& ix, float& iy) {
 #pragma clang fp contract(off)
   const float fh = (float)h, fw = (float)w;
   float xs, ys;
@@ -77,7 +80,6 @@ __device__ __forceinline__ Taps make_taps(const Theta& t, int i, int j, int h, i
   }
   const float gx = ((t.t00 * xs) + (t.t01 * ys)) + t.t02;
   const float gy = ((t.t10 * xs) + (t.t11 * ys)) + t.t12;
-  float ix, iy;
   if (align_corners) {
     ix = ((gx + 1.0f) / 2.0f) * (fw - 1.0f);
     iy = ((gy + 1.0f) / 2.0f) * (fh - 1.0f);
@@ -85,6 +87,12 @@ __device__ __forceinline__ Taps make_taps(const Theta& t, int i, int j, int h, i
     ix = (((gx + 1.0f) * fw) - 1.0f) / 2.0f;
     iy = (((gy + 1.0f) * fh) - 1.0f) / 2.0f;
   }
+}
+
+__device__ __forceinline__ Taps make_taps(const Theta& t, int i, int j, int h, int w, int align_corners) {
+#pragma clang fp contract(off)
+  float ix, iy;
+  make_coords(t, i, j, h, w, align_corners, ix, iy);
   const float x0f = floorf(ix), y0f = floorf(iy);
   const float fx = ix - x0f, fy = iy - y0f;
   Taps r;
@@ -151,17 +159,128 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* feat, const 
   }
 }
 
+// ---- backward.  Gather form: an input pixel (X, Y) collects from the output pixels whose bilinear footprint under some
+// transform covers it.  The affine map is inverted per (sample, transform): the pre-image of the 2 x 2 neighbourhood of
+// (X, Y) is a parallelogram, its bounding box holds <= GATHER_CAP integer points for every "narrow" transform (identity
+// 9, scale 0.8 / 30 degrees 16).  Phase 1 (one lane per (input pixel, transform)): walk the box, keep the candidates with a
+// non-zero mask whose taps (evaluated by the SAME make_taps as the forward pass) hit (X, Y) in an LDS list (output pixel,
+// mask x bilinear weight).  Phase 2 (lanes = 4 channels of a pixel): run the lists, add g where the forward arg-max
+// selected that transform.  No atomics, deterministic, one 16-byte store per 4 elements, no zero-fill of the destination.
+// "Wide" transforms (a strongly shrinking limb fit; rare) take the scatter kernel below with float atomics.
+constexpr int GATHER_CAP = 16, GATHER_PIX = 32, GATHER_T = 10;      // T <= 10 on the gather path (10 limb transforms / 1)
+
+struct WarpInv { float jx, jy, ix_, iy_, cx, cy, ej, ei; int narrow; };
+
+__device__ __forceinline__ WarpInv invert_warp(const Theta& th, int h, int w, int align) {
+  float x00, y00, x10, y10, x01, y01;
+  make_coords(th, 0, 0, h, w, align, x00, y00);
+  make_coords(th, 0, 1, h, w, align, x10, y10);        // j + 1
+  make_coords(th, 1, 0, h, w, align, x01, y01);        // i + 1
+  const float a = x10 - x00, b = x01 - x00, c = y10 - y00, d = y01 - y00;     // (ix, iy) = [a b; c d] (j, i) + (x00, y00)
+  const float det = a * d - b * c;
+  WarpInv r;
+  r.narrow = 0;
+  r.cx = x00; r.cy = y00;
+  r.jx = r.jy = r.ix_ = r.iy_ = r.ej = r.ei = 0.f;
+  if (!(fabsf(det) > 1e-12f) || !isfinite(det) || !isfinite(x00) || !isfinite(y00)) return r;
+  r.jx = d / det; r.jy = -b / det;                      // j = jx (x - cx) + jy (y - cy)
+  r.ix_ = -c / det; r.iy_ = a / det;                    // i = ix_ (x - cx) + iy_ (y - cy)
+  r.ej = fabsf(r.jx) + fabsf(r.jy) + 0.02f;             // half extents of the pre-image of [X-1, X+1] x [Y-1, Y+1]
+  r.ei = fabsf(r.ix_) + fabsf(r.iy_) + 0.02f;
+  const float nj = floorf(2.f * r.ej) + 1.f, ni = floorf(2.f * r.ei) + 1.f;
+  r.narrow = (nj * ni <= (float)GATHER_CAP) ? 1 : 0;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* gout, const uint8_t* amax, const float* warps,
+                                                              const float* masks, int T, int C, int h, int w, int H0, int W0,
+                                                              int align, float* dfeat) {
+  __shared__ Theta th[MAXT];
+  __shared__ WarpInv inv[MAXT];
+  __shared__ int e_pix[GATHER_PIX][GATHER_T][GATHER_CAP];       // [pixel][transform][entry]: 20 KB
+  __shared__ float e_w[GATHER_PIX][GATHER_T][GATHER_CAP];       // mask x bilinear weight: 20 KB
+  __shared__ unsigned char e_cnt[GATHER_PIX][GATHER_T];
+  const int n = blockIdx.y;
+  if (threadIdx.x < T) {
+    th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
+    inv[threadIdx.x] = invert_warp(th[threadIdx.x], h, w, align);
+  }
+  __syncthreads();
+  const long nb = (long)n * h * w;
+  const int P0 = blockIdx.x * GATHER_PIX;
+  // ---- phase 1
+  {
+    const int p = threadIdx.x & (GATHER_PIX - 1), P = P0 + p;
+    const int Y = P / w, X = P - Y * w;
+    for (int t = threadIdx.x / GATHER_PIX; t < T; t += 256 / GATHER_PIX) {
+      int cnt = 0;
+      const WarpInv v = inv[t];
+      if (v.narrow && P < h * w) {
+        const float dx = (float)X - v.cx, dy = (float)Y - v.cy;
+        const float jc = v.jx * dx + v.jy * dy, ic = v.ix_ * dx + v.iy_ * dy;
+        const int j0 = max((int)ceilf(jc - v.ej), 0), j1 = min((int)floorf(jc + v.ej), w - 1);
+        const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
+        if (jc + v.ej >= 0.f && jc - v.ej <= (float)w && ic + v.ei >= 0.f && ic - v.ei <= (float)h)
+          for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j) {
+              const float m = masks[(nb + (long)i * w + j) * T + t];
+              if (m == 0.f) continue;
+              const Taps tp = make_taps(th[t], i, j, h, w, align);
+              const int kx = X - tp.x0, ky = Y - tp.y0;
+              if ((unsigned)kx > 1u || (unsigned)ky > 1u) continue;
+              const float wk = ky ? (kx ? tp.w11 : tp.w10) : (kx ? tp.w01 : tp.w00);
+              if (cnt < GATHER_CAP) { e_pix[p][t][cnt] = i * w + j; e_w[p][t][cnt] = m * wk; ++cnt; }
+            }
+      }
+      e_cnt[p][t] = (unsigned char)cnt;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2
+  const int cq = C >> 2;
+  for (int q = threadIdx.x; q < GATHER_PIX * cq; q += 256) {
+    const int p = q / cq, c4 = (q - p * cq) * 4;
+    const int P = P0 + p;
+    if (P >= h * w) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+      const int cnt = e_cnt[p][t];
+      for (int e = 0; e < cnt; ++e) {
+        const long o = (nb + e_pix[p][t][e]) * C + c4;
+        const uchar4 am = *reinterpret_cast<const uchar4*>(amax + o);
+        if (am.x != t && am.y != t && am.z != t && am.w != t) continue;
+        const float4 g = *reinterpret_cast<const float4*>(gout + o);
+        const float wt = e_w[p][t][e];
+        acc.x += am.x == t ? g.x * wt : 0.f;
+        acc.y += am.y == t ? g.y * wt : 0.f;
+        acc.z += am.z == t ? g.z * wt : 0.f;
+        acc.w += am.w == t ? g.w * wt : 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(dfeat + (nb + P) * C + c4) = acc;
+  }
+}
+
+// Scatter form (float atomics), `wide_only`: only the elements whose selected transform is not "narrow" — the complement
+// of the gather kernel; workgroups of a sample without wide transforms leave at once.
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const uint8_t* amax, const float* warps,
                                                        const float* masks, int T, int C, int h, int w, int H0, int W0,
-                                                       int align, float* dfeat) {
+                                                       int align, float* dfeat, int wide_only) {
   __shared__ Theta th[MAXT];
+  __shared__ int wide[MAXT];
+  __shared__ int any_wide;
   const int n = blockIdx.y;
-  if (threadIdx.x < T) th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
+  if (threadIdx.x == 0) any_wide = 0;
   __syncthreads();
+  if (threadIdx.x < T) {
+    th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
+    wide[threadIdx.x] = wide_only ? !invert_warp(th[threadIdx.x], h, w, align).narrow : 1;
+    if (wide[threadIdx.x]) any_wide = 1;
+  }
+  __syncthreads();
+  if (!any_wide) return;
   // One lane per (pixel, channel): every element has exactly ONE selected transform (the forward argmax), so a lane
-  // computes the taps of its own transform and issues its four corner atomics once — 4 atomic instructions per 64
-  // elements with all lanes active, instead of looping the wave over the T transforms with ~1/T of the lanes live.
-  // Lanes of one pixel that share a transform hit consecutive addresses (coalesced within the atomic).
+  // computes the taps of its own transform and issues its four corner atomics once.
   const long items = (long)h * w * C;
   float* db = dfeat + (long)n * h * w * C;
   const long nb = (long)n * h * w;
@@ -171,18 +290,16 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const 
     const int i = pix / w, j = pix - i * w;
     const long o = (nb + pix) * C + c;
     const int t = amax[o];
+    if (t >= T || !wide[t]) continue;                // 255: no transform won (all masks zero) -> no gradient
     const float g = gout[o];
-    const bool live = t < T;                       // 255: no transform won (all masks zero) -> no gradient
-    const int tt = live ? t : 0;
-    const float m = masks[(nb + pix) * T + tt];
-    const Taps tp = make_taps(th[tt], i, j, h, w, align);
-    const float gm = live ? g * m : 0.f;
+    const float m = masks[(nb + pix) * T + t];
+    const Taps tp = make_taps(th[t], i, j, h, w, align);
+    const float gm = g * m;
     const float wg[4] = {tp.w00, tp.w01, tp.w10, tp.w11};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int xx = tp.x0 + (k & 1), yy = tp.y0 + (k >> 1);
       const float v = gm * wg[k];
-      // ReLU'd consumers make about half of the gradients exact zeros
       if (v != 0.f && xx >= 0 && xx < w && yy >= 0 && yy < h) atomicAdd(db + ((long)yy * w + xx) * C + c, v);
     }
   }
@@ -266,8 +383,20 @@ extern "C" int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, co
                                     int32_t H0, int32_t W0, int32_t align_corners, float* dfeat, void* stream) {
   PG_REQUIRE(gout && argmax && warps && lvl_masks && dfeat, "pg_warp_mask_max_bwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_bwd: need T<=32, C%%4==0");
+  static const bool no_gather = getenv("PG_WARP_BWD_SCATTER") != nullptr;       // ablation: round-1 scatter kernel only
+  if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 30)) {
+    // gather kernel OVERWRITES dfeat (narrow transforms), then the scatter kernel adds the wide ones
+    hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((h * w + GATHER_PIX - 1) / GATHER_PIX, N), dim3(256), 0, (hipStream_t)stream,
+                       gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
+    PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
+                       warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 1);
+    PG_LAUNCH_OK("pg_warp_mask_max_bwd (wide transforms)");
+    return 0;
+  }
+  PG_HIP(hipMemsetAsync(dfeat, 0, sizeof(float) * (size_t)N * h * w * C, (hipStream_t)stream));
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
-                     warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
+                     warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
   PG_LAUNCH_OK("pg_warp_mask_max_bwd");
   return 0;
 }

@@ -87,31 +87,67 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
   const int b_ch = n0 + ((b_slot ^ ((b_row & 3) << 2)) << 3);
   const int hw = p.Hs * p.Ws;
 
-  auto src_ptr = [&](bool is_small, const unsigned short* base, int C, int ch, long q) -> const char* {
-    if (q >= p.Q) return zero_pg + (lane & 7) * 16;
-    if (is_small) return reinterpret_cast<const char*>(base + q * C + ch);
-    const int n = (int)(q / hw);
-    const int rem = (int)(q - (long)n * hw);
-    const int qy = rem / p.Ws, qx = rem - qy * p.Ws;
-    const int ly = 2 * qy + tr - 1, lx = 2 * qx + ts - 1;
-    const bool ok = (ly >= 0) & (ly < p.Hl) & (lx >= 0) & (lx < p.Wl);
-    return ok ? reinterpret_cast<const char*>(base + ((long)(n * p.Hl + ly) * p.Wl + lx) * C + ch) : zero_pg + (lane & 7) * 16;
+  // Per-row pixel state, advanced by 64 small-grid pixels per K tile WITHOUT divisions: q = (n, qy, qx) flattened;
+  // +64 pixels = (+d64n samples, +c64y rows, +a64x columns) with at most one carry each (the step constants are
+  // wave-uniform).  The large-grid byte offset is rebuilt from (n, qy, qx) with three multiplies per row and tile.
+  const int a64x = 64 % p.Ws, b64 = 64 / p.Ws, c64y = b64 % p.Hs, d64n = b64 / p.Hs;
+  constexpr int L_PASS = (A_PASS > B_PASS) ? A_PASS : B_PASS;
+  int ln[L_PASS], ly0[L_PASS], lx0[L_PASS];            // large operand rows: sample, qy, qx of the row's current pixel
+  const bool a_small = p.a_is_small != 0;
+  const int l_rpi = a_small ? B_RPI : A_RPI, l_row = a_small ? b_row : a_row, l_pass = a_small ? B_PASS : A_PASS;
+  {
+    const long q0 = (long)kt0 * 64;
+#pragma unroll
+    for (int i = 0; i < L_PASS; ++i) {
+      const long q = q0 + i * 8 * l_rpi + l_row;
+      const int n = (int)(q / hw);
+      const int rem = (int)(q - (long)n * hw);
+      ln[i] = n; ly0[i] = rem / p.Ws; lx0[i] = rem - (rem / p.Ws) * p.Ws;
+    }
+  }
+  const long lrow_b = (long)p.Wl * (a_small ? Cb : Ca) * 2, lsmp_b = lrow_b * p.Hl;      // bytes per large row / sample
+  const int lpix_b = (a_small ? Cb : Ca) * 2;
+  auto large_ptr = [&](const unsigned short* base, int ch, int i) -> const char* {
+    const int ly = 2 * ly0[i] + tr - 1, lx = 2 * lx0[i] + ts - 1;
+    const bool ok = (ln[i] < p.N) & (ly >= 0) & (ly < p.Hl) & (lx >= 0) & (lx < p.Wl);
+    const char* ptr = reinterpret_cast<const char*>(base + ch) + ln[i] * lsmp_b + ly * lrow_b + (long)lx * lpix_b;
+    return ok ? ptr : zero_pg + (lane & 7) * 16;
+  };
+  auto advance_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < L_PASS; ++i) {
+      int x = lx0[i] + a64x, y = ly0[i] + c64y, n = ln[i] + d64n;
+      const bool cx = x >= p.Ws;
+      x -= cx ? p.Ws : 0; y += cx ? 1 : 0;
+      const bool cy = y >= p.Hs;
+      y -= cy ? p.Hs : 0; n += cy ? 1 : 0;
+      lx0[i] = x; ly0[i] = y; ln[i] = n;
+    }
+  };
+  // small operand: plain row pointers, +64 pixels per tile (rows past the end read the zero page)
+  const int s_rpi = a_small ? A_RPI : B_RPI, s_row = a_small ? a_row : b_row;
+  const int Csm = a_small ? Ca : Cb;
+  const unsigned short* const s_base = (a_small ? a_base : b_base) + (a_small ? a_ch : b_ch);
+  auto small_ptr = [&](int i, int kt) -> const char* {
+    const long q = (long)kt * 64 + i * 8 * s_rpi + s_row;
+    return q < p.Q ? reinterpret_cast<const char*>(s_base + q * Csm) : zero_pg + (lane & 7) * 16;
   };
   auto issue = [&](int stage, int kt) {
     float* const As = reinterpret_cast<float*>(smem + stage * STAGE);
     float* const Bs = reinterpret_cast<float*>(smem + stage * STAGE + A_ST);
-    const long q0 = (long)kt * 64;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      const char* s = src_ptr(p.a_is_small != 0, a_base, Ca, a_ch, q0 + i * 8 * A_RPI + a_row);
+      const char* s = a_small ? small_ptr(i, kt) : large_ptr(a_base, a_ch, i);
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s), As + (i * 8 + wave) * 256, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      const char* s = src_ptr(p.a_is_small == 0, b_base, Cb, b_ch, q0 + i * 8 * B_RPI + b_row);
+      const char* s = a_small ? large_ptr(b_base, b_ch, i) : small_ptr(i, kt);
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s), Bs + (i * 8 + wave) * 256, 16, 0, 0);
     }
+    advance_rows();
   };
+  (void)l_pass;
 
   // ---- operand fetch (transposing reads).  lane: i = l & 15 -> pixel sub-row r4 = i >> 2, channel quad cq = i & 3;
   // 16-channel block mb = (l >> 4) & 1; k half kh = l >> 5 (pixels + 8).

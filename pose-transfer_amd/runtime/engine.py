@@ -261,17 +261,58 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
     return ent[idx]
 
 
+_BF_CTX = None              # bf16 operand cache of the pass that is running (set by the engines, see BfCache)
+_BF_CTX_X = None            # during a backward pass: the forward pass's cache (activated inputs = weight-gradient operands)
+
+
+class BfCache:
+    """bf16 operand tensors of ONE engine pass, keyed by (tensor, channels, activation, deferred affine, mask): a tensor
+    that feeds several contractions (forward + weight gradient, data gradient + weight gradient) is converted ONCE per
+    pass; the buffers persist across iterations, `begin()` only invalidates their contents."""
+
+    def __init__(self):
+        self.buf, self.valid = {}, set()
+
+    def begin(self):
+        self.valid.clear()
+
+    @staticmethod
+    def key(ptr, C, act, aff, mask):
+        return (int(ptr or 0), int(C), int(act), int(aff or 0), int(mask or 0))
+
+    def lookup(self, ptr, C, act, aff, mask):
+        k = self.key(ptr, C, act, aff, mask)
+        return self.buf[k] if k in self.valid else None
+
+    def get(self, ptr, C, act, aff, mask, N, HW, dev):
+        """the bf16 NHWC tensor bf16(act((a*x+b)*mask)), materialised on the current stream if this pass has not yet"""
+        k = self.key(ptr, C, act, aff, mask)
+        need = N * HW * C
+        b = self.buf.get(k)
+        if b is None or b.numel() < need:
+            b = self.buf[k] = torch.empty(need, dtype=torch.bfloat16, device=dev)
+            self.valid.discard(k)
+        if k not in self.valid:
+            L.call("pg_materialise_bf16", ptr, aff, mask, act, N, HW, C, L.ptr(b), L.stream())
+            self.valid.add(k)
+        return b
+
+
 def _bf16_sources(srcs, N, Hi, Wi, act, dev):
     """Materialise every source as a bf16 NHWC tensor: bf16(act((a*x+b)*mask)); returns pure Src descriptors."""
     pool = _BF_SRC.setdefault(dev, [None] * L.PG_MAX_SRC)
     out = []
     for j, s in enumerate(srcs):
-        need = N * Hi * Wi * s.C
-        if pool[j] is None or pool[j].numel() < need:
-            pool[j] = torch.empty(need, dtype=torch.bfloat16, device=dev)
-        L.call("pg_materialise_bf16", s.ptr, s.aff, s.mask, act, N, Hi * Wi, s.C, L.ptr(pool[j]), L.stream())
+        if _BF_CTX is not None:
+            t = _BF_CTX.get(s.ptr, s.C, act, s.aff, s.mask, N, Hi * Wi, dev)
+        else:
+            need = N * Hi * Wi * s.C
+            if pool[j] is None or pool[j].numel() < need:
+                pool[j] = torch.empty(need, dtype=torch.bfloat16, device=dev)
+            L.call("pg_materialise_bf16", s.ptr, s.aff, s.mask, act, N, Hi * Wi, s.C, L.ptr(pool[j]), L.stream())
+            t = pool[j]
         q = L.Src()
-        q.ptr, q.C = L.ptr(pool[j]), s.C
+        q.ptr, q.C = L.ptr(t), s.C
         out.append(q)
     return out
 
@@ -442,11 +483,17 @@ _BF_WGT = {}       # device -> bf16 scratch of the transposing-read weight gradi
 WGRAD_TR = os.environ.get("PG_NO_WGRAD_TR") is None        # ablation switch: channel-major copies + NT GEMMs instead
 
 
-def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
-    """Weight gradient on the bf16 data path straight from pixel-major bf16 tensors (csrc/wgrad_bf16.hip): every source
-    of the virtual concat and the gradient are materialised once as bf16 NHWC (the same pass the forward / data-gradient
-    contractions use) and pg_wgrad_bf16 adds each source's column block into dW — no channel-major copies, no product
-    buffer.  Runs on the weight-gradient side stream with its OWN scratch (the main stream's pool is busy)."""
+def _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N):
+    return (PRECISION == 3 and WGRAD_TR and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None
+            and cout_store == 0 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor) and Cout % 128 == 0
+            and all(s_.C % 128 == 0 for s_ in srcs) and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS)
+
+
+def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16=None):
+    """Weight gradient on the bf16 data path straight from pixel-major bf16 tensors (csrc/wgrad_bf16.hip): pg_wgrad_bf16
+    adds each source's column block into dW — no channel-major copies, no product buffer.  The operands are the bf16
+    tensors the forward pass (activated inputs) and the data-gradient (dY) already materialised (BfCache); anything
+    missing is converted into this function's OWN scratch (it runs on the weight-gradient side stream)."""
     dev = dW.device
     pool = _BF_WGT.setdefault(dev, [None] * (L.PG_MAX_SRC + 1))
     Hx, Wx = (Hl, Wl) if x_is_large else (Hs, Ws)
@@ -457,13 +504,17 @@ def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
             pool[slot] = torch.empty(need, dtype=torch.bfloat16, device=dev)
         return pool[slot]
 
-    dyb = buf(L.PG_MAX_SRC, N * Hy * Wy * Cout)
-    L.call("pg_materialise_bf16", dY if isinstance(dY, int) else L.ptr(dY), None, None, L.ACT_NONE, N, Hy * Wy, Cout,
-           L.ptr(dyb), L.stream())
+    dyb = dy_bf16
+    if dyb is None:
+        dyb = buf(L.PG_MAX_SRC, N * Hy * Wy * Cout)
+        L.call("pg_materialise_bf16", dY if isinstance(dY, int) else L.ptr(dY), None, None, L.ACT_NONE, N, Hy * Wy, Cout,
+               L.ptr(dyb), L.stream())
     c0 = 0
     for j, s_ in enumerate(srcs):
-        xb = buf(j, N * Hx * Wx * s_.C)
-        L.call("pg_materialise_bf16", s_.ptr, s_.aff, s_.mask, act, N, Hx * Wx, s_.C, L.ptr(xb), L.stream())
+        xb = _BF_CTX_X.lookup(s_.ptr, s_.C, act, s_.aff, s_.mask) if _BF_CTX_X is not None else None
+        if xb is None:
+            xb = buf(j, N * Hx * Wx * s_.C)
+            L.call("pg_materialise_bf16", s_.ptr, s_.aff, s_.mask, act, N, Hx * Wx, s_.C, L.ptr(xb), L.stream())
         L.call("pg_wgrad_bf16", L.ptr(xb), s_.C, L.ptr(dyb), Cout, 1 if x_is_large else 0, N, Hs, Ws, L.ptr(dW), Cin, c0, 0,
                L.stream())
         c0 += s_.C
@@ -471,23 +522,28 @@ def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
 
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
            y_strides=None, ksplit=0, cout_store=0):
+    dyb = None
+    if _BF_CTX is not None and _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N):
+        # the bf16 gradient is shared with the data-gradient contraction of the same layer: convert it once, on the MAIN stream
+        Hy, Wy = (Hs, Ws) if x_is_large else (Hl, Wl)
+        dyb = _BF_CTX.get(dY if isinstance(dY, int) else L.ptr(dY), Cout, L.ACT_NONE, None, None, N, Hy * Wy, dW.device)
     if not SIDE_STREAM or not torch.cuda.is_available():
         return _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x,
-                           y_strides, ksplit, cout_store)
+                           y_strides, ksplit, cout_store, dyb)
     side = _side_stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x, y_strides,
-                    ksplit, cout_store)
+                    ksplit, cout_store, dyb)
 
 
 def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
-                y_strides=None, ksplit=0, cout_store=0):
+                y_strides=None, ksplit=0, cout_store=0, dy_bf16=None):
     if (PRECISION == 3 and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None and cout_store == 0
             and Cin > 32 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor)
             and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS):
         if WGRAD_TR and Cout % 128 == 0 and all(s_.C % 128 == 0 for s_ in srcs):
-            run = lambda: _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW)
+            run = lambda: _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16)
             if PROFILER is not None:
                 PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
                 return
@@ -658,6 +714,7 @@ class GeneratorEngine:
         self._drop_counter = 0
         self.drop_stream = "drop"      # mixed into the dropout key (the trainer sets seed / rank / global iteration)
         self.grad_ready_cb = None      # DP hook: called with the parameter keys whose gradients are complete
+        self._bf_fwd, self._bf_bwd = BfCache(), BfCache()      # bf16 data path: operand tensors of the last forward / backward
 
     # -------------------------------------------------------------------------------- helpers
     def _ready(self, *prefixes):
@@ -712,6 +769,15 @@ class GeneratorEngine:
                 L.call("pg_dropout_mask", L.ptr(d), d.numel(), key, 0.5, L.stream())
 
     def forward(self, inp, warps=None, masks=None):
+        global _BF_CTX
+        self._bf_fwd.begin()
+        _BF_CTX = self._bf_fwd if PRECISION == 3 else None
+        try:
+            return self._forward(inp, warps, masks)
+        finally:
+            _BF_CTX = None
+
+    def _forward(self, inp, warps=None, masks=None):
         """inp (N,3+2P,H,W) NCHW fp32; warps (N,10,8); masks (N,10,H,W) fp32|fp64.  Returns out_gen NCHW."""
         A, N, H, W = self.A, self.N, self.H, self.W
         assert tuple(inp.shape) == (N, 3 + 2 * self.P, H, W) and inp.is_contiguous() and inp.dtype == torch.float32
@@ -793,9 +859,13 @@ class GeneratorEngine:
         return dsts
 
     def backward(self, dpre, image_grad=None):
+        global _BF_CTX, _BF_CTX_X
+        self._bf_bwd.begin()
+        _BF_CTX, _BF_CTX_X = (self._bf_bwd, self._bf_fwd) if PRECISION == 3 else (None, None)
         try:
             return self._backward(dpre, image_grad)
         finally:
+            _BF_CTX = _BF_CTX_X = None
             _join_side()
 
     def _backward(self, dpre, image_grad=None):
@@ -806,8 +876,6 @@ class GeneratorEngine:
         assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
         ystr = (3 * H * W, H * W, W, 1)
         self.nscr.bsums.zero_()
-        for l in range(self.nwarp):
-            self.e_dz["encoder_app"][l].zero_()
         # ---- final conv k3s1p1 (+bias, tanh handled by the caller)
         i = self.ndec - 1
         srcs = self._dec_sources(i)
@@ -921,6 +989,7 @@ class DiscriminatorEngine:
         self.K = hs[-1] * ws[-1]               # outputs per image (49 at 256^2)
         self.inputs = None
         self.grad_ready_cb = None
+        self._bf_fwd, self._bf_bwd = BfCache(), BfCache()
 
     def _ready(self, *prefixes):
         # the reducer orders its collective against BOTH producer streams with events (runtime/dp.py: _wait_producers);
@@ -950,6 +1019,15 @@ class DiscriminatorEngine:
         return Act(self.raw[j], self.chans[j], aff=st.aff if st is not None else None)
 
     def forward(self, pairs):
+        global _BF_CTX
+        self._bf_fwd.begin()
+        _BF_CTX = self._bf_fwd if PRECISION == 3 else None
+        try:
+            return self._forward(pairs)
+        finally:
+            _BF_CTX = None
+
+    def _forward(self, pairs):
         """pairs: list of (input NCHW (n,3+2P,H,W), judged NCHW (n,3,H,W)); sum n == M.  Returns logits (M,K)."""
         A, H, W = self.A, self.H, self.W
         self.inputs = pairs
@@ -973,9 +1051,13 @@ class DiscriminatorEngine:
         return self.raw[-1].view(self.M, self.K)
 
     def backward(self, dlogits, need_wgrad=True, image_grad=None):
+        global _BF_CTX, _BF_CTX_X
+        self._bf_bwd.begin()
+        _BF_CTX, _BF_CTX_X = (self._bf_bwd, self._bf_fwd) if PRECISION == 3 else (None, None)
         try:
             return self._backward(dlogits, need_wgrad, image_grad)
         finally:
+            _BF_CTX = _BF_CTX_X = None
             _join_side()
 
     def _backward(self, dlogits, need_wgrad=True, image_grad=None):

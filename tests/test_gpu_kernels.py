@@ -141,6 +141,45 @@ def test_warp_mask_max_vs_oracle_and_golden(name, size, s, c, ac):
     assert (dg > 3e-4).float().mean() < 5e-4
 
 
+@pytest.mark.parametrize("scatter", [False, True])
+def test_warp_backward_wide_and_degenerate_transforms(scatter, monkeypatch):
+    """Backward of the warp layer on transforms outside the synthetic range: strongly shrinking fits (0.35x: the gather
+    kernel's pre-image box exceeds its capacity -> float-atomic scatter on top), a singular matrix, a 3x magnification,
+    the "no point" row and a sheared one, with masks covering the whole image so that every transform wins somewhere.
+    Gather + fallback must equal the oracle; with PG_WARP_BWD_SCATTER the round-1 scatter kernel alone must as well."""
+    from pose_transfer_amd.utils.pose_transform import AffineTransformLayer
+    if scatter:
+        import subprocess, sys as _sys      # the switch is read once per process: run this variant in a child
+        env = dict(os.environ, PG_WARP_BWD_SCATTER="1")
+        r = subprocess.run([_sys.executable, "-m", "pytest", "-q", "-x", __file__ + "::test_warp_backward_wide_and_degenerate_transforms",
+                            "-k", "False", "-m", "gpu"], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        return
+    N, C, h, w, H0, W0 = 2, 8, 24, 20, 48, 40
+    feat = t(synth.normal(17, "ww/f", (N, C, h, w)))
+    go = t(synth.normal(17, "ww/go", (N, C, h, w)))
+    wr = np.zeros((N, 10, 8), np.float32)
+    rows = [[1, 0, 0, 0, 1, 0], [0.35, 0, 6, 0, 0.35, 9], [0.3, -0.2, 20, 0.2, 0.3, 4], [0, 0, 10, 0, 0, 10],
+            [3.0, 0, -30, 0, 3.0, -20], [1, 0, 1000, 0, 1, 1000], [1, 0.6, -5, 0.1, 1, 2], [0.5, 0, 0, 0, 2.0, -10],
+            [1.2, 0.3, 3, -0.3, 1.2, 1], [0.9, 0, 2.5, 0, 0.9, -1.5]]
+    for n in range(N):
+        for k, r in enumerate(rows):
+            wr[n, (k + 3 * n) % 10, :6] = r
+    mk = np.zeros((N, 10, H0, W0), np.float32)
+    mk[:, 0] = 1.0
+    for k in range(1, 10):                       # overlapping bands: every transform is selected somewhere
+        mk[:, k, (k * 4) % H0:(k * 4) % H0 + 14, :] = 1.0
+    fr = feat.clone().requires_grad_(True)
+    ref = R.warp_mask_max(fr, t(wr), t(mk), (H0, W0))
+    (gref,) = torch.autograd.grad((ref * go).sum(), fr)
+    fd = feat.to(DEV).requires_grad_(True)
+    out = AffineTransformLayer(10, (H0, W0), "mask")(fd, t(wr).to(DEV), t(mk).to(DEV))
+    (gin,) = torch.autograd.grad((out * go.to(DEV)).sum(), fd)
+    assert maxdiff(out, ref) < 2e-5
+    d = (gin.cpu() - gref).abs()
+    assert (d > 2e-5 * float(gref.abs().max())).float().mean() < 2e-3 and float(gref.abs().max()) > 1.0, float(d.max())
+
+
 def test_warp_with_deferred_affine():
     N, C, h, w = 2, 8, 16, 12
     raw = t(synth.normal(6, "wa/f", (N, C, h, w)))

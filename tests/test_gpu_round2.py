@@ -228,18 +228,22 @@ def test_generator_full_warp_vs_golden_and_oracle():
     assert maxdiff(out, t(fix["full_out"])) < 1e-3
     go = t(synth.normal(71, "full/go", tuple(out.shape)))
     (out * go.to(DEV)).sum().backward()
-    pr = {k: v.clone().requires_grad_(True) for k, v in par.items()}
-    oref = R.generator_forward(inp, wr[:, :1], None, pr, P, enc, dec, size, drops)
-    gref = dict(zip(pr.keys(), torch.autograd.grad((oref * go).sum(), list(pr.values()))))
-    # unmasked warps put bilinear samples of BOTH signs in front of the decoder's ReLU: a sample that rounds to the other
-    # side of zero re-routes one pixel's gradient, so a few elements of a weight gradient move by more than the usual 2e-3
+
+    # noise-aware bar (see test_generator_edge_shapes_vs_oracle): device vs the float64 oracle within 2e-3 of the tensor max
+    # + twice the float32 oracle's own distance from the float64 one.  Unmasked warps put bilinear samples of BOTH signs in
+    # front of the decoder's ReLU, so fp32 rounding re-routes single pixels' gradients (seen on the ORACLE itself).
+    def oracle(dt):
+        pr = {k: v.to(dt).requires_grad_(True) for k, v in par.items()}
+        o = R.generator_forward(inp.to(dt), wr[:, :1].to(dt), None, pr, P, enc, dec, size, [d.to(dt) for d in drops])
+        return dict(zip(pr.keys(), torch.autograd.grad((o * go.to(dt)).sum(), list(pr.values()))))
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
     bad = []
     for k, g in gen.arena.grad_dict().items():
-        scale = max(float(gref[k].abs().max()), 1e-8)
-        d = (g.cpu() - gref[k]).abs() / scale
-        ok = float(d.max()) < 2e-2 if gref[k].numel() <= 64 else (float(d.max()) < 2e-2 and float((d > 2e-3).float().mean()) < 1e-2)
-        if not ok:
-            bad.append((k, float(d.max()), float((d > 2e-3).float().mean())))
+        scale = max(float(g64[k].abs().max()), 1e-8)
+        d = float((g.cpu().double() - g64[k]).abs().max()) / scale
+        noise = float((g32[k].double() - g64[k]).abs().max()) / scale
+        if d > 2e-3 + 2.0 * noise:
+            bad.append((k, d, noise))
     assert not bad, bad
 
 
