@@ -228,14 +228,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   f32x4 va0[TM], vb0[TN], va1[TM], vb1[TN];
   fetch(0, 0, va0, vb0);
   int stage = 0;
+  // tile kt0 + 1 is issued before the loop; inside, the DMA of tile kt + 2 is issued RIGHT AFTER the tile-switch barrier of
+  // tile kt (its stage was released by that barrier) and before the last 8 MFMAs of tile kt: a full tile of MFMA time
+  // (2048 SIMD cycles with two waves per SIMD) lies between a DMA's issue and the vmcnt(0) that waits for it
+  // (PMC, round 2: with the issue after those MFMAs the waves were parked at the wait for 37 % of their cycles).
+  if (kt0 + 1 < kt1) { issue(1); advance(); }
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
-    // next tile's DMA into the other stage (every wave finished reading it before the previous barrier), then the
-    // pointers of the tile after it
-    if (more) {
-      issue(stage ^ 1);
-      advance();
-    }
     __builtin_amdgcn_sched_barrier(0);
     fetch(stage, 1, va1, vb1);
     PGB_LDS_WAIT(NRD);
@@ -247,9 +246,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     PGB_LDS_WAIT(NRD);
     mfmas(va0, vb0);
     // tile switch: this wave's last operand fetch of the stage has landed (lgkmcnt(0)), its share of the next tile has
-    // landed (vmcnt(0), issued a whole tile ago); after the barrier both hold for every wave
+    // landed (vmcnt(0)); after the barrier both hold for every wave
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < kt1) { issue(stage); advance(); }          // tile kt + 2 into the stage this tile just released
     __builtin_amdgcn_sched_barrier(0);
     if (more) fetch(stage ^ 1, 0, va0, vb0);
     mfmas(va1, vb1);

@@ -195,66 +195,99 @@ __device__ __forceinline__ WarpInv invert_warp(const Theta& th, int h, int w, in
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* gout, const uint8_t* amax, const float* warps,
                                                               const float* masks, int T, int C, int h, int w, int H0, int W0,
                                                               int align, float* dfeat) {
+  constexpr int FLAT = GATHER_T * GATHER_CAP;             // worst case per input pixel: no overflow possible
   __shared__ Theta th[MAXT];
   __shared__ WarpInv inv[MAXT];
-  __shared__ int e_pix[GATHER_PIX][GATHER_T][GATHER_CAP];       // [pixel][transform][entry]: 20 KB
-  __shared__ float e_w[GATHER_PIX][GATHER_T][GATHER_CAP];       // mask x bilinear weight: 20 KB
-  __shared__ unsigned char e_cnt[GATHER_PIX][GATHER_T];
+  __shared__ int e_pix[GATHER_PIX][FLAT];                 // output pixel | transform << 24      (20 KB)
+  __shared__ float e_w[GATHER_PIX][FLAT];                 // mask x bilinear weight              (20 KB)
+  __shared__ int e_cnt[GATHER_PIX];
   const int n = blockIdx.y;
   if (threadIdx.x < T) {
     th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
     inv[threadIdx.x] = invert_warp(th[threadIdx.x], h, w, align);
   }
+  if (threadIdx.x < GATHER_PIX) e_cnt[threadIdx.x] = 0;
   __syncthreads();
   const long nb = (long)n * h * w;
   const int P0 = blockIdx.x * GATHER_PIX;
-  // ---- phase 1
+  // ---- phase 1: one lane per (input pixel, transform); the <= 16 mask values of the pre-image box are loaded as ONE batch
   {
     const int p = threadIdx.x & (GATHER_PIX - 1), P = P0 + p;
     const int Y = P / w, X = P - Y * w;
     for (int t = threadIdx.x / GATHER_PIX; t < T; t += 256 / GATHER_PIX) {
-      int cnt = 0;
       const WarpInv v = inv[t];
-      if (v.narrow && P < h * w) {
-        const float dx = (float)X - v.cx, dy = (float)Y - v.cy;
-        const float jc = v.jx * dx + v.jy * dy, ic = v.ix_ * dx + v.iy_ * dy;
-        const int j0 = max((int)ceilf(jc - v.ej), 0), j1 = min((int)floorf(jc + v.ej), w - 1);
-        const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
-        if (jc + v.ej >= 0.f && jc - v.ej <= (float)w && ic + v.ei >= 0.f && ic - v.ei <= (float)h)
-          for (int i = i0; i <= i1; ++i)
-            for (int j = j0; j <= j1; ++j) {
-              const float m = masks[(nb + (long)i * w + j) * T + t];
-              if (m == 0.f) continue;
-              const Taps tp = make_taps(th[t], i, j, h, w, align);
-              const int kx = X - tp.x0, ky = Y - tp.y0;
-              if ((unsigned)kx > 1u || (unsigned)ky > 1u) continue;
-              const float wk = ky ? (kx ? tp.w11 : tp.w10) : (kx ? tp.w01 : tp.w00);
-              if (cnt < GATHER_CAP) { e_pix[p][t][cnt] = i * w + j; e_w[p][t][cnt] = m * wk; ++cnt; }
-            }
+      if (!v.narrow || P >= h * w) continue;
+      const float dx = (float)X - v.cx, dy = (float)Y - v.cy;
+      const float jc = v.jx * dx + v.jy * dy, ic = v.ix_ * dx + v.iy_ * dy;
+      if (!(jc + v.ej >= 0.f && jc - v.ej <= (float)w && ic + v.ei >= 0.f && ic - v.ei <= (float)h)) continue;
+      const int j0 = max((int)ceilf(jc - v.ej), 0), j1 = min((int)floorf(jc + v.ej), w - 1);
+      const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
+      const int nj = j1 - j0 + 1, tot = nj * (i1 - i0 + 1);
+      if (nj <= 0 || tot <= 0) continue;
+      float mv[GATHER_CAP];
+      int ci[GATHER_CAP], cj[GATHER_CAP];
+      {
+        int ii = i0, jj = j0;
+#pragma unroll
+        for (int e = 0; e < GATHER_CAP; ++e) {
+          const bool val = e < tot;
+          ci[e] = ii; cj[e] = jj;
+          mv[e] = val ? masks[(nb + (long)ii * w + jj) * T + t] : 0.f;
+          ++jj;
+          if (jj > j1) { jj = j0; ii = min(ii + 1, i1); }
+        }
       }
-      e_cnt[p][t] = (unsigned char)cnt;
+      int ep[GATHER_CAP];
+      float ew[GATHER_CAP];
+      int cnt = 0;
+#pragma unroll
+      for (int e = 0; e < GATHER_CAP; ++e) {
+        ep[e] = -1; ew[e] = 0.f;
+        if (mv[e] != 0.f) {
+          const Taps tp = make_taps(th[t], ci[e], cj[e], h, w, align);
+          const int kx = X - tp.x0, ky = Y - tp.y0;
+          if ((unsigned)kx <= 1u && (unsigned)ky <= 1u) {
+            const float wk = ky ? (kx ? tp.w11 : tp.w10) : (kx ? tp.w01 : tp.w00);
+            ep[e] = (ci[e] * w + cj[e]) | (t << 24); ew[e] = mv[e] * wk; ++cnt;
+          }
+        }
+      }
+      if (cnt) {
+        int at = atomicAdd(&e_cnt[p], cnt);
+#pragma unroll
+        for (int e = 0; e < GATHER_CAP; ++e)
+          if (ep[e] >= 0) { e_pix[p][at] = ep[e]; e_w[p][at] = ew[e]; ++at; }
+      }
     }
   }
   __syncthreads();
-  // ---- phase 2
+  // ---- phase 2: lanes = 4 channels of an input pixel; entries in batches of four (independent loads in flight)
   const int cq = C >> 2;
   for (int q = threadIdx.x; q < GATHER_PIX * cq; q += 256) {
     const int p = q / cq, c4 = (q - p * cq) * 4;
     const int P = P0 + p;
     if (P >= h * w) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < T; ++t) {
-      const int cnt = e_cnt[p][t];
-      for (int e = 0; e < cnt; ++e) {
-        const long o = (nb + e_pix[p][t][e]) * C + c4;
-        const uchar4 am = *reinterpret_cast<const uchar4*>(amax + o);
-        if (am.x != t && am.y != t && am.z != t && am.w != t) continue;
-        const float4 g = *reinterpret_cast<const float4*>(gout + o);
-        const float wt = e_w[p][t][e];
-        acc.x += am.x == t ? g.x * wt : 0.f;
-        acc.y += am.y == t ? g.y * wt : 0.f;
-        acc.z += am.z == t ? g.z * wt : 0.f;
-        acc.w += am.w == t ? g.w * wt : 0.f;
+    const int cnt = e_cnt[p];
+    for (int e0 = 0; e0 < cnt; e0 += 4) {
+      long o[4]; float wt[4]; int tt[4]; uchar4 am[4]; float4 g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool val = e0 + u < cnt;
+        const int ee = val ? e0 + u : e0;
+        const int pk = e_pix[p][ee];
+        tt[u] = val ? (pk >> 24) : 256;          // padding entries match no arg-max byte (255 = "no transform won" is a byte value)
+        wt[u] = val ? e_w[p][ee] : 0.f;
+        o[u] = (nb + (pk & 0xffffff)) * C + c4;
+        am[u] = *reinterpret_cast<const uchar4*>(amax + o[u]);
+        g[u] = *reinterpret_cast<const float4*>(gout + o[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc.x += am[u].x == tt[u] ? g[u].x * wt[u] : 0.f;
+        acc.y += am[u].y == tt[u] ? g[u].y * wt[u] : 0.f;
+        acc.z += am[u].z == tt[u] ? g[u].z * wt[u] : 0.f;
+        acc.w += am[u].w == tt[u] ? g[u].w * wt[u] : 0.f;
       }
     }
     *reinterpret_cast<float4*>(dfeat + (nb + P) * C + c4) = acc;
@@ -389,7 +422,8 @@ extern "C" int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, co
     hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((h * w + GATHER_PIX - 1) / GATHER_PIX, N), dim3(256), 0, (hipStream_t)stream,
                        gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
-    hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
+    // (a sample without wide transforms costs one early-exiting workgroup round: keep that grid small)
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
                        warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 1);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (wide transforms)");
     return 0;

@@ -212,9 +212,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
   Frag va0[TM], vb0[TN], va1[TM], vb1[TN];
   fetch(0, K0{}, va0, vb0);
   int stage = 0;
+  if (kt0 + 1 < kt1) issue(1, kt0 + 1);
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
-    if (more) issue(stage ^ 1, kt + 1);
     __builtin_amdgcn_sched_barrier(0);
     fetch(stage, K1{}, va1, vb1);
     PGW_WAIT(NRD);
@@ -227,6 +227,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
     mfmas(va0, vb0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < kt1) issue(stage, kt + 2);       // the stage this tile just released; a full tile of MFMA time ahead of its wait
     __builtin_amdgcn_sched_barrier(0);
     if (more) fetch(stage ^ 1, K0{}, va0, vb0);
     mfmas(va1, vb1);

@@ -359,7 +359,7 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
     d.ksplit = ksplit
     d.precision = prec
     d.stats = L.ptr(stats)
-    if SPLITK_WS_BYTES > 0:
+    if SPLITK_WS_BYTES > 0 and os.environ.get("PG_WS_SKIP") != str(d.epilogue):     # PG_WS_SKIP: debugging switch
         dev_ = W.device if isinstance(W, torch.Tensor) else torch.device("cuda", torch.cuda.current_device())
         ws = _SPLITK_WS.get(dev_)
         if ws is None:

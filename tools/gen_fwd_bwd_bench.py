@@ -37,11 +37,12 @@ for prec, peak, tag in MODES:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10):
+    ITERS = int(os.environ.get('PG_NS_ITERS', '10'))
+    for _ in range(ITERS):
         step()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
+    ms = e0.elapsed_time(e1) / ITERS
     tf = flops / ms / 1e9
     print("generator fwd+bwd, 256x256, batch %d, %s: %.2f ms = %.1f TFLOP/s = %.3f of the %s MFMA peak (%.0f TFLOP/s)"
           % (N, tag, ms, tf, tf / peak, "fp32" if prec == 0 else "bf16", peak), flush=True)
