@@ -36,6 +36,7 @@ struct WgBf16K {
   float* dW;                  // [16][Cout][ldw] fp32, accumulated
   int Cout, ldw, col_off;
   int ksplit, atomic;
+  int xcd_remap;              // the 16 taps of one (M tile, N tile, K split) run back-to-back on ONE XCD (shared L2)
   long Q;                     // N * Hs * Ws
 };
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ void lds_tr64(unsigned long long& v, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int AS>
 __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) {
   constexpr int WGN = (BN == 256) ? 4 : (BM == 256 ? 2 : 4);
   constexpr int WGM = 8 / WGN;
@@ -58,18 +59,32 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
   const unsigned lds0 = (unsigned)(size_t)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tap = blockIdx.z / p.ksplit, split = blockIdx.z - tap * p.ksplit;
+  // Workgroups are dealt round-robin to the 8 XCDs in dispatch order.  The 16 taps of one (M tile, N tile, K split) read
+  // the SAME dY tiles and pixel-shifted copies of the same X tiles: remapped, they are the 16 consecutive workgroups one
+  // XCD receives, so 15 of the 16 reads of every tile are hits in that XCD's 4 MB L2 instead of fabric round trips (round 2
+  // PMC: the waves of this kernel were parked at vmcnt for a third of their cycles behind L2 misses).
+  int bx = blockIdx.x, by = blockIdx.y, tap = blockIdx.z / p.ksplit, split = blockIdx.z - tap * p.ksplit;
+  if (p.xcd_remap) {            // host: (gridDim.x * gridDim.y * ksplit) % 8 == 0
+    const int mt = (int)gridDim.x, nt = (int)gridDim.y;
+    const int L = bx + mt * (by + nt * (int)blockIdx.z);
+    const int xcd = L & 7, j = L >> 3;
+    tap = j & 15;
+    const int u = (j >> 4) * 8 + xcd;          // unit = (bx, by, split)
+    bx = u % mt;
+    by = (u / mt) % nt;
+    split = u / (mt * nt);
+  }
   const int tr = tap >> 2, ts = tap & 3;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
   const int ktot = (int)((p.Q + 63) >> 6);
   const int kper = (ktot + p.ksplit - 1) / p.ksplit;
   const int kt0 = split * kper, kt1 = min(ktot, kt0 + kper);
   if (kt0 >= kt1) return;
 
-  // operand roles
-  const unsigned short* const a_base = p.a_is_small ? p.sm : p.lg;
-  const unsigned short* const b_base = p.a_is_small ? p.lg : p.sm;
-  const int Ca = p.a_is_small ? p.Cs : p.Cl, Cb = p.a_is_small ? p.Cl : p.Cs;
+  // operand roles are compile-time (AS = 1: A / rows = Cout is the small-grid tensor, i.e. Conv2d)
+  const unsigned short* const a_base = AS ? p.sm : p.lg;
+  const unsigned short* const b_base = AS ? p.lg : p.sm;
+  const int Ca = AS ? p.Cs : p.Cl, Cb = AS ? p.Cl : p.Cs;
   const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
 
   f32x16 acc[TM][TN];
@@ -87,67 +102,80 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
   const int b_ch = n0 + ((b_slot ^ ((b_row & 3) << 2)) << 3);
   const int hw = p.Hs * p.Ws;
 
-  // Per-row pixel state, advanced by 64 small-grid pixels per K tile WITHOUT divisions: q = (n, qy, qx) flattened;
-  // +64 pixels = (+d64n samples, +c64y rows, +a64x columns) with at most one carry each (the step constants are
-  // wave-uniform).  The large-grid byte offset is rebuilt from (n, qy, qx) with three multiplies per row and tile.
+  // Loader state = 32-bit BYTE offsets against wave-uniform bases, advanced by 64 small-grid pixels per K tile with adds
+  // and selects only (round 2, first version: divisions and branchy 64-bit pointer code per load — 5000 ISA lines, the
+  // address code outweighed the 32 MFMAs of a tile):
+  //   small operand: offset += 64 * C * 2;  large operand: pixel (n, y, x) -> + a64x columns, + c64y rows, + d64n samples
+  //   with at most one carry each, the byte offset moves by a uniform step plus a uniform correction per carry.
+  constexpr int S_PASS = AS ? A_PASS : B_PASS, L_PASS = AS ? B_PASS : A_PASS;
+  constexpr int S_RPI = AS ? A_RPI : B_RPI, L_RPI = AS ? B_RPI : A_RPI;
+  const int s_row = AS ? a_row : b_row, l_row = AS ? b_row : a_row;
+  const int Csm = AS ? Ca : Cb, Clg = AS ? Cb : Ca;
+  const char* const s_base = uniform_ptr(reinterpret_cast<const char*>(AS ? a_base : b_base));
+  const char* const l_base = uniform_ptr(reinterpret_cast<const char*>(AS ? b_base : a_base));
+  const int s_ch = AS ? a_ch : b_ch, l_ch = AS ? b_ch : a_ch;
+  const unsigned s_step = 64u * (unsigned)Csm * 2u;
+  const unsigned Sx = 2u * (unsigned)Clg * 2u;                       // bytes per small-grid column step on the large grid
+  const unsigned Sy = 2u * (unsigned)p.Wl * (unsigned)Clg * 2u;      // ... per small-grid row step
+  const unsigned Sn = (unsigned)p.Hl * (unsigned)p.Wl * (unsigned)Clg * 2u;
   const int a64x = 64 % p.Ws, b64 = 64 / p.Ws, c64y = b64 % p.Hs, d64n = b64 / p.Hs;
-  constexpr int L_PASS = (A_PASS > B_PASS) ? A_PASS : B_PASS;
-  int ln[L_PASS], ly0[L_PASS], lx0[L_PASS];            // large operand rows: sample, qy, qx of the row's current pixel
-  const bool a_small = p.a_is_small != 0;
-  const int l_rpi = a_small ? B_RPI : A_RPI, l_row = a_small ? b_row : a_row, l_pass = a_small ? B_PASS : A_PASS;
+  const unsigned l_step = (unsigned)a64x * Sx + (unsigned)c64y * Sy + (unsigned)d64n * Sn;
+  const unsigned l_cx = Sy - (unsigned)p.Ws * Sx, l_cy = Sn - (unsigned)p.Hs * Sy;      // carry corrections (mod 2^32)
+  unsigned s_off[S_PASS], l_off[L_PASS];
+  int s_q[S_PASS];                                      // small rows: flattened pixel (validity only)
+  int ln[L_PASS], ly0[L_PASS], lx0[L_PASS];             // large rows: sample, row, column of the row's small-grid pixel
   {
     const long q0 = (long)kt0 * 64;
 #pragma unroll
+    for (int i = 0; i < S_PASS; ++i) {
+      const long q = q0 + i * 8 * S_RPI + s_row;
+      s_q[i] = (int)q;
+      s_off[i] = (unsigned)((q * Csm + s_ch) * 2);
+    }
+#pragma unroll
     for (int i = 0; i < L_PASS; ++i) {
-      const long q = q0 + i * 8 * l_rpi + l_row;
+      const long q = q0 + i * 8 * L_RPI + l_row;
       const int n = (int)(q / hw);
       const int rem = (int)(q - (long)n * hw);
-      ln[i] = n; ly0[i] = rem / p.Ws; lx0[i] = rem - (rem / p.Ws) * p.Ws;
+      const int y = rem / p.Ws, x = rem - y * p.Ws;
+      ln[i] = n; ly0[i] = y; lx0[i] = x;
+      // offset of large pixel (n, 2y + tr - 1, 2x + ts - 1), channel l_ch — may point one row / column outside (masked below)
+      l_off[i] = (unsigned)n * Sn + (unsigned)y * Sy + (unsigned)x * Sx +
+                 (unsigned)(((long)(tr - 1) * p.Wl + (ts - 1)) * Clg * 2 + (long)l_ch * 2);
     }
   }
-  const long lrow_b = (long)p.Wl * (a_small ? Cb : Ca) * 2, lsmp_b = lrow_b * p.Hl;      // bytes per large row / sample
-  const int lpix_b = (a_small ? Cb : Ca) * 2;
-  auto large_ptr = [&](const unsigned short* base, int ch, int i) -> const char* {
-    const int ly = 2 * ly0[i] + tr - 1, lx = 2 * lx0[i] + ts - 1;
-    const bool ok = (ln[i] < p.N) & (ly >= 0) & (ly < p.Hl) & (lx >= 0) & (lx < p.Wl);
-    const char* ptr = reinterpret_cast<const char*>(base + ch) + ln[i] * lsmp_b + ly * lrow_b + (long)lx * lpix_b;
-    return ok ? ptr : zero_pg + (lane & 7) * 16;
-  };
-  auto advance_rows = [&]() {
-#pragma unroll
-    for (int i = 0; i < L_PASS; ++i) {
-      int x = lx0[i] + a64x, y = ly0[i] + c64y, n = ln[i] + d64n;
-      const bool cx = x >= p.Ws;
-      x -= cx ? p.Ws : 0; y += cx ? 1 : 0;
-      const bool cy = y >= p.Hs;
-      y -= cy ? p.Hs : 0; n += cy ? 1 : 0;
-      lx0[i] = x; ly0[i] = y; ln[i] = n;
-    }
-  };
-  // small operand: plain row pointers, +64 pixels per tile (rows past the end read the zero page)
-  const int s_rpi = a_small ? A_RPI : B_RPI, s_row = a_small ? a_row : b_row;
-  const int Csm = a_small ? Ca : Cb;
-  const unsigned short* const s_base = (a_small ? a_base : b_base) + (a_small ? a_ch : b_ch);
-  auto small_ptr = [&](int i, int kt) -> const char* {
-    const long q = (long)kt * 64 + i * 8 * s_rpi + s_row;
-    return q < p.Q ? reinterpret_cast<const char*>(s_base + q * Csm) : zero_pg + (lane & 7) * 16;
-  };
+  const int Q32 = (int)p.Q;
+  const bool edge_y0 = tr == 0, edge_y1 = tr == 3, edge_x0 = ts == 0, edge_x1 = ts == 3;     // taps that can leave the image
   auto issue = [&](int stage, int kt) {
+    (void)kt;
     float* const As = reinterpret_cast<float*>(smem + stage * STAGE);
     float* const Bs = reinterpret_cast<float*>(smem + stage * STAGE + A_ST);
+    float* const Ss = AS ? As : Bs;
+    float* const Ls = AS ? Bs : As;
+    const char* const zp = zero_pg + (lane & 7) * 16;
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) {
-      const char* s = a_small ? small_ptr(i, kt) : large_ptr(a_base, a_ch, i);
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s), As + (i * 8 + wave) * 256, 16, 0, 0);
+    for (int i = 0; i < S_PASS; ++i) {
+      const bool ok = s_q[i] < Q32;
+      const char* src = ok ? s_base + s_off[i] : zp;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), Ss + (i * 8 + wave) * 256, 16, 0, 0);
+      s_q[i] += 64; s_off[i] += s_step;
     }
 #pragma unroll
-    for (int i = 0; i < B_PASS; ++i) {
-      const char* s = a_small ? large_ptr(b_base, b_ch, i) : small_ptr(i, kt);
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s), Bs + (i * 8 + wave) * 256, 16, 0, 0);
+    for (int i = 0; i < L_PASS; ++i) {
+      const bool oob = (ln[i] >= p.N) | (edge_y0 & (ly0[i] == 0)) | (edge_y1 & (ly0[i] == p.Hs - 1)) |
+                       (edge_x0 & (lx0[i] == 0)) | (edge_x1 & (lx0[i] == p.Ws - 1));
+      const char* src = oob ? zp : l_base + l_off[i];
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), Ls + (i * 8 + wave) * 256, 16, 0, 0);
+      // advance by 64 small-grid pixels
+      int x = lx0[i] + a64x, y = ly0[i] + c64y, n = ln[i] + d64n;
+      unsigned off = l_off[i] + l_step;
+      const bool cx = x >= p.Ws;
+      x -= cx ? p.Ws : 0; y += cx ? 1 : 0; off += cx ? l_cx : 0u;
+      const bool cy = y >= p.Hs;
+      y -= cy ? p.Hs : 0; n += cy ? 1 : 0; off += cy ? l_cy : 0u;
+      lx0[i] = x; ly0[i] = y; ln[i] = n; l_off[i] = off;
     }
-    advance_rows();
   };
-  (void)l_pass;
 
   // ---- operand fetch (transposing reads).  lane: i = l & 15 -> pixel sub-row r4 = i >> 2, channel quad cq = i & 3;
   // 16-channel block mb = (l >> 4) & 1; k half kh = l >> 5 (pixels + 8).
@@ -274,7 +302,8 @@ extern "C" int pg_wgrad_bf16(const void* x_bf16, int32_t Cx, const void* dy_bf16
   else { k.sm = (const unsigned short*)x_bf16; k.Cs = Cx; k.lg = (const unsigned short*)dy_bf16; k.Cl = Cout; }
   k.dW = dW; k.Cout = Cout; k.ldw = ldw; k.col_off = col_off;
   k.Q = (long)N * Hs * Ws;
-  PG_REQUIRE((double)N * 4.0 * Hs * Ws * (Cx > Cout ? Cx : Cout) * 2.0 < 9.0e18, "pg_wgrad_bf16: tensor too large");
+  PG_REQUIRE((double)N * 4.0 * Hs * Ws * (Cx > Cout ? Cx : Cout) * 2.0 < 4294967296.0 && (double)N * Hs * Ws < 2147483000.0,
+             "pg_wgrad_bf16: operands must be < 4 GiB each (32-bit byte offsets)");
   const int bm = (Cout % 256 == 0) ? 256 : 128, bn = (Cx % 256 == 0) ? 256 : 128;
   const int mt = Cout / bm, nt = Cx / bn;
   const int ktot = (int)((k.Q + 63) / 64);
@@ -287,13 +316,22 @@ extern "C" int pg_wgrad_bf16(const void* x_bf16, int32_t Cx, const void* dy_bf16
   }
   if (ks > ktot) ks = ktot;
   while (ks > 1 && (long)(ks - 1) * ((ktot + ks - 1) / ks) >= ktot) --ks;      // no empty split
+  if (ks >= 8 && ks % 8 != 0 && ktot / ((ks + 7) / 8 * 8) >= 8) ks = (ks + 7) / 8 * 8;       // whole XCD groups of taps
+  while (ks > 1 && (long)(ks - 1) * ((ktot + ks - 1) / ks) >= ktot) --ks;
   k.ksplit = ks; k.atomic = ks > 1 ? 1 : 0;
+  k.xcd_remap = (((long)mt * nt * ks) % 8 == 0 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
   dim3 grid(mt, nt, 16 * ks);
   hipStream_t st = (hipStream_t)stream;
-  if (bm == 256 && bn == 256) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<256, 256>), grid, dim3(512), 0, st, k);
-  else if (bm == 128 && bn == 256) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<128, 256>), grid, dim3(512), 0, st, k);
-  else if (bm == 256 && bn == 128) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<256, 128>), grid, dim3(512), 0, st, k);
-  else hipLaunchKernelGGL((wgrad_bf16_tr_kernel<128, 128>), grid, dim3(512), 0, st, k);
+#define PGW_LAUNCH(M_, N_)                                                                                   \
+  do {                                                                                                       \
+    if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<M_, N_, 1>), grid, dim3(512), 0, st, k);      \
+    else hipLaunchKernelGGL((wgrad_bf16_tr_kernel<M_, N_, 0>), grid, dim3(512), 0, st, k);                   \
+  } while (0)
+  if (bm == 256 && bn == 256) PGW_LAUNCH(256, 256);
+  else if (bm == 128 && bn == 256) PGW_LAUNCH(128, 256);
+  else if (bm == 256 && bn == 128) PGW_LAUNCH(256, 128);
+  else PGW_LAUNCH(128, 128);
+#undef PGW_LAUNCH
   PG_LAUNCH_OK("pg_wgrad_bf16");
   last_info() = 6 | (ks << 16) | (1 << 30);
   return 0;
