@@ -129,6 +129,8 @@ HBM_MODELS = {
     "pg_small_cin_wgrad": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * 4 * sum(a[0][i].C for i in range(_ival(a[1])))
                           + 256 * _ival(a[2]) * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
                           * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
+    "pg_stem_conv_bf16": lambda a: HBM_MODELS["pg_small_cin_conv"](a),
+    "pg_stem_wgrad_bf16": lambda a: HBM_MODELS["pg_small_cin_wgrad"](a),
     # last conv (256 -> 3): tap tensor (27 -> 32 columns) + NCHW image; data-gradient: im2col'd gradient + fwd read / grad write
     "pg_tap_gather": lambda a: _ival(a[1]) * _ival(a[2]) * _ival(a[3]) * (27 * 4 + 12),
     "pg_out_conv_dgrad": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (128 + 8 * sum(a[5][i].C for i in range(_ival(a[6])))),

@@ -193,6 +193,22 @@ int pg_small_cin_wgrad(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi,
                        int32_t pad, const float* dY, float* dW, float* workspace, int64_t workspace_floats,
                        void* stream);
 
+/* The same two first layers on the bf16 data path (csrc/stem_bf16.hip): operands rounded to bf16 (RNE), fp32
+ * accumulation, v_mfma_f32_32x32x16_bf16.  The input patch of a pixel tile is staged once, channel-last, as bf16; the
+ * forward reads its A operand straight out of the patch, the weight gradient reads both operands with the transposing
+ * LDS read.  Reference: models/networks.py:186 (k3 s1 p1) and :341 (k4 s2 p0) and their autograd.
+ *   pg_stem_pack_elems(K, Cin)  : number of bf16 elements of the packed filter
+ *   pg_stem_pack_bf16           : W packed fp32 [K][K][64][Cin] -> Wp (groups of 24 / 40 channels, zero padded)
+ *   pg_stem_conv_bf16           : out NHWC [N][Ho][Wo][64] fp32 = conv(x) + bias;  Cin <= 80
+ *   pg_stem_wgrad_bf16          : dW packed [K][K][64][Cin] += ...; k3: Cin <= 36, k4: Cin <= 72; `workspace` is REQUIRED
+ *                                 (PG_SMALL_CIN_WGRAD_WS floats cover every shape; fewer -> fewer persistent workgroups). */
+int64_t pg_stem_pack_elems(int32_t K, int32_t Cin);
+int pg_stem_pack_bf16(const float* W, int32_t K, int32_t Cin, uint16_t* Wp, void* stream);
+int pg_stem_conv_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                      int32_t pad, const uint16_t* Wp, const float* bias, float* out, void* stream);
+int pg_stem_wgrad_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                       int32_t pad, const float* dY, float* dW, float* workspace, int64_t workspace_floats, void* stream);
+
 /* db[c] += sum over rows of a strided [rows][C] view (bias gradient; torch autograd of conv bias). */
 int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,
                  int64_t s_inner, int64_t sC, float* db, void* stream);

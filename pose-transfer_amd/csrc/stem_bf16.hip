@@ -1,0 +1,484 @@
+// First-layer ("stem") convolutions of the bf16 data path (gfx950): few NCHW fp32 input channels -> 64 NHWC channels.
+//   encoder level 0 : nn.Conv2d(cin, 64, k3, s1, p1, bias)      reference models/networks.py:186   (cin = 3+P / P)
+//   discriminator   : nn.Conv2d(3+2P+3, 64, k4, s2, p0, bias)   reference models/networks.py:341
+// and their weight gradients (what autograd computes for loss.backward(), models/pose_gan.py:112,170).
+//
+// The fp32 versions (edge.hip / small_cin_wgrad.hip) feed v_mfma_f32_32x32x2f32 one K element per LDS read and run at
+// 0.12 of the HBM rate they could stream at (round-2 hbm_kernels block).  On the bf16 data path the operands are rounded
+// to bf16 anyway, so here the input patch of a pixel tile is staged ONCE as bf16, CHANNEL-LAST ([row][col][channels]):
+//   forward : A (pixels x K) lane = pixel, its 8 consecutive k are 8 channels of one tap -> one ds_read_b128 per MFMA
+//             operand straight out of the patch (no im2col tile); B = weights repacked [chunk][co][8 k] (pg_stem_pack_bf16),
+//             v_mfma_f32_32x32x16_bf16.  K = taps x padded channels, split into channel groups of CG (24 / 40: pixel
+//             stride 48 / 80 B, an odd number of 16-byte units -> conflict-free b128 reads) so that any Cin fits the LDS.
+//   wgrad   : dW[(tap,ci)][co] = sum_pixels dY[pixel][co] * x[pixel*S + tap][ci]: K = pixels, which is the SLOW index of
+//             both LDS images (dY tile [pixel][64], patch [pixel][channels]) -> both MFMA operands come from the
+//             transposing read ds_read_b64_tr_b16 (lane 4r+c of a 16-lane group supplies the address of 4 channels of
+//             pixel r and receives channel `lane` of pixels 0..3).  All taps share one pass over dY; accumulators stay in
+//             registers across the tiles of a persistent workgroup; partial results go through a workspace.
+// Supported: k3 s1 and k4 s2, 64 output channels, Cin <= 80 (conv) / Cin <= 36 (k3 wgrad) / Cin <= 72 (k4 wgrad) — P = 18
+// and P = 32 key-points (BASELINE.json configs[1..4]).
+#include "igemm_common.h"
+
+namespace pg {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ unsigned short to_bf16(float v) { return (unsigned short)(pack_bf16(v, 0.f) & 0xffffu); }
+
+struct StemK {
+  pg_src_t src[PG_MAX_SRC];
+  int nsrc, Ctot;
+  int cstart[PG_MAX_SRC + 1];
+  int N, Hi, Wi, Ho, Wo, pad;
+  const unsigned short* Wp;   // conv: packed bf16 weights (pg_stem_pack_bf16)
+  const float* bias;
+  float* out;                 // conv: NHWC [N][Ho][Wo][64]
+  const float* dY;            // wgrad: NHWC [N][Ho][Wo][64]
+  float* part;                // wgrad: per-workgroup partial results [blocks][64][npad]
+  int npad;
+  int tiles_x, tiles_y, ntiles, ngroups;
+};
+
+// Stage channels [c_first, c_first + CH) of the virtual concat as bf16 into the channel-last patch at channel slot 0..:
+// one item = (channel, patch row, patch column); lanes run along the image row (coalesced 4-byte loads); batches of U
+// branch-free loads are in flight before the first LDS write.
+template <int S, int PH, int PW, int ROWP, int PWH, int PS, int NT>
+__device__ __forceinline__ void stem_stage_patch(const StemK& p, char* patch, int n, int iy0, int ix0, int c_first, int CH,
+                                                 int tid) {
+  constexpr int U = 8;
+  const int c_last = min(c_first + CH, p.Ctot);
+  for (int j = 0; j < p.nsrc; ++j) {
+    const int lo = max(p.cstart[j], c_first), hi = min(p.cstart[j + 1], c_last);
+    if (lo >= hi) continue;
+    const int sC = (int)p.src[j].sC, sH = (int)p.src[j].sH, sW = (int)p.src[j].sW;
+    const char* ptr = uniform_ptr(reinterpret_cast<const char*>(p.src[j].ptr + (long)n * p.src[j].sN + (long)(lo - p.cstart[j]) * sC));
+    const int slot0 = lo - c_first;
+    const int E = (hi - lo) * PH * PW;
+    for (int e0 = tid; e0 < E; e0 += NT * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + NT * u;
+        const int col = e % PW;
+        const int rr = (e / PW) % PH;
+        const int c = e / (PW * PH);
+        const int iy = iy0 + rr, ix = ix0 + col;
+        const bool ok = (e < E) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+        const int off = ok ? c * sC + iy * sH + ix * sW : 0;
+        v[u] = ldg32(ptr, (long)off * 4);
+        if (!ok) v[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + NT * u;
+        const int col = e % PW;
+        const int rr = (e / PW) % PH;
+        const int c = e / (PW * PH);
+        const int ci = (S == 1) ? col : (col & 1) * PWH + (col >> 1);
+        if (e < E) *reinterpret_cast<unsigned short*>(patch + (rr * ROWP + ci) * PS + (slot0 + c) * 2) = to_bf16(v[u]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward.  Workgroup = 4 waves, output tile TH x 16 pixels x 64 channels; wave w owns rows 2*TMW*w .. (TMW M-tiles of two
+// image rows each) and both 32-channel halves.
+template <int K, int S, int CG, int TH>
+__global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
+  constexpr int TW = 16;
+  constexpr int PH = (TH - 1) * S + K, PW = (TW - 1) * S + K, PWH = (PW + 1) / 2;
+  constexpr int ROWP = (S == 1) ? PW : 2 * PWH;             // patch pixels per row (S = 2: even columns, then odd ones)
+  constexpr int PS = CG * 2;                                // bytes per patch pixel
+  constexpr int PATCH_B = (PH * ROWP * PS + 15) / 16 * 16;
+  constexpr int CPT = CG / 8;                               // 8-channel chunks per tap
+  constexpr int TPS = (K == 3) ? 9 : 4;                     // taps per weight stage (k3: all; k4: one filter row)
+  constexpr int NST = (K == 3) ? 1 : 4;
+  constexpr int NCH = TPS * CPT, NKS = (NCH + 1) / 2;       // chunks / MFMA k-steps per stage
+  constexpr int W_B = 2 * NKS * 1024;                       // bytes of one weight stage: [chunk][co 64][8 k] bf16
+  constexpr int TMW = TH / 8;                               // M-tiles (2 rows x 16 columns) per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const patch = smem;
+  char* const wl = smem + PATCH_B;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const bool resident = p.ngroups == 1 && NST == 1;         // the whole filter stays in LDS across tiles
+
+  for (int i = tid; i < PATCH_B / 16; i += 256) reinterpret_cast<float4*>(patch)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto stage_w = [&](int g, int st) {
+    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.Wp) + (size_t)(g * NST + st) * W_B);
+#pragma unroll
+    for (int u = 0; u < (W_B / 16 + 255) / 256; ++u) {
+      const int e = tid + 256 * u;
+      if (e < W_B / 16) reinterpret_cast<float4*>(wl)[e] = src[e];
+    }
+  };
+  if (resident) stage_w(0, 0);
+
+  // lane constants: A = pixel (row 2*mt + (l31 >> 4), column l31 & 15) of the wave's first M-tile; B = (k half, channel)
+  const int a_base = (((2 * TMW * wave + (l31 >> 4)) * S) * ROWP + (l31 & 15)) * PS;
+  const int b_base = lhi * 1024 + l31 * 16;
+  const float bias0 = p.bias ? p.bias[l31] : 0.f, bias1 = p.bias ? p.bias[32 + l31] : 0.f;
+
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    int b = t;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+    f32x16 acc[TMW][2];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int g = 0; g < p.ngroups; ++g) {
+      __syncthreads();                                      // every wave is done with the previous patch / filter stage
+      stem_stage_patch<S, PH, PW, ROWP, PWH, PS, 256>(p, patch, n, iy0, ix0, g * CG, CG, tid);
+      for (int st = 0; st < NST; ++st) {
+        if (!resident) {
+          if (st > 0) __syncthreads();
+          stage_w(g, st);
+        }
+        __syncthreads();
+        const int a_st = a_base + ((K == 3) ? 0 : st * ROWP * PS);      // k4: stage = filter row
+#pragma unroll
+        for (int kk = 0; kk < NKS; ++kk) {
+          // compile-time patch offsets of chunk 2kk (lanes 0-31) and 2kk+1 (lanes 32-63)
+          int off[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int j = 2 * kk + h;
+            const int tp = (j < NCH) ? j / CPT : 0, c8 = (j < NCH) ? j % CPT : 0;
+            const int r = (K == 3) ? tp / 3 : 0, s = (K == 3) ? tp % 3 : tp;
+            const int ci = (S == 1) ? s : (s & 1) * PWH + (s >> 1);
+            off[h] = (r * ROWP + ci) * PS + c8 * 16;
+          }
+          const int ao = a_st + (lhi ? off[1] : off[0]);
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wl + b_base + kk * 2048);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wl + b_base + kk * 2048 + 512);
+#pragma unroll
+          for (int i = 0; i < TMW; ++i) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + ao + i * (2 * S * ROWP * PS));
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[i][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- epilogue: + bias, raw fp32 NHWC store (32 consecutive channels per half wave = 128-byte segments)
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
+        if (oy < p.Ho && ox < p.Wo) {
+          float* o = p.out + (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + l31;
+          o[0] = acc[i][0][r] + bias0;
+          o[32] = acc[i][1][r] + bias1;
+        }
+      }
+  }
+}
+
+// W packed fp32 [tap][co 64][Cin]  ->  bf16 [group][stage][chunk][co][8]; chunk j of a stage = tap j / CPT, channels
+// group*CG + (j % CPT)*8 .. +7; zero where the channel / chunk does not exist.
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* W, int K, int Cin, int CG, int ngroups, unsigned short* Wp) {
+  const int CPT = CG / 8, TPS = (K == 3) ? 9 : 4, NST = (K == 3) ? 1 : 4;
+  const int NCH = TPS * CPT, NCHP = (NCH + 1) / 2 * 2;
+  const long total = (long)ngroups * NST * NCHP * 64 * 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i & 7);
+  const int co = (int)((i >> 3) & 63);
+  long q = i >> 9;
+  const int j = (int)(q % NCHP); q /= NCHP;
+  const int st = (int)(q % NST);
+  const int g = (int)(q / NST);
+  float v = 0.f;
+  if (j < NCH) {
+    const int tp = j / CPT, c = g * CG + (j % CPT) * 8 + e;
+    const int tap = (K == 3) ? tp : st * 4 + tp;
+    if (c < Cin) v = W[((long)tap * 64 + co) * Cin + c];
+  }
+  Wp[i] = to_bf16(v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient.  NW waves; wave w: output-channel half mt = w & 1, N-tiles (w >> 1) + (NW/2) * i of the T*CP columns
+// n = tap * CP + ci (CP = channels per tap padded to a multiple of 4: a transposing read moves 4-channel blocks).
+template <int K, int S, int TH, int CP, int NW, int NTW>
+__global__ __launch_bounds__(NW * 64) void stem_wgrad_bf16_kernel(const StemK p) {
+  constexpr int TW = 16, T = K * K, NT = NW * 64;
+  constexpr int PH = (TH - 1) * S + K, PW = (TW - 1) * S + K, PWH = (PW + 1) / 2;
+  constexpr int ROWP = (S == 1) ? PW : 2 * PWH;
+  constexpr int PS = CP * 2;
+  constexpr int DY_B = TH * TW * 128;                       // [pixel][64] bf16, 16-byte slots XOR-swizzled by pixel bit 1
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const dyt = smem;
+  char* const patch = smem + DY_B;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int gq = lane >> 4, rr = (lane >> 2) & 3, c4 = lane & 3;      // transposing-read roles inside the 16-lane group
+  const int mt = wave & 1;
+
+  // A (dY^T): this lane supplies pixel (8 * khalf + rr) (+ 4 for the second read), channels co0 .. co0 + 3
+  const int co0 = mt * 32 + 16 * (gq & 1) + 4 * c4;
+  const int a_base = (8 * (gq >> 1) + rr) * 128 + (((co0 >> 3) ^ (((rr >> 1) & 1) << 2)) << 4) + (co0 & 7) * 2;
+  // B (patch^T): columns n0 .. n0 + 3 of each of the wave's N-tiles
+  int b_base[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    int n0 = ((wave >> 1) + (NW / 2) * i) * 32 + 16 * (gq & 1) + 4 * c4;
+    if (n0 >= T * CP) n0 = 0;                               // columns beyond the filter: computed, never stored
+    const int tap = n0 / CP, ci0 = n0 - tap * CP;
+    const int r = tap / K, s = tap % K;
+    const int ci = (S == 1) ? s : (s & 1) * PWH + (s >> 1);
+    b_base[i] = (r * ROWP + ci + 8 * (gq >> 1) + rr) * PS + ci0 * 2;
+  }
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    int b = t;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+    __syncthreads();
+    // ---- gradient tile: fp32 NHWC -> bf16, one item = 8 channels of a pixel
+    {
+      constexpr int NI = (TH * TW * 8 + NT - 1) / NT;
+      float4 v[NI][2];
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int e = tid + NT * u;
+        const int px = e >> 3, sl = e & 7;
+        const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+        const bool ok = (e < TH * TW * 8) & (oy < p.Ho) & (ox < p.Wo);
+        const float4* src = reinterpret_cast<const float4*>(p.dY + (ok ? (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + sl * 8 : 0));
+        v[u][0] = src[0]; v[u][1] = src[1];
+        if (!ok) { v[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); v[u][1] = v[u][0]; }
+      }
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int e = tid + NT * u;
+        const int px = e >> 3, sl = e & 7;
+        uint4 w;
+        w.x = pack_bf16(v[u][0].x, v[u][0].y); w.y = pack_bf16(v[u][0].z, v[u][0].w);
+        w.z = pack_bf16(v[u][1].x, v[u][1].y); w.w = pack_bf16(v[u][1].z, v[u][1].w);
+        if (e < TH * TW * 8) *reinterpret_cast<uint4*>(dyt + px * 128 + ((sl ^ (((px >> 1) & 1) << 2)) << 4)) = w;
+      }
+    }
+    // ---- input patch, channel-last bf16
+    stem_stage_patch<S, PH, PW, ROWP, PWH, PS, NT>(p, patch, n, iy0, ix0, 0, CP, tid);
+    __syncthreads();
+    // ---- MFMA: one k-step = the 16 pixels of a tile row
+#pragma unroll
+    for (int y = 0; y < TH; ++y) {
+      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dyt + a_base + (y * 16) * 128));
+      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dyt + a_base + (y * 16 + 4) * 128));
+      const s16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(patch + b_base[i] + (y * S * ROWP) * PS));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(patch + b_base[i] + (y * S * ROWP + 4) * PS));
+        const s16x8 bb = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), acc[i], 0, 0, 0);
+      }
+    }
+  }
+  // ---- partial result [block][co][n]: plain coalesced stores; stem_wgrad_reduce_kernel adds the blocks up
+  float* o = p.part + (long)blockIdx.x * 64 * p.npad + (long)(mt * 32 + 4 * lhi) * p.npad + l31;
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int ntile = (wave >> 1) + (NW / 2) * i;
+    if (ntile * 32 < p.npad) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * p.npad + ntile * 32] = acc[i][r];
+    }
+  }
+}
+
+// dW[tap][co][ci] += sum over workgroups of part[b][co][n = tap*CP + ci]; blockIdx.y strides over the workgroups
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* part, int nblocks, int npad, int T, int CP, int Ctot,
+                                                                float* dW) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 64 * npad) return;
+  const int co = e / npad, n = e - co * npad;
+  const int tap = n / CP, ci = n - tap * CP;
+  if (tap >= T || ci >= Ctot) return;
+  const long stride = (long)64 * npad;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int b = blockIdx.y;
+  const int step = gridDim.y;
+  for (; b + 3 * step < nblocks; b += 4 * step) {
+    t0 += part[b * stride + e];
+    t1 += part[(b + step) * stride + e];
+    t2 += part[(b + 2 * step) * stride + e];
+    t3 += part[(b + 3 * step) * stride + e];
+  }
+  for (; b < nblocks; b += step) t0 += part[b * stride + e];
+  atomicAdd(dW + ((long)tap * 64 + co) * Ctot + ci, (t0 + t1) + (t2 + t3));
+}
+
+static int stem_fill(StemK& k, const pg_src_t* src, int nsrc, int N, int Hi, int Wi, int K, int stride, int pad) {
+  memset(&k, 0, sizeof(k));
+  int c = 0;
+  for (int j = 0; j < nsrc; ++j) {
+    if (src[j].aff || src[j].mask) return -1;
+    k.src[j] = src[j]; k.cstart[j] = c; c += src[j].C;
+  }
+  for (int j = nsrc; j <= PG_MAX_SRC; ++j) k.cstart[j] = c;
+  k.nsrc = nsrc; k.Ctot = c;
+  k.N = N; k.Hi = Hi; k.Wi = Wi; k.pad = pad;
+  k.Ho = (Hi + 2 * pad - K) / stride + 1; k.Wo = (Wi + 2 * pad - K) / stride + 1;
+  return 0;
+}
+
+static int stem_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <int K, int S, int CG, int TH>
+static int launch_stem_conv(StemK& k, hipStream_t st) {
+  constexpr int PH = (TH - 1) * S + K, PW = 15 * S + K, PWH = (PW + 1) / 2, ROWP = (S == 1) ? PW : 2 * PWH;
+  constexpr int PATCH_B = (PH * ROWP * CG * 2 + 15) / 16 * 16;
+  constexpr int NCH = ((K == 3) ? 9 : 4) * (CG / 8), NKS = (NCH + 1) / 2;
+  constexpr int LDS = PATCH_B + 2 * NKS * 1024;
+  static_assert(LDS <= 160 * 1024, "stem conv: LDS");
+  k.tiles_x = (k.Wo + 15) / 16; k.tiles_y = (k.Ho + TH - 1) / TH;
+  k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  auto kern = stem_conv_bf16_kernel<K, S, CG, TH>;
+  static bool set = false;
+  if (!set) {
+    PG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    set = true;
+  }
+  int per_cu = (160 * 1024) / LDS;
+  if (per_cu > 4) per_cu = 4;
+  int blocks = stem_cu_count() * per_cu;
+  if (blocks > k.ntiles) blocks = k.ntiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, st, k);
+  return 0;
+}
+
+template <int K, int S, int TH, int CP, int NW, int NTW>
+static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hipStream_t st) {
+  constexpr int PH = (TH - 1) * S + K, PW = 15 * S + K, PWH = (PW + 1) / 2, ROWP = (S == 1) ? PW : 2 * PWH;
+  constexpr int LDS = TH * 16 * 128 + (PH * ROWP * CP * 2 + 15) / 16 * 16;
+  static_assert(LDS <= 160 * 1024, "stem wgrad: LDS");
+  static_assert(NTW * (NW / 2) * 32 >= K * K * CP, "stem wgrad: N-tiles");
+  k.tiles_x = (k.Wo + 15) / 16; k.tiles_y = (k.Ho + TH - 1) / TH;
+  k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  k.npad = (K * K * CP + 31) / 32 * 32;
+  auto kern = stem_wgrad_bf16_kernel<K, S, TH, CP, NW, NTW>;
+  static bool set = false;
+  if (!set) {
+    PG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    set = true;
+  }
+  int per_cu = (160 * 1024) / LDS;
+  const int reg_cap = (NTW * 16 + 64 <= 128) ? 4 / (NW / 4) : (NTW * 16 + 64 <= 256 ? 2 / (NW / 4) : 1);
+  if (per_cu > reg_cap) per_cu = reg_cap;
+  if (per_cu < 1) per_cu = 1;
+  int blocks = stem_cu_count() * per_cu;
+  if (blocks > k.ntiles) blocks = k.ntiles;
+  const long need = (long)blocks * 64 * k.npad;
+  if (ws == nullptr || ws_floats < need) {
+    blocks = (int)(ws_floats / ((long)64 * k.npad));
+    if (ws == nullptr || blocks < 1) return -2;
+  }
+  k.part = ws;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), LDS, st, k);
+  const int ry = blocks >= 32 ? 16 : 1;
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256), 0, st, k.part,
+                     blocks, k.npad, K * K, CP, k.Ctot, dW);
+  return 0;
+}
+
+}  // namespace pg
+
+static int pg_stem_group_channels(int32_t Cin) { return (Cin <= 24 || (Cin > 40 && Cin <= 48)) ? 24 : 40; }
+
+extern "C" int64_t pg_stem_pack_elems(int32_t K, int32_t Cin) {
+  const int CG = pg_stem_group_channels(Cin), ng = (Cin + CG - 1) / CG;
+  const int NCH = ((K == 3) ? 9 : 4) * (CG / 8), NCHP = (NCH + 1) / 2 * 2;
+  return (int64_t)ng * ((K == 3) ? 1 : 4) * NCHP * 512;
+}
+
+extern "C" int pg_stem_pack_bf16(const float* W, int32_t K, int32_t Cin, uint16_t* Wp, void* stream) {
+  PG_REQUIRE(W && Wp && (K == 3 || K == 4) && Cin > 0 && Cin <= 80, "pg_stem_pack_bf16: bad arguments (K=%d Cin=%d)", K, Cin);
+  const int CG = pg_stem_group_channels(Cin), ng = (Cin + CG - 1) / CG;
+  const long total = pg_stem_pack_elems(K, Cin);
+  hipLaunchKernelGGL(pg::stem_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin, CG,
+                     ng, Wp);
+  PG_LAUNCH_OK("pg_stem_pack_bf16");
+  return 0;
+}
+
+extern "C" int pg_stem_conv_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                                 int32_t pad, const uint16_t* Wp, const float* bias, float* out, void* stream) {
+  PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && Wp && out, "pg_stem_conv_bf16: bad arguments");
+  PG_REQUIRE((K == 3 && stride == 1) || (K == 4 && stride == 2), "pg_stem_conv_bf16: only k3s1 / k4s2 (got k%d s%d)", K, stride);
+  pg::StemK k;
+  PG_REQUIRE(pg::stem_fill(k, src, nsrc, N, Hi, Wi, K, stride, pad) == 0, "pg_stem_conv_bf16: sources must not carry aff / mask");
+  PG_REQUIRE(k.Ctot <= 80 && k.Ho > 0 && k.Wo > 0 && N > 0, "pg_stem_conv_bf16: Cin <= 80 and a non-empty output required");
+  k.Wp = Wp; k.bias = bias; k.out = out;
+  const int CG = pg_stem_group_channels(k.Ctot);
+  k.ngroups = (k.Ctot + CG - 1) / CG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (K == 3) rc = (CG == 24) ? pg::launch_stem_conv<3, 1, 24, 16>(k, st) : pg::launch_stem_conv<3, 1, 40, 16>(k, st);
+  else rc = (CG == 24) ? pg::launch_stem_conv<4, 2, 24, 16>(k, st) : pg::launch_stem_conv<4, 2, 40, 8>(k, st);
+  if (rc) return rc;
+  PG_LAUNCH_OK("pg_stem_conv_bf16");
+  return 0;
+}
+
+extern "C" int pg_stem_wgrad_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
+                                  int32_t stride, int32_t pad, const float* dY, float* dW, float* workspace,
+                                  int64_t workspace_floats, void* stream) {
+  PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && dY && dW, "pg_stem_wgrad_bf16: bad arguments");
+  PG_REQUIRE((K == 3 && stride == 1) || (K == 4 && stride == 2), "pg_stem_wgrad_bf16: only k3s1 / k4s2 (got k%d s%d)", K, stride);
+  pg::StemK k;
+  PG_REQUIRE(pg::stem_fill(k, src, nsrc, N, Hi, Wi, K, stride, pad) == 0, "pg_stem_wgrad_bf16: sources must not carry aff / mask");
+  PG_REQUIRE(k.Ho > 0 && k.Wo > 0 && N > 0, "pg_stem_wgrad_bf16: empty output");
+  k.dY = dY;
+  hipStream_t st = (hipStream_t)stream;
+  const int c = k.Ctot;
+  int rc;
+  if (K == 3) {
+    PG_REQUIRE(c <= 36, "pg_stem_wgrad_bf16: k3 supports Cin <= 36 (got %d)", c);
+    rc = (c <= 24) ? pg::launch_stem_wgrad<3, 1, 8, 24, 4, 4>(k, dW, workspace, workspace_floats, st)
+                   : pg::launch_stem_wgrad<3, 1, 8, 36, 4, 6>(k, dW, workspace, workspace_floats, st);
+  } else {
+    PG_REQUIRE(c <= 72, "pg_stem_wgrad_bf16: k4 supports Cin <= 72 (got %d)", c);
+    rc = (c <= 44) ? pg::launch_stem_wgrad<4, 2, 8, 44, 8, 6>(k, dW, workspace, workspace_floats, st)
+                   : pg::launch_stem_wgrad<4, 2, 8, 72, 8, 9>(k, dW, workspace, workspace_floats, st);
+  }
+  PG_REQUIRE(rc != -2, "pg_stem_wgrad_bf16: a workspace of at least 64 x %d floats is required", k.npad);
+  if (rc) return rc;
+  pg::last_info() = 7 | (1 << 4) | (1 << 16) | (1 << 30);     // tile code 7 = bf16 stem kernel, scalar X
+  PG_LAUNCH_OK("pg_stem_wgrad_bf16");
+  return 0;
+}

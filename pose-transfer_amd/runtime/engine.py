@@ -26,7 +26,7 @@ class KernelProfiler:
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
     CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32", 4: "256x256", 5: "256x128"}
-    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin", 6: "bf16-tr-256"}
+    WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin", 6: "bf16-tr-256", 7: "bf16-stem"}
 
     def __init__(self):
         self.records = []
@@ -383,9 +383,23 @@ def _conv_dgrad(gy_src, N, Hi, Wi, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, d
           ksplit=ksplit)
 
 
+STEM_BF16 = os.environ.get("PG_NO_STEM_BF16") is None     # ablation switch: fp32 first-layer kernels on the bf16 data path
+
+
+def stem_pack_floats(K, cin):
+    """Size (in floats) of the weight-repack scratch of a first layer: fp32 [Cin][K*K][64] or the packed bf16 filter."""
+    return max(cin * K * K * 64, (int(L.load().pg_stem_pack_elems(K, cin)) + 1) // 2)
+
+
 def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
     """First-layer convolution (few NCHW input channels -> 64 NHWC): repack the weights, then the patch kernel."""
     cin = sum(a.C for a in acts)
+    if PRECISION == 3 and STEM_BF16 and cin <= 80:
+        L.call("pg_stem_pack_bf16", L.ptr(W), K, cin, L.ptr(wt_buf), L.stream())
+        arr = (L.Src * len(acts))(*[a.src() for a in acts])
+        L.call("pg_stem_conv_bf16", arr, len(acts), N, Hi, Wi, K, stride, pad, L.ptr(wt_buf), L.ptr(bias),
+               out if isinstance(out, int) else L.ptr(out), L.stream())
+        return
     L.call("pg_repack_small_cin", L.ptr(W), K, K, 64, cin, L.ptr(wt_buf), L.stream())
     arr = (L.Src * len(acts))(*[a.src() for a in acts])
     L.call("pg_small_cin_conv", arr, len(acts), N, Hi, Wi, K, stride, pad, L.ptr(wt_buf), L.ptr(bias),
@@ -555,15 +569,16 @@ def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stri
         return _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW)
     if (scalar_x and x_is_large and Cout == 64 and y_strides is None and cout_store == 0 and ksplit == 0
             and act == L.ACT_NONE and SMALL_CIN_WGRAD
-            and ((K == 3 and stride == 1 and Cin <= 21) or (K == 4 and stride == 2 and Cin <= 44))):
+            and ((K == 3 and stride == 1 and Cin <= (36 if PRECISION == 3 and STEM_BF16 else 21))
+                 or (K == 4 and stride == 2 and Cin <= (72 if PRECISION == 3 and STEM_BF16 else 44)))):
         # first layers (raw NCHW inputs): all taps in one pass over dY, patch gathered from LDS
         arr = (L.Src * len(srcs))(*srcs)
         dYp = dY if isinstance(dY, int) else L.ptr(dY)
         ws = _SCW_WS.get(dW.device)
         if ws is None:
             ws = _SCW_WS[dW.device] = torch.empty(SMALL_CIN_WGRAD_WS, dtype=torch.float32, device=dW.device)
-        run = lambda: L.call("pg_small_cin_wgrad", arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, L.ptr(dW), L.ptr(ws),
-                             ws.numel(), L.stream())
+        fn = "pg_stem_wgrad_bf16" if PRECISION == 3 and STEM_BF16 else "pg_small_cin_wgrad"
+        run = lambda: L.call(fn, arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, L.ptr(dW), L.ptr(ws), ws.numel(), L.stream())
         if PROFILER is not None:
             PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
         else:
@@ -705,7 +720,7 @@ class GeneratorEngine:
         self.drop = [torch.ones(N, self.dec[i], **f32) for i in range(min(3, self.ndec - 1))]
         self.out = torch.empty(N, 3, H, W, **f32)
         cin0 = {"encoder_app": 3 + pose_dim, "encoder_pose": pose_dim, "encoder": 3 + 2 * pose_dim}
-        self.wt0 = {e: torch.empty(cin0[e] * 9 * 64, **f32) for e in self.encs}    # [Cin][9][64] repack of conv 0
+        self.wt0 = {e: torch.empty(stem_pack_floats(3, cin0[e]), **f32) for e in self.encs}    # [Cin][9][64] repack of conv 0
         self.y_taps = torch.empty(N, H, W, 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
         self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh): weight- and data-gradient operand
         self.wt_out = torch.zeros((2 if deformable else 1) * self.enc[0] + self.dec[-2], 32, **f32)   # [cin][(tap, co)]
@@ -985,7 +1000,7 @@ class DiscriminatorEngine:
         self.dz = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
         self.nscr = NormScratch(self.nblk, M, device)
         self.norm = [NormState(M, device, self.nscr) if 0 < j < self.nblk - 1 else None for j in range(self.nblk)]
-        self.wt0 = torch.empty((3 + 2 * pose_dim + 3) * 16 * 64, **f32)          # [Cin][16][64] repack of the stem
+        self.wt0 = torch.empty(stem_pack_floats(4, 3 + 2 * pose_dim + 3), **f32)          # [Cin][16][64] repack of the stem
         self.K = hs[-1] * ws[-1]               # outputs per image (49 at 256^2)
         self.inputs = None
         self.grad_ready_cb = None

@@ -69,6 +69,10 @@ _PROTOS = {
     "pg_repack_small_cin": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_small_cin_conv": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pg_small_cin_wgrad": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
+    "pg_stem_pack_elems": [_i32, _i32],
+    "pg_stem_pack_bf16": [_vp, _i32, _i32, _vp, _vp],
+    "pg_stem_conv_bf16": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "pg_stem_wgrad_bf16": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
     "pg_bias_grad": [_vp, _i64, _i64, _i32, _i64, _i64, _i64, _vp, _vp],
     "pg_cords_to_map": [_vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _i64, _i64, _i64, _i64, _vp],
     "pg_affine_transforms": [_vp, _vp, _i32, _i32, _vp, _vp],
@@ -134,6 +138,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.pg_stem_pack_elems.restype = C.c_int64
     lib.pg_last_error.argtypes = []
     lib.pg_last_error.restype = C.c_char_p
     _lib = lib

@@ -700,6 +700,52 @@ def test_small_cin_patch_conv(name):
         assert rel(nchw(out.cpu()), out_ref) < 1e-5, hw
 
 
+STEM_SRCS = {
+    "p18_app": [(21, False, False)], "p18_pose": [(18, False, False)],
+    "p18_disc": [(21, False, False), (18, False, False), (3, False, False)],            # 42 channels, pairs straddle sources
+    "p32_app": [(35, False, False)], "p32_pose": [(32, False, False)],
+    "p32_disc": [(35, False, False), (32, False, False), (3, False, False)],            # 70 channels
+    "odd": [(3, False, False), (16, False, False), (3, False, False), (5, False, False)],
+}
+
+
+@pytest.mark.parametrize("kname", ["first_k3", "stem_k4p0"])
+@pytest.mark.parametrize("sname", list(STEM_SRCS))
+def test_stem_bf16_conv_and_wgrad(kname, sname, monkeypatch):
+    """First layers of the bf16 data path (csrc/stem_bf16.hip: channel-last bf16 patch, b128 / transposing LDS reads,
+    v_mfma_f32_32x32x16_bf16) for the P = 18 and P = 32 channel counts (BASELINE.json configs[1..4]), ragged tiles, several
+    persistent tiles per workgroup and sources whose boundaries are odd.  Exact up to summation order against the fp32
+    contraction of the bf16-ROUNDED operands (1e-4 of the tensor max); the engine dispatch must pick these kernels."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    base = [c for c in conv_cases() if c.name == kname][0]
+    srcs = STEM_SRCS[sname]
+    cin = sum(c[0] for c in srcs)
+    if kname == "first_k3" and cin > 36:
+        pytest.skip("k3 stem layers have at most 3 + 32 channels")
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    for hw, n in (((12, 10), 2), ((33, 19), 1), ((40, 72), 3), ((96, 160), 2)):
+        case = ConvCase("%s_%s_%dx%d" % (kname, sname, hw[0], hw[1]), "conv", srcs, 64, n, hw[0], hw[1], base.K, base.stride,
+                        base.pad, L.ACT_NONE, bias=True, scalar=True)
+        x = bf(torch.cat(case.raw, 1))
+        w = bf(case.w).requires_grad_(True)
+        ref = F.conv2d(x, w, case.b, stride=case.stride, padding=case.pad)
+        (dw_ref,) = torch.autograd.grad((F.conv2d(x, w, None, stride=case.stride, padding=case.pad) * bf(case.gout)).sum(), w)
+        acts = case.device_sources()
+        wp = case.packed_weight()
+        wt = torch.empty(E.stem_pack_floats(case.K, cin), device=DEV)
+        out = torch.full((case.N, case.Ho, case.Wo, 64), float("nan"), device=DEV)
+        bd = case.b.to(DEV)
+        hooked = []
+        monkeypatch.setattr(L, "CALL_HOOK", lambda name, args, launch: (hooked.append(name), launch())[1])
+        E._small_cin_conv(acts, case.N, case.H, case.W, case.K, case.stride, case.pad, wp, bd, wt, out)
+        dw = case.run_wgrad()
+        monkeypatch.setattr(L, "CALL_HOOK", None)
+        torch.cuda.synchronize()
+        assert "pg_stem_conv_bf16" in hooked and "pg_stem_wgrad_bf16" in hooked, hooked
+        assert rel(nchw(out.cpu()), ref.detach()) < 1e-4, (case.name, float(rel(nchw(out.cpu()), ref.detach())))
+        assert rel(dw, dw_ref) < 1e-4, (case.name, float(rel(dw, dw_ref)))
+
+
 # ------------------------------------------------------------------------------------------ 256-row bf16 kernel
 def big_cases():
     A, M = True, True
