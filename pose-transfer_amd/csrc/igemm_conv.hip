@@ -1565,18 +1565,30 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   }
   int ks = d->ksplit;
   if (ks <= 0) {
-    // Split K so that (a) there are >= 2 workgroups per CU to overlap each other's barriers and (b) the grid is
-    // close to a multiple of the 512 workgroup slots (two per CU): 768 blocks would leave the second round half empty.
+    // Split K by a small time model (round 2; round 1 maximised the fill of the last round of 512 workgroup slots with a
+    // flat 0.2 % cost per split, which picked 13 splits for 784-workgroup launches at 224^2 — 1.3 GB of partial-tile
+    // traffic on a 1.7 ms contraction, 67 TFLOP/s instead of 120):
+    //   T(c) = rounds(c) * (t_iter * ceil(ktot / c) + t_fixed) + [c > 1] * (2 c out_bytes / BW + t_launch)
+    // rounds = ceil(blocks c / 512) (two co-resident workgroups x 256 CUs), t_iter = the K-tile time of one workgroup at
+    // the sustained rate of the operand format, t_fixed = prologue + epilogue of a workgroup, the last term = partial
+    // tiles written and read back by the fix-up kernel.  tools/r2_gpu11.sh sweeps the two constants (PG_SPLITK_* override): flat within 2 % over 4-30 us and 1.5-3 TB/s;
+    // configs[2] (224^2, P = 32, batch 8): fp32 167 -> 210 img/s, bf16 data path 446 -> 681 img/s against the round-1 rule.
+    static const double t_fixed = getenv("PG_SPLITK_FIXED_US") ? atof(getenv("PG_SPLITK_FIXED_US")) : 12.0;
+    static const double bw_tbs = getenv("PG_SPLITK_BW_TBS") ? atof(getenv("PG_SPLITK_BW_TBS")) : 3.0;
+    static const double t_launch = 6.0;
+    const double rate_tf = d->precision == PG_PREC_F32 ? 125.0 : (d->precision == PG_PREC_BF16X3 ? 250.0 : 650.0);
+    const double t_iter = 2.0 * BMs[cfg] * BNs[cfg] * ((amode == A_VEC) ? bke : BK) / (rate_tf * 1e6 / 512.0);      // us
     const long blocks = (long)mt * nt * (tb ? tb->gtaps : k.nphase);
-    const int kmax = ktot_min / 8 > 0 ? ktot_min / 8 : 1;
+    const double out_bytes = (double)d->N * d->Ho * d->Wo * k.n_cnt * 4.0;
+    const int kmax = ktot_min / 4 > 0 ? ktot_min / 4 : 1;
     ks = 1;
-    double best = -1.0;
+    double best = 1e30;
     for (int c = 1; c <= 32 && c <= kmax; ++c) {
       const long b = blocks * c;
-      const double eff = (double)b / (double)(((b + 511) / 512) * 512);     // 2 co-resident workgroups x 256 CUs
-      // per-split cost (partial tile traffic + fix-up work); swept 0.0003 .. 0.008 on the full iteration: flat below 0.004
-      const double score = (b >= 512 ? eff - 0.002 * c : (double)b / 512.0 - 0.001 * c);    // fill fraction below one round
-      if (score > best + 1e-9) { best = score; ks = c; }
+      const double rounds = (double)((b + 511) / 512);
+      double t = rounds * (t_iter * ((ktot_min + c - 1) / c) + t_fixed);
+      if (c > 1) t += 2.0 * c * out_bytes / (bw_tbs * 1e6) + t_launch;
+      if (t < best * 0.98) { best = t; ks = c; }             // a further split must buy 2 %
     }
   }
   if (d->out_act != PG_OUT_NONE) ks = 1;

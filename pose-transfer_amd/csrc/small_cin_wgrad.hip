@@ -238,8 +238,9 @@ extern "C" int pg_small_cin_wgrad(const pg_src_t* src, int32_t nsrc, int32_t N, 
   hipStream_t st = (hipStream_t)stream;
   int rc = -1;
   if (K == 3) {
-    PG_REQUIRE(tiles <= 12, "pg_small_cin_wgrad: k3 supports Cin <= 21 (got %d)", c);
-    rc = pg::launch_small_cin_wgrad<3, 1, 8, 3>(k, workspace, workspace_floats, st);
+    PG_REQUIRE(tiles <= 20, "pg_small_cin_wgrad: k3 supports Cin <= 35 (got %d)", c);
+    rc = (tiles <= 12) ? pg::launch_small_cin_wgrad<3, 1, 8, 3>(k, workspace, workspace_floats, st)
+                       : pg::launch_small_cin_wgrad<3, 1, 8, 5>(k, workspace, workspace_floats, st);     // P = 32: 3 + 32 channels
   } else {
     PG_REQUIRE(tiles <= 44, "pg_small_cin_wgrad: k4 supports Cin <= 44 (got %d)", c);
     rc = (tiles <= 24) ? pg::launch_small_cin_wgrad<4, 2, 4, 6>(k, workspace, workspace_floats, st) : pg::launch_small_cin_wgrad<4, 2, 4, 11>(k, workspace, workspace_floats, st);
