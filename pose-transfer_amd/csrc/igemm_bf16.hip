@@ -5,7 +5,7 @@
 // NHWC activations / gradients gathered per (tap, source) with a zero page for padding rows, B = K-contiguous bf16
 // weights, fp32 accumulation, raw fp32 outputs (+ fused per-sample statistics) or the data-gradient scatter.
 // What changes is the tile and the pipeline:
-//   * workgroup tile 256 x BN (BN = 256 or 128) x 64, 512 threads = 8 waves (2 per SIMD), ONE workgroup per CU; a wave
+//   * workgroup tile 256 x BN (BN = 256 or 128; 512 x 64 for the N = 64 layers) x 64, 512 threads = 8 waves (2 per SIMD), ONE workgroup per CU; a wave
 //     owns 128 x 64 (BN = 256: 4 x 2 tiles of v_mfma_f32_32x32x16_bf16, 128 accumulator registers) or 64 x 64: half
 //     the LDS and global->LDS bytes per FLOP of the 128 x 128 kernel (24 ds_read_b128 per 32 MFMAs instead of 16 per 16);
 //   * operands go global -> LDS with global_load_lds_dwordx4 (rows of 64 bf16 = 128 B, 16-byte chunks XOR-swizzled on the
@@ -39,8 +39,8 @@ __device__ __forceinline__ int lds_rd32_now(unsigned addr) {      // opaque LDS 
 
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
-  constexpr int BM = 256;
-  constexpr int WGN = BN / 64, WGM = 8 / WGN;            // 256: 2 x 4 waves, 128: 4 x 2 waves
+  constexpr int BM = (BN == 64) ? 512 : 256;                // BN = 64 (N = 64 layers at full resolution): 512 x 64, a wave owns 64 x 64
+  constexpr int WGN = BN / 64, WGM = 8 / WGN;            // 256: 2 x 4 waves, 128: 4 x 2 waves, 64: 8 x 1 waves
   constexpr int TM = BM / WGM / 32, TN = 2;              // MFMA tiles per wave: 4 x 2 or 2 x 2
   constexpr int A_PASS = BM / 64, B_PASS = BN / 64;      // global_load_lds per thread and tile (64 rows per pass)
   constexpr int A_ST = BM * 128, B_ST = BN * 128;        // bytes per stage
@@ -365,6 +365,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
 // launch helper used by conv_impl (igemm_conv.hip)
 void launch_conv_bf16_big(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
   if (bn == 256) hipLaunchKernelGGL((conv_bf16_big_kernel<256>), grid, dim3(512), 0, st, k);
+  else if (bn == 64) hipLaunchKernelGGL((conv_bf16_big_kernel<64>), grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((conv_bf16_big_kernel<128>), grid, dim3(512), 0, st, k);
 }
 

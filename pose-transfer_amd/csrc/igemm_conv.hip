@@ -1669,15 +1669,15 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   // 256-row bf16 kernel (igemm_bf16.hip) for launches with enough 256 x BN tiles to fill the chip (one workgroup per CU)
   if (bf16_data && tb == nullptr && ks == 1 && amode == A_VEC && bmode == B_NT && d->out_act == PG_OUT_NONE &&
       ((d->epilogue == 0 && k.vec_out) || (d->epilogue == 1 && k.vec_dst)) && getenv("PG_NO_BF16_BIG") == nullptr) {
-    const int bn = (k.n_cnt % 256 == 0) ? 256 : (k.n_cnt % 128 == 0 ? 128 : 0);
+    const int bn = (k.n_cnt % 256 == 0) ? 256 : (k.n_cnt % 128 == 0 ? 128 : (k.n_cnt == 64 && getenv("PG_NO_BF16_BIG64") == nullptr ? 64 : 0));
     if (bn != 0) {
-      const int mtb = cdiv(k.M, 256), ntb = k.n_cnt / bn;
+      const int mtb = cdiv(k.M, bn == 64 ? 512 : 256), ntb = k.n_cnt / bn;
       const long wgs = (long)mtb * ntb * k.nphase;
       if (wgs >= 448 || getenv("PG_FORCE_BF16_BIG") != nullptr) {
         k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
         launch_conv_bf16_big(k, bn, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
-        last_info() = (bn == 256 ? 4 : 5) | (amode << 4) | (bmode << 8) | (1 << 16);
+        last_info() = (bn == 256 ? 4 : (bn == 128 ? 5 : 6)) | (amode << 4) | (bmode << 8) | (1 << 16);
         return 0;
       }
     }

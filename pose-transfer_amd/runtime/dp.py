@@ -104,8 +104,18 @@ class GradReducer:
         self.bf16 = self.grad_dtype == "bf16" and self.on_device
         self.packed = torch.empty(arena.total, dtype=torch.bfloat16, device=arena.grads.device) if self.bf16 else None
         self.comm_stream = torch.cuda.Stream(device=arena.grads.device) if self.on_device else None
-        self.comm = rccl_comm(arena.grads.device) if (self.backend == "rccl" and world > 1 or
-                                                      (self.backend == "rccl" and os.environ.get("PG_FORCE_REDUCER") == "1")) else None
+        self.comm = None
+        if self.backend == "rccl" and (world > 1 or os.environ.get("PG_FORCE_REDUCER") == "1"):
+            try:
+                self.comm = rccl_comm(arena.grads.device)
+            except (RuntimeError, OSError) as e:
+                # Both transports are RCCL over xGMI; the C-ABI communicator only saves torch's per-collective host work.
+                # If it cannot be created (librccl not loadable by dlopen, rendezvous refused), say so and keep going
+                # through torch.distributed's communicator rather than losing the run.  All ranks take the same branch:
+                # the failure modes are properties of the node image, not of a rank.
+                import sys
+                print("[pose_transfer_amd.dp] pg_comm_init failed (%s); using torch.distributed all_reduce" % e, file=sys.stderr)
+                self.backend = "torch"
         self.launch_count = 0
         self.begin()
 
