@@ -191,11 +191,14 @@ class HbmProfiler:
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/round1_pmc.json, made by
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/round2_pmc.json, made by
     tools/pmc_bench.sh on the default workload): 2*FETCH_SIZE + WRITE_SIZE, in bytes (MI355X_MICROARCH.md: FETCH_SIZE
     reads half of a wide coalesced stream on gfx950).  None when no PMC summary is available."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))
+        path = os.path.join(ROOT, "profiles", "round2_pmc.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "round1_pmc.json")
+        d = json.load(open(path))
         k = d["kernels"].get(kernel)
         return None if k is None else int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
     except Exception:

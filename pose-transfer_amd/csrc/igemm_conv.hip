@@ -9,10 +9,16 @@
 //   A is gathered on the fly from up to 4 NHWC sources (the reference's torch.cat is never materialised) with the
 //   producer's deferred per-sample norm (a_n*x+b_n), channel-dropout mask and activation fused into the load;
 //   B is the packed weight [KH][KW][Cout][Cin], read k-contiguous (forward) or n-contiguous (data-gradient).
-// Tiling: 256 threads = 4 waves; block tile BMxBNx32; each wave owns (BM/WGM)x(BN/WGN) as 32x32 MFMA tiles.
-//   LDS tiles are K-major ([k][m], [k][n]) so that an MFMA operand fetch is one conflict-free ds_read_b32 per lane.
-//   Global->register prefetch of tile t+1 overlaps the 16 MFMA k-steps of tile t (64 cycles each per SIMD).
-// Split-K (atomic accumulate) fills the 256 CUs on the deep, small-M layers.
+// Tiling: 256 threads = 4 waves; block tile BMxBNx32; each wave owns (BM/WGM)x(BN/WGN) as 32x32 MFMA tiles, two
+//   workgroups per CU.  LDS tiles are [m][k] / [n][k] rows of 32 k's + 4 pad floats (K-contiguous global float4 -> ONE
+//   ds_write_b128; an MFMA operand fetch = ONE conflict-free ds_read_b128 per lane per four k-steps); N-contiguous weights
+//   (data-gradient) use [k][n].  The K loop is software-pipelined: two LDS stages, two operand register sets, ONE barrier
+//   per K tile, the loader work of tile t+1 / t+2 cut into four chunks that travel with the four 16-MFMA groups of tile t
+//   (DESIGN.md section 3).  PREC = 3 (bf16 data path) and DMA = 1 (fp32 data-gradient) have no register loaders at all:
+//   operands go global -> LDS with global_load_lds_dwordx4.
+// Split-K fills the 256 CUs on the deep, small-M layers: partial tiles through a caller workspace + one fix-up kernel
+//   (float atomics without a workspace); the split count comes from a time model (conv_impl below).
+// Launches of the bf16 data path that can fill the chip with 256-row tiles are routed to igemm_bf16.hip.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
