@@ -5,6 +5,7 @@
 //  * nn_loss:     nearest-neighbour L1 over an area x area window, value + gradient in one pass — the reference's 25x
 //                 materialisation (419 MB/img) never exists (pose_gan.py:173-199)
 #include "common.h"
+#include <cstdlib>
 
 namespace pg {
 
@@ -94,6 +95,68 @@ __global__ __launch_bounds__(256) void vgg_fwd_kernel(const float* x, const floa
       o[e] = acc > 0.f ? acc : 0.f;
     }
     *reinterpret_cast<float4*>(feat + pix * 64 + lane16 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Round 2: the same arithmetic, tiled.  The kernel above evaluates the input normalisation ((x - mean[k%3]) / std[k%3], a
+// 64-bit modulo and an IEEE division) 27 times in EVERY one of the 16 lanes of a pixel and reads its 108 weights from LDS
+// per pixel: 2.1 ms for 2 M pixels (0.03 of the HBM rate of its 256 B/pixel output).  Here a workgroup owns a 16 x 16 pixel
+// tile: the normalised 18 x 18 x 3 input patch is built ONCE in LDS (4 values per thread), a lane keeps the 27 weights of
+// its 4 output channels in registers for all the tiles it walks, and a pixel costs 27 broadcast LDS reads + 108 FMAs per
+// lane.  Same operation order per output (bias, then q = (c, r, s) ascending).
+__global__ __launch_bounds__(256) void vgg_fwd_tile_kernel(const float* x, const float* w, const float* b, int N, int H,
+                                                           int W, int tiles_x, int tiles_y, float* feat) {
+  __shared__ float patch[3 * 18 * 18];
+  const int tid = threadIdx.x, lane16 = tid & 15, px = tid >> 4;
+  float wr[4][27], br[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    br[e] = b[lane16 * 4 + e];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) wr[e][q] = w[(lane16 * 4 + e) * 27 + q];
+  }
+  const int ntiles = tiles_x * tiles_y * N;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int bb = t;
+    const int tx = bb % tiles_x; bb /= tiles_x;
+    const int ty = bb % tiles_y;
+    const int n = bb / tiles_y;
+    const int y0 = ty * 16, x0 = tx * 16;
+    __syncthreads();
+    for (int e = tid; e < 3 * 18 * 18; e += 256) {
+      const int c = e / 324, rr = (e / 18) % 18, cc = e % 18;
+      const int yy = y0 + rr - 1, xs = x0 + cc - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xs >= 0 && xs < W) {
+        const long k = ((long)c * H + yy) * W + xs;     // flat per-sample offset: mean/std index = k % 3 (the reference's broadcast)
+        const int q = (int)(k % 3);
+        v = (x[(long)n * 3 * H * W + k] - kVggMean[q]) / kVggStd[q];
+      }
+      patch[e] = v;
+    }
+    __syncthreads();
+    const int ox = x0 + px;
+#pragma unroll 2
+    for (int row = 0; row < 16; ++row) {
+      const int oy = y0 + row;
+      float in[27];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) in[c * 9 + r * 3 + s2] = patch[c * 324 + (row + r) * 18 + px + s2];
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = br[e];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc += in[q] * wr[e][q];
+        o[e] = acc > 0.f ? acc : 0.f;
+      }
+      if (oy < H && ox < W)
+        *reinterpret_cast<float4*>(feat + (((long)n * H + oy) * W + ox) * 64 + lane16 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -202,6 +265,107 @@ static int ew_blocks(long count) {
   return (int)b;
 }
 
+// Round 2, C = 64 (the VGG block1 feature loss of configs[3]): one workgroup = an 8 x 8 tile of predicted pixels, FOUR lanes
+// per pixel (16 channels each).  The kernel above gives a pixel 16 lanes, pays a 4-stage cross-lane sum for every one of
+// the area^2 offsets (18 VALU per lane and offset: VALU-bound at 1.2 ms for 2 M pixels) and re-reads G from L2 area^2
+// times.  Here the (8 + 2 half)^2 ground-truth tile sits in LDS with a pixel pitch of 68 floats (272 B: the float4 reads of a
+// 16-lane group — 4 pixels x 4 channel quarters — fall into disjoint bank groups), a lane keeps its 16 predicted channels in
+// registers, and an offset costs 4 ds_read_b128 + 32 VALU + a 2-stage cross-lane sum.  39 KB of LDS per workgroup keeps
+// four workgroups per CU resident, which is what hides the LDS latency (a 16 x 16 tile with one lane per pixel was tried:
+// 109 KB, one wave per SIMD, every read's latency exposed — no faster than the kernel above).  Offsets are walked in the
+// same (di, dj) order with the same strict '<', so ties resolve as before; the winning offset is re-read for the gradient.
+template <int AREA>
+__global__ __launch_bounds__(256) void nn_loss_tile64_kernel(const float* P, const float* G, int N, int H, int W, float scale,
+                                                             int relu_mask, int tiles_x, int tiles_y, float* loss, float* dP) {
+  constexpr int HALF = AREA / 2, TS = 8 + 2 * HALF, PITCH = 68;
+  __shared__ __attribute__((aligned(16))) float gt[TS * TS * PITCH + 4];     // tile + 4 floats of reduction scratch
+  float* const red = gt + TS * TS * PITCH;
+  const int tid = threadIdx.x;
+  int bb = blockIdx.x;
+  const int tx = bb % tiles_x; bb /= tiles_x;
+  const int ty = bb % tiles_y;
+  const int n = bb / tiles_y;
+  const int y0 = ty * 8, x0 = tx * 8;
+  // ---- stage the ground-truth tile (ConstantPad2d(-10000) outside the image, reference pose_gan.py:176); branch-free
+  //      loads in batches so that a batch costs one memory latency
+  constexpr int NE = TS * TS * 16, U = 4;
+  for (int e0 = tid; e0 < NE; e0 += 256 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 256 * u;
+      const int c4 = e & 15, pp = e >> 4;
+      const int rr = pp / TS, cc = pp - rr * TS;
+      const int yy = y0 + rr - HALF, xx = x0 + cc - HALF;
+      const bool ok = (e < NE) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+      const long off = ok ? (((long)n * H + yy) * W + xx) * 64 + c4 * 4 : 0;
+      v[u] = *reinterpret_cast<const float4*>(G + off);
+      if (!ok) v[u] = make_float4(-10000.f, -10000.f, -10000.f, -10000.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 256 * u;
+      if (e < NE) *reinterpret_cast<float4*>(gt + (e >> 4) * PITCH + (e & 15) * 4) = v[u];
+    }
+  }
+  const int sub = tid & 3, lp = tid >> 2, ly = lp >> 3, lx = lp & 7;
+  const int y = y0 + ly, x = x0 + lx;
+  const bool pv = y < H && x < W;
+  const long pix = ((long)n * H + (pv ? y : 0)) * W + (pv ? x : 0);
+  float4 p[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) p[c] = *reinterpret_cast<const float4*>(P + pix * 64 + sub * 16 + c * 4);
+  __syncthreads();
+  float best = INFINITY;
+  int bo = 0;
+  for (int di = 0; di < AREA; ++di)
+#pragma unroll
+    for (int dj = 0; dj < AREA; ++dj) {
+      const float* gp = gt + ((ly + di) * TS + lx + dj) * PITCH + sub * 16;
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 g = *reinterpret_cast<const float4*>(gp + c * 4);
+        d0 += fabsf(g.x - p[c].x); d1 += fabsf(g.y - p[c].y); d2 += fabsf(g.z - p[c].z); d3 += fabsf(g.w - p[c].w);
+      }
+      float d = (d0 + d1) + (d2 + d3);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      if (d < best) { best = d; bo = di * AREA + dj; }
+    }
+  float lacc = 0.f;
+  if (pv) {
+    if (sub == 0) lacc = best;
+    if (dP) {
+      const int di = bo / AREA, dj = bo - di * AREA;
+      const float* gp = gt + ((ly + di) * TS + lx + dj) * PITCH + sub * 16;
+      auto sg = [&](float pp, float gg) {
+        float s = pp > gg ? scale : (pp < gg ? -scale : 0.f);
+        if (relu_mask && !(pp > 0.f)) s = 0.f;
+        return s;
+      };
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 g = *reinterpret_cast<const float4*>(gp + c * 4);
+        float4 o;
+        o.x = sg(p[c].x, g.x); o.y = sg(p[c].y, g.y); o.z = sg(p[c].z, g.z); o.w = sg(p[c].w, g.w);
+        *reinterpret_cast<float4*>(dP + pix * 64 + sub * 16 + c * 4) = o;
+      }
+    }
+  }
+  const float t = block_sum_256(lacc, red);
+  if (tid == 0 && loss) atomicAdd(loss, scale * t);
+}
+
+template <int AREA>
+static int launch_nn_tile64(const float* P, const float* G, int N, int H, int W, float scale, int relu_mask, float* loss, float* dP,
+                            hipStream_t st) {
+  const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+  hipLaunchKernelGGL(nn_loss_tile64_kernel<AREA>, dim3((unsigned)(tiles_x * tiles_y * N)), dim3(256), 0, st, P, G, N, H, W, scale,
+                     relu_mask, tiles_x, tiles_y, loss, dP);
+  return 0;
+}
+
 }  // namespace pg
 
 using namespace pg;
@@ -234,10 +398,19 @@ extern "C" int pg_tanh_bwd(float* g, const float* out, int64_t count, void* stre
 extern "C" int pg_vgg_conv1_relu_fwd(const float* x, const float* w, const float* b, int32_t N, int32_t H, int32_t W,
                                      float* feat, void* stream) {
   PG_REQUIRE(x && w && b && feat && N > 0, "pg_vgg_conv1_relu_fwd: bad arguments");
-  const long npix = (long)N * H * W;
-  long blocks = (npix + 15) / 16;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(vgg_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, N, H, W, feat);
+  static const bool v1 = getenv("PG_VGG_FWD_V1") != nullptr;       // ablation switch: the round-1 per-pixel kernel
+  if (v1) {
+    const long npix = (long)N * H * W;
+    long blocks = (npix + 15) / 16;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(vgg_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, N, H, W, feat);
+  } else {
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    long blocks = (long)tiles_x * tiles_y * N;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(vgg_fwd_tile_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, N, H, W, tiles_x,
+                       tiles_y, feat);
+  }
   PG_LAUNCH_OK("pg_vgg_conv1_relu_fwd");
   return 0;
 }
@@ -264,6 +437,14 @@ extern "C" int pg_nn_loss(const float* P, const float* G, int32_t N, int32_t H, 
     if (blocks > 8192) blocks = 8192;                                                                  \
     hipLaunchKernelGGL(nn_loss_kernel<LPP>, dim3((int)blocks), dim3(256), 0, st, P, G, N, H, W, area,  \
                        scale, relu_mask, loss, dP);                                                    \
+  }
+  if (C == 64 && (area == 3 || area == 5 || area == 7) && getenv("PG_NN_LOSS_V1") == nullptr) {
+    int rc = area == 3 ? launch_nn_tile64<3>(P, G, N, H, W, scale, relu_mask, loss, dP, st)
+           : area == 5 ? launch_nn_tile64<5>(P, G, N, H, W, scale, relu_mask, loss, dP, st)
+                       : launch_nn_tile64<7>(P, G, N, H, W, scale, relu_mask, loss, dP, st);
+    if (rc) return rc;
+    PG_LAUNCH_OK("pg_nn_loss");
+    return 0;
   }
   switch (C) {
     case 4: PG_NN(1); break;
