@@ -192,96 +192,117 @@ __device__ __forceinline__ WarpInv invert_warp(const Theta& th, int h, int w, in
   return r;
 }
 
-// Round-2 forward: the same arithmetic per (pixel, 4 channels, transform), restructured for memory-level parallelism.
-// The first version walked all T transforms behind a data-dependent branch with one more branch around each of the four tap
-// loads: every load waited for the previous one (0.23 of the HBM rate at batch 32).  Here a lane walks only the transforms
-// whose mask is non-zero at its pixel (typically 1-3 of 10; a bit set built from the mask row), the four taps of a transform
-// are unconditional loads from clamped addresses with zeroed weights (adding +-0 leaves the sum bit-identical), and the taps
-// of the NEXT active transform are in flight while the current one is reduced.  Masked-out transforms contribute the
-// candidate 0 with arg-max byte 255 exactly where the sequential walk would have met the first of them (ties at 0 are
-// common — an out-of-range sample is exactly 0 — so the position matters for the arg-max byte).
-struct WarpLoad { float4 v[4]; float wg[4]; float m; };
+// Round-2 forward.  PMC / ISA of the kernel above: it is VALU-bound, not memory-bound — every one of the C/4 lanes of a pixel
+// recomputes the transform's sampling coordinates (four IEEE divisions, floor, clamps: ~90 instructions) for every transform
+// whose mask is non-zero, next to 64 multiply/adds of actual sampling (0.23 of the HBM rate at batch 32).  Here a workgroup
+// owns 64 consecutive pixels: a pre-pass computes the taps of every (pixel, transform) pair ONCE (64 T pairs over 256
+// threads; the column / row terms of the normalised grid come from per-image tables, so the pre-pass has no division) into
+// LDS — four clamped byte offsets, four weights (zeroed outside the image) and the mask value — and the sampling pass reads
+// them back: per (lane, active transform) two ds_read_b128 + one b32, four unconditional float4 loads, 64 multiply/adds.
+// Arithmetic per output element is unchanged (same operations in the same order, adding a +-0 for a zero-weight tap).
+struct WarpTap { int o[4]; float w[4]; };          // byte offsets into the sample's feature map (x C x 4 applied), weights
 
-__device__ __forceinline__ void warp_issue(WarpLoad& L, const Theta& th, const float* fb, const float* mp, int t, int i, int j,
-                                           int h, int w, int C, int cc, int align) {
-#pragma clang fp contract(off)
-  const Taps tp = make_taps(th, i, j, h, w, align);
-  const float wg[4] = {tp.w00, tp.w01, tp.w10, tp.w11};
-  L.m = mp[t];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int xx = tp.x0 + (k & 1), yy = tp.y0 + (k >> 1);
-    const bool ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h);
-    const int xc = min(max(xx, 0), w - 1), yc = min(max(yy, 0), h - 1);
-    L.v[k] = *reinterpret_cast<const float4*>(fb + ((long)yc * w + xc) * C + cc);
-    L.wg[k] = ok ? wg[k] : 0.f;
-  }
-}
-
-__global__ __launch_bounds__(256) void warp_fwd2_kernel(const float* feat, const float* aff, const float* warps,
+__global__ __launch_bounds__(256) void warp_fwd3_kernel(const float* feat, const float* aff, const float* warps,
                                                         const float* masks, int T, int C, int h, int w, int H0, int W0,
-                                                        int align, float* out, uint8_t* amax) {
-  __shared__ Theta th[MAXT];
-  const int n = blockIdx.y;
-  if (threadIdx.x < T) th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
-  __syncthreads();
-  const int cpp = C >> 2;
-  const long items = (long)h * w * cpp;
-  const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
-  const float* fb = feat + (long)n * h * w * C;
-  const unsigned full = (T >= 32) ? 0xffffffffu : ((1u << T) - 1u);
-  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-    const int cc = (int)(it % cpp) * 4;
-    const int pix = (int)(it / cpp);
-    const int i = pix / w, j = pix - i * w;
-    const float* mp = masks + ((long)n * h * w + pix) * T;
-    unsigned act = 0;
-    for (int t = 0; t < T; ++t) act |= (mp[t] != 0.f ? 1u : 0u) << t;
-    const unsigned inact = ~act & full;
-    int zpos = inact ? __builtin_ctz(inact) : 64;            // position of the first masked-out transform (zero candidate)
-    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bi[4] = {255, 255, 255, 255};
-    WarpLoad cur, nxt;
-    int tc = act ? __builtin_ctz(act) : -1;
-    if (tc >= 0) warp_issue(cur, th[tc], fb, mp, tc, i, j, h, w, C, cc, align);
-    while (tc >= 0) {
-      act &= act - 1;
-      const int tn = act ? __builtin_ctz(act) : -1;
-      if (tn >= 0) warp_issue(nxt, th[tn], fb, mp, tn, i, j, h, w, C, cc, align);
-      if (zpos < tc) {                                       // the sequential walk met a masked-out transform first
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (0.f > best[e]) { best[e] = 0.f; bi[e] = 255; }
-        zpos = 64;
-      }
-      {
+                                                        int align, int TP, float* out, uint8_t* amax) {
+  // TP = pixels per tile (host: 64, fewer on small maps so that the grid still fills the chip)
+  extern __shared__ __attribute__((aligned(16))) char wsm[];
+  Theta* th = reinterpret_cast<Theta*>(wsm);                   // [MAXT]
+  float* xs_t = reinterpret_cast<float*>(wsm + MAXT * sizeof(Theta));       // [w] normalised column coordinate
+  float* ys_t = xs_t + w;                                                   // [h]
+  float* mval = ys_t + h;                                                   // [TP * T]
+  WarpTap* taps = reinterpret_cast<WarpTap*>(wsm + ((MAXT * sizeof(Theta) + (size_t)(w + h + TP * T) * 4 + 15) / 16) * 16);
+  const int n = blockIdx.y, tid = threadIdx.x;
+  if (tid < T) th[tid] = make_theta(warps + ((long)n * T + tid) * 8, h, w, H0, W0);
+  {
 #pragma clang fp contract(off)
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float fh = (float)h, fw = (float)w;
+    for (int j = tid; j < w; j += 256)
+      xs_t[j] = align ? (w > 1 ? (((float)j * 2.0f) / (fw - 1.0f)) - 1.0f : 0.0f) : ((((float)j * 2.0f) + 1.0f) / fw) - 1.0f;
+    for (int i = tid; i < h; i += 256)
+      ys_t[i] = align ? (h > 1 ? (((float)i * 2.0f) / (fh - 1.0f)) - 1.0f : 0.0f) : ((((float)i * 2.0f) + 1.0f) / fh) - 1.0f;
+  }
+  const int cpp = C >> 2;
+  const int ppp = 256 / cpp;                                   // pixels per pass (host: cpp divides 256)
+  const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
+  const char* fb = reinterpret_cast<const char*>(feat + (long)n * h * w * C);
+  const int npix = h * w;
+  const int cc = (tid % cpp) * 4, lp = tid / cpp;
+  for (int p0 = blockIdx.x * TP; p0 < npix; p0 += gridDim.x * TP) {
+    __syncthreads();
+    // ---- pre-pass: (pixel, transform) pairs, mask values read as one contiguous run
+    const float* mrow = masks + ((long)n * npix + p0) * T;
+    for (int q = tid; q < TP * T; q += 256) {
+      const int pl = q / T, t = q - pl * T;
+      const int pix = p0 + pl;
+      float m = 0.f;
+      if (pix < npix) m = mrow[q];
+      mval[q] = m;
+      if (m != 0.f) {
+#pragma clang fp contract(off)
+        const int i = pix / w, j = pix - i * w;
+        const Theta tt = th[t];
+        const float fh = (float)h, fw = (float)w;
+        const float xs = xs_t[j], ys = ys_t[i];
+        const float gx = ((tt.t00 * xs) + (tt.t01 * ys)) + tt.t02;
+        const float gy = ((tt.t10 * xs) + (tt.t11 * ys)) + tt.t12;
+        float ix, iy;
+        if (align) { ix = ((gx + 1.0f) / 2.0f) * (fw - 1.0f); iy = ((gy + 1.0f) / 2.0f) * (fh - 1.0f); }
+        else { ix = (((gx + 1.0f) * fw) - 1.0f) / 2.0f; iy = (((gy + 1.0f) * fh) - 1.0f) / 2.0f; }
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float fx = ix - x0f, fy = iy - y0f;
+        const int x0 = (int)fminf(fmaxf(x0f, -4.0f), (float)w + 4.0f);
+        const int y0 = (int)fminf(fmaxf(y0f, -4.0f), (float)h + 4.0f);
+        const float wg[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+        WarpTap tp;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          s[0] = s[0] + ((cur.v[k].x * a) + b) * cur.wg[k];
-          s[1] = s[1] + ((cur.v[k].y * a) + b) * cur.wg[k];
-          s[2] = s[2] + ((cur.v[k].z * a) + b) * cur.wg[k];
-          s[3] = s[3] + ((cur.v[k].w * a) + b) * cur.wg[k];
+          const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+          const bool ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h);
+          tp.o[k] = (min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)) * C * 4;
+          tp.w[k] = ok ? wg[k] : 0.f;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float cand = s[e] * cur.m;
-          if (cand > best[e]) { best[e] = cand; bi[e] = tc; }
-        }
+        taps[q] = tp;
       }
-      cur = nxt;
-      tc = tn;
     }
-    if (zpos < 64) {
+    __syncthreads();
+    // ---- sampling pass: lane = (pixel of the pass, 4 channels)
+    for (int pl = lp; pl < TP; pl += ppp) {
+      const int pix = p0 + pl;
+      if (pix >= npix) break;
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int bi[4] = {255, 255, 255, 255};
+      for (int t = 0; t < T; ++t) {
+        const float m = mval[pl * T + t];
+        float cand[4] = {0.f, 0.f, 0.f, 0.f};
+        int id = 255;
+        if (m != 0.f) {
+#pragma clang fp contract(off)
+          const WarpTap tp = taps[pl * T + t];
+          float4 v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (0.f > best[e]) { best[e] = 0.f; bi[e] = 255; }
+          for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(fb + (size_t)(unsigned)tp.o[k] + cc * 4);
+          float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            s[0] = s[0] + ((v[k].x * a) + b) * tp.w[k];
+            s[1] = s[1] + ((v[k].y * a) + b) * tp.w[k];
+            s[2] = s[2] + ((v[k].z * a) + b) * tp.w[k];
+            s[3] = s[3] + ((v[k].w * a) + b) * tp.w[k];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cand[e] = s[e] * m;
+          id = t;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cand[e] > best[e]) { best[e] = cand[e]; bi[e] = id; }
+      }
+      const long o = ((long)n * npix + pix) * C + cc;
+      *reinterpret_cast<float4*>(out + o) = make_float4(best[0], best[1], best[2], best[3]);
+      if (amax) *reinterpret_cast<uchar4*>(amax + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1],
+                                                                    (unsigned char)bi[2], (unsigned char)bi[3]);
     }
-    const long o = ((long)n * h * w + pix) * C + cc;
-    *reinterpret_cast<float4*>(out + o) = make_float4(best[0], best[1], best[2], best[3]);
-    if (amax) *reinterpret_cast<uchar4*>(amax + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1],
-                                                                  (unsigned char)bi[2], (unsigned char)bi[3]);
   }
 }
 
@@ -498,13 +519,21 @@ extern "C" int pg_warp_mask_max_fwd(const float* feat, const float* aff, const f
                                     int32_t align_corners, float* out, uint8_t* argmax, void* stream) {
   PG_REQUIRE(feat && warps && lvl_masks && out, "pg_warp_mask_max_fwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_fwd: need T<=32, C%%4==0 (T=%d C=%d)", T, C);
-  static const bool v1 = getenv("PG_WARP_FWD_V1") != nullptr;      // ablation switch: the round-1 sequential walk
-  if (v1)
+  static const bool v1 = getenv("PG_WARP_FWD_V1") != nullptr;      // ablation switch: the round-1 per-lane walk
+  const int cpp = C / 4;
+  const size_t lds = ((MAXT * sizeof(Theta) + (size_t)(w + h + 64 * T) * 4 + 15) / 16) * 16 + (size_t)64 * T * sizeof(WarpTap);
+  if (v1 || cpp > 256 || 256 % cpp != 0 || lds > 64 * 1024 || (double)h * w * C * 4.0 >= 2147483648.0) {
     hipLaunchKernelGGL(warp_fwd_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, feat, aff, warps,
                        lvl_masks, T, C, h, w, H0, W0, align_corners, out, argmax);
-  else
-    hipLaunchKernelGGL(warp_fwd2_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, feat, aff, warps,
-                       lvl_masks, T, C, h, w, H0, W0, align_corners, out, argmax);
+  } else {
+    int tp = 64;
+    const int ppp = 256 / cpp;
+    while (tp > 8 && tp / 2 >= ppp && (((long)h * w + tp - 1) / tp) * N < 1024) tp /= 2;
+    long tiles = ((long)h * w + tp - 1) / tp;
+    if (tiles > 1024) tiles = 1024;
+    hipLaunchKernelGGL(warp_fwd3_kernel, dim3((unsigned)tiles, N), dim3(256), lds, (hipStream_t)stream, feat, aff, warps,
+                       lvl_masks, T, C, h, w, H0, W0, align_corners, tp, out, argmax);
+  }
   PG_LAUNCH_OK("pg_warp_mask_max_fwd");
   return 0;
 }
