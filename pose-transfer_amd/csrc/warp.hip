@@ -106,6 +106,33 @@ __device__ __forceinline__ Taps make_taps(const Theta& t, int i, int j, int h, i
   return r;
 }
 
+// The same with the normalised grid coordinates of the column / row given (per-image tables: the two divisions of
+// make_coords depend on j or i alone).  Identical operations in identical order -> identical results.
+__device__ __forceinline__ float warp_norm_coord(int k, int n, int align_corners) {
+#pragma clang fp contract(off)
+  const float fn = (float)n;
+  return align_corners ? (n > 1 ? (((float)k * 2.0f) / (fn - 1.0f)) - 1.0f : 0.0f) : ((((float)k * 2.0f) + 1.0f) / fn) - 1.0f;
+}
+__device__ __forceinline__ Taps make_taps_xy(const Theta& t, float xs, float ys, int h, int w, int align_corners) {
+#pragma clang fp contract(off)
+  const float fh = (float)h, fw = (float)w;
+  const float gx = ((t.t00 * xs) + (t.t01 * ys)) + t.t02;
+  const float gy = ((t.t10 * xs) + (t.t11 * ys)) + t.t12;
+  float ix, iy;
+  if (align_corners) { ix = ((gx + 1.0f) / 2.0f) * (fw - 1.0f); iy = ((gy + 1.0f) / 2.0f) * (fh - 1.0f); }
+  else { ix = (((gx + 1.0f) * fw) - 1.0f) / 2.0f; iy = (((gy + 1.0f) * fh) - 1.0f) / 2.0f; }
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float fx = ix - x0f, fy = iy - y0f;
+  Taps r;
+  r.x0 = (int)fminf(fmaxf(x0f, -4.0f), (float)w + 4.0f);
+  r.y0 = (int)fminf(fmaxf(y0f, -4.0f), (float)h + 4.0f);
+  r.w00 = (1.0f - fx) * (1.0f - fy);
+  r.w01 = fx * (1.0f - fy);
+  r.w10 = (1.0f - fx) * fy;
+  r.w11 = fx * fy;
+  return r;
+}
+
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* feat, const float* aff, const float* warps,
                                                        const float* masks, int T, int C, int h, int w, int H0, int W0,
                                                        int align, float* out, uint8_t* amax) {
@@ -167,6 +194,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* feat, const 
 // mask x bilinear weight).  Phase 2 (lanes = 4 channels of a pixel): run the lists, add g where the forward arg-max
 // selected that transform.  No atomics, deterministic, one 16-byte store per 4 elements, no zero-fill of the destination.
 // "Wide" transforms (a strongly shrinking limb fit; rare) take the scatter kernel below with float atomics.
+constexpr int GATHER_MAXDIM = 1024;                                  // per-image coordinate tables of the gather kernel
 constexpr int GATHER_CAP = 16, GATHER_PIX = 32, GATHER_T = 10;      // T <= 10 on the gather path (10 limb transforms / 1)
 
 struct WarpInv { float jx, jy, ix_, iy_, cx, cy, ej, ei; int narrow; };
@@ -315,11 +343,14 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* gout,
   __shared__ int e_pix[GATHER_PIX][FLAT];                 // output pixel | transform << 24      (20 KB)
   __shared__ float e_w[GATHER_PIX][FLAT];                 // mask x bilinear weight              (20 KB)
   __shared__ int e_cnt[GATHER_PIX];
+  __shared__ float xs_t[GATHER_MAXDIM], ys_t[GATHER_MAXDIM];      // normalised grid coordinate per column / row (host: h, w <= 1024)
   const int n = blockIdx.y;
   if (threadIdx.x < T) {
     th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
     inv[threadIdx.x] = invert_warp(th[threadIdx.x], h, w, align);
   }
+  for (int k = threadIdx.x; k < w; k += 256) xs_t[k] = warp_norm_coord(k, w, align);
+  for (int k = threadIdx.x; k < h; k += 256) ys_t[k] = warp_norm_coord(k, h, align);
   if (threadIdx.x < GATHER_PIX) e_cnt[threadIdx.x] = 0;
   __syncthreads();
   const long nb = (long)n * h * w;
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* gout,
       for (int e = 0; e < GATHER_CAP; ++e) {
         ep[e] = -1; ew[e] = 0.f;
         if (mv[e] != 0.f) {
-          const Taps tp = make_taps(th[t], ci[e], cj[e], h, w, align);
+          const Taps tp = make_taps_xy(th[t], xs_t[cj[e]], ys_t[ci[e]], h, w, align);      // division-free (tables)
           const int kx = X - tp.x0, ky = Y - tp.y0;
           if ((unsigned)kx <= 1u && (unsigned)ky <= 1u) {
             const float wk = ky ? (kx ? tp.w11 : tp.w10) : (kx ? tp.w01 : tp.w00);
@@ -544,7 +575,7 @@ extern "C" int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, co
   PG_REQUIRE(gout && argmax && warps && lvl_masks && dfeat, "pg_warp_mask_max_bwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_bwd: need T<=32, C%%4==0");
   static const bool no_gather = getenv("PG_WARP_BWD_SCATTER") != nullptr;       // ablation: round-1 scatter kernel only
-  if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 30)) {
+  if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM) {
     // gather kernel OVERWRITES dfeat (narrow transforms), then the scatter kernel adds the wide ones
     hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((h * w + GATHER_PIX - 1) / GATHER_PIX, N), dim3(256), 0, (hipStream_t)stream,
                        gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
