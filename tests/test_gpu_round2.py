@@ -101,8 +101,17 @@ def test_generator_224_p32_vs_golden(prec, monkeypatch):
     assert np.abs(got[3:] - ref[3:]).max() < TOL[prec][0]
 
 
-def test_p32_step_vs_golden():
-    """dis_update + gen_update at pose_dim 32 (first-layer channel counts 35 / 32 / 70) vs the reference capture."""
+# step tolerances vs the REFERENCE capture: (loss rtol, out_gen max-abs, gradient summary / tensor max)
+STEP_TOL = {"f32": (1e-4, 1e-3, 2e-3), "bf16x3": (1e-3, 1e-3, 1e-2), "bf16_data": (3e-2, 0.3, None)}
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16_data"])
+def test_p32_step_vs_golden(prec, monkeypatch):
+    """dis_update + gen_update at pose_dim 32 (first-layer channel counts 35 / 32 / 70) vs the reference capture — in
+    fp32, in the split-operand mode bf16x3 (the sub-fp32-cost mode that keeps the 1e-3 bar end to end) and on the bf16 data
+    path (stated bf16 tolerance, against the reference's tensors, not against the build's own fp32 path)."""
+    monkeypatch.setattr(E, "PRECISION", PREC[prec])
+    rt, ot, gt_ = STEP_TOL[prec]
     fix = np.load(os.path.join(GOLDEN, "p32.npz"))
     P, H, W, N = 32, 64, 64, 2
     enc, dec = synth.nfilters((H, W))
@@ -115,18 +124,22 @@ def test_p32_step_vs_golden():
     dA = dev(*[t(m) for m in synth.dropout_masks(63, "p32/step/dA", N)])
     dC = dev(*[t(m) for m in synth.dropout_masks(63, "p32/step/dC", N)])
     dl = model.dis_update(bA[0], bA[1], {"warps": bA[2], "masks": bA[3], "drop_masks": dA}, bB[0], bB[1], od)
-    np.testing.assert_allclose(dl, fix["step_dis_losses"], rtol=1e-4, atol=LOSS_ATOL)
-    for k, g in model.disc.arena.grad_dict().items():
-        ref = fix["step_dgrad_" + k]
-        if not np.all(ref[3:] == ref[3]):
-            assert np.abs(_summ(g)[2:] - ref[2:]).max() <= 2e-3 * max(ref[2], 1e-12), k
+    np.testing.assert_allclose(dl, fix["step_dis_losses"], rtol=rt, atol=max(LOSS_ATOL, rt))
+    if gt_ is not None:
+        for k, g in model.disc.arena.grad_dict().items():
+            ref = fix["step_dgrad_" + k]
+            if not np.all(ref[3:] == ref[3]):
+                assert np.abs(_summ(g)[2:] - ref[2:]).max() <= gt_ * max(ref[2], 1e-12), k
     og, _, gl = model.gen_update(bC[0], bC[1], {"warps": bC[2], "masks": bC[3], "drop_masks": dC}, od)
-    np.testing.assert_allclose(gl, fix["step_gen_losses"], rtol=1e-4, atol=LOSS_ATOL)
-    assert maxdiff(og, t(fix["step_out_gen"])) < 1e-3
-    for k, g in model.gen.arena.grad_dict().items():
-        ref = fix["step_ggrad_" + k]
-        if not np.all(ref[3:] == ref[3]):
-            assert np.abs(_summ(g)[2:] - ref[2:]).max() <= 2e-3 * max(ref[2], 1e-12), k
+    np.testing.assert_allclose(gl, fix["step_gen_losses"], rtol=rt, atol=max(LOSS_ATOL, rt))
+    assert maxdiff(og, t(fix["step_out_gen"])) < ot
+    if prec == "bf16_data":
+        assert float((og.cpu() - t(fix["step_out_gen"])).abs().mean()) < 2.6e-2
+    if gt_ is not None:
+        for k, g in model.gen.arena.grad_dict().items():
+            ref = fix["step_ggrad_" + k]
+            if not np.all(ref[3:] == ref[3]):
+                assert np.abs(_summ(g)[2:] - ref[2:]).max() <= gt_ * max(ref[2], 1e-12), k
 
 
 def _property_step(H, W, P, N, prec, monkeypatch):
