@@ -228,6 +228,10 @@ int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t
                        double* bsums, void* stream);
 int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
                       int32_t N, int64_t L, float* dgamma, float* dbeta, void* stream);
+/* the same; `dy_bf16` (NULL = none): also write dy as a bf16 tensor of the same shape — the operand copy the data- and
+ * weight-gradient contractions of the bf16 data path read (saves their pg_materialise_bf16 pass over dy). */
+int pg_norm_bwd_apply_ex(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
+                         int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, void* stream);
 
 /* ---- key-point heat-maps (utils/pose_utils.py:79-86 cords_to_map; SURVEY.md §8f row 1: the step before the path).
  * cords [N][P][2] = (y, x) as float, -1 = missing (zero map); out[n*oN + c*oC + y*oH + x*oW] =

@@ -98,9 +98,15 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* dz, c
   }
 }
 
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {      // RNE, lo -> bits 0..15 (as pg_materialise_bf16)
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* dz, const float* y, const float* mr,
                                                              const double* bsums, const float* gamma, int N, long L,
-                                                             float* dgamma, float* dbeta) {
+                                                             float* dgamma, float* dbeta, unsigned short* dy_bf16) {
   const int n = blockIdx.y;
   const float mean = mr[2 * n], rstd = mr[2 * n + 1];
   const float g = gamma[0];
@@ -118,10 +124,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* dz, const fl
     d.z = k * (d.z - m1 - ((v.z - mean) * rstd) * m2);
     d.w = k * (d.w - m1 - ((v.w - mean) * rstd) * m2);
     reinterpret_cast<float4*>(bd)[i] = d;
+    if (dy_bf16) {           // the bf16 operand copy the data- / weight-gradient contractions read (bf16 data path)
+      uint2 pk;
+      pk.x = pack_bf16_rne(d.x, d.y); pk.y = pack_bf16_rne(d.z, d.w);
+      reinterpret_cast<uint2*>(dy_bf16 + (long)n * L)[i] = pk;
+    }
   }
   if (blockIdx.x == 0)
-    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256)
+    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) {
       bd[i] = k * (bd[i] - m1 - ((by[i] - mean) * rstd) * m2);
+      if (dy_bf16) dy_bf16[(long)n * L + i] = (unsigned short)(pack_bf16_rne(bd[i], 0.f) & 0xffffu);
+    }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     double sg = 0.0, sb = 0.0;
     for (int i = 0; i < N; ++i) { sb += bsums[2 * i]; sg += bsums[2 * i + 1]; }
@@ -177,11 +190,16 @@ extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* 
   return 0;
 }
 
-extern "C" int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
-                                 int32_t N, int64_t L, float* dgamma, float* dbeta, void* stream) {
+extern "C" int pg_norm_bwd_apply_ex(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
+                                    int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, void* stream) {
   PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0, "pg_norm_bwd_apply: bad arguments");
   hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, dz, y, mr,
-                     bsums, gamma, N, (long)L, dgamma, dbeta);
+                     bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
   PG_LAUNCH_OK("pg_norm_bwd_apply");
   return 0;
+}
+
+extern "C" int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
+                                 int32_t N, int64_t L, float* dgamma, float* dbeta, void* stream) {
+  return pg_norm_bwd_apply_ex(dz, y, mr, bsums, gamma, N, L, dgamma, dbeta, nullptr, stream);
 }

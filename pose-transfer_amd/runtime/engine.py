@@ -284,6 +284,15 @@ class BfCache:
         k = self.key(ptr, C, act, aff, mask)
         return self.buf[k] if k in self.valid else None
 
+    def reserve(self, ptr, C, act, aff, mask, need, dev):
+        """the buffer of this key, marked valid: the caller's kernel writes the operand itself"""
+        k = self.key(ptr, C, act, aff, mask)
+        b = self.buf.get(k)
+        if b is None or b.numel() < need:
+            b = self.buf[k] = torch.empty(need, dtype=torch.bfloat16, device=dev)
+        self.valid.add(k)
+        return b
+
     def get(self, ptr, C, act, aff, mask, N, HW, dev):
         """the bf16 NHWC tensor bf16(act((a*x+b)*mask)), materialised on the current stream if this pass has not yet"""
         k = self.key(ptr, C, act, aff, mask)
@@ -383,6 +392,7 @@ def _conv_dgrad(gy_src, N, Hi, Wi, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, d
           ksplit=ksplit)
 
 
+NORM_BWD_BF16 = os.environ.get("PG_NO_NORM_BWD_BF16") is None    # ablation switch: separate materialisation of dy
 STEM_BF16 = os.environ.get("PG_NO_STEM_BF16") is None     # ablation switch: fp32 first-layer kernels on the bf16 data path
 
 
@@ -648,12 +658,22 @@ class NormState:
         L.call("pg_norm_finalize", L.ptr(self.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(self.mr),
                L.ptr(self.aff), L.stream())
 
-    def backward(self, dz, y, N, Lr, gamma, dgamma, dbeta):
+    def backward(self, dz, y, N, Lr, gamma, dgamma, dbeta, C=0):
+        """dz <- dy in place.  On the bf16 data path (C = channels of the tensor, a multiple of 64) the apply kernel also
+        writes dy as the bf16 operand the data- / weight-gradient contractions of this layer will ask the pass's operand
+        cache for, so their materialisation pass (4 B read + 2 B write per element) does not run."""
         if not self.shared:
             self.bsums.zero_()
         L.call("pg_norm_bwd_reduce", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), L.stream())
-        L.call("pg_norm_bwd_apply", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
-               L.ptr(dgamma), L.ptr(dbeta), L.stream())
+        bf = None
+        if PRECISION == 3 and NORM_BWD_BF16 and _BF_CTX is not None and C > 0 and C % 64 == 0:
+            bf = _BF_CTX.reserve(L.ptr(dz), C, L.ACT_NONE, None, None, N * Lr, dz.device)
+        if bf is not None:
+            L.call("pg_norm_bwd_apply_ex", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
+                   L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), L.stream())
+        else:
+            L.call("pg_norm_bwd_apply", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
+                   L.ptr(dgamma), L.ptr(dbeta), L.stream())
 
 
 def generator_param_order(spec, nlev, ndec, deformable=True):
@@ -921,7 +941,7 @@ class GeneratorEngine:
             wkey = "decoder.net.%d.net.1.weight" % i
             self.d_norm[i].backward(self.d_dz[i], self.d_raw[i], N, ho * wo * self.dec[i],
                                     A.p("decoder.net.%d.net.3.weight" % i), A.g("decoder.net.%d.net.3.weight" % i),
-                                    A.g("decoder.net.%d.net.3.bias" % i))
+                                    A.g("decoder.net.%d.net.3.bias" % i), C=self.dec[i])
             dy = self.d_dz[i]
             _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, dy, self.dec[i], cin, False, hi, wi, ho, wo, 4, 2, 1,
                    A.g(wkey))
@@ -943,7 +963,7 @@ class GeneratorEngine:
                 if l < self.nlev - 1:
                     self.e_norm[e][l].backward(dz, self.e_raw[e][l], N, ho * wo * self.enc[l],
                                                A.p("%s.net.%d.net.2.weight" % (e, l)), A.g("%s.net.%d.net.2.weight" % (e, l)),
-                                               A.g("%s.net.%d.net.2.bias" % (e, l)))
+                                               A.g("%s.net.%d.net.2.bias" % (e, l)), C=self.enc[l])
                 xin = self._enc_act(e, l - 1)
                 _wgrad([xin.src()], N, L.ACT_LEAKY, dz, self.enc[l], self.enc[l - 1], True, ho, wo, hi, wi, 4, 2, 1,
                        A.g(wkey))
@@ -1102,7 +1122,7 @@ class DiscriminatorEngine:
             self.norm[j].backward(dz, self.raw[j], M, self.hs[j] * self.ws[j] * self.chans[j],
                                   A.p("net.%d.net.2.weight" % j),
                                   A.g("net.%d.net.2.weight" % j) if need_wgrad else None,
-                                  A.g("net.%d.net.2.bias" % j) if need_wgrad else None)
+                                  A.g("net.%d.net.2.bias" % j) if need_wgrad else None, C=self.chans[j])
             xin = self._act(j - 1)
             if need_wgrad:
                 _wgrad([xin.src()], M, L.ACT_LEAKY, dz, self.chans[j], self.chans[j - 1], True, self.hs[j], self.ws[j],

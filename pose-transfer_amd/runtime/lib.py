@@ -88,6 +88,7 @@ _PROTOS = {
     "pg_norm_finalize": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
     "pg_norm_bwd_reduce": [_vp, _vp, _vp, _i32, _i64, _vp, _vp],
     "pg_norm_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp],
+    "pg_norm_bwd_apply_ex": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "pg_mask_pyramid": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_warp_mask_max_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "pg_warp_mask_max_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -78,6 +78,15 @@ def test_sample_norm_forward_backward():
     assert maxdiff(nchw(dz), dx) < 2e-6
     assert abs(dgam.item() - dg.item()) < 1e-4 * max(1, abs(dg.item()))
     assert abs(dbet.item() - db.item()) < 1e-4 * max(1, abs(db.item()))
+    # bf16 data path: the apply kernel also emits dy as the bf16 operand of the layer's gradient contractions
+    dz2 = nhwc(gz).to(DEV)
+    dgam.zero_(); dbet.zero_()
+    st.bsums.zero_()
+    L.call("pg_norm_bwd_reduce", L.ptr(dz2), L.ptr(y), L.ptr(st.mr), N, C * H * W, L.ptr(st.bsums), L.stream())
+    dy16 = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.call("pg_norm_bwd_apply_ex", L.ptr(dz2), L.ptr(y), L.ptr(st.mr), L.ptr(st.bsums), L.ptr(gamma.to(DEV)), N, C * H * W,
+           L.ptr(dgam), L.ptr(dbet), L.ptr(dy16), L.stream())
+    assert torch.equal(dz2, dz) and torch.equal(dy16, dz2.to(torch.bfloat16))
 
 
 def test_cords_to_map_vs_reference_golden():
