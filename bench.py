@@ -129,6 +129,7 @@ HBM_MODELS = {
     "pg_norm_stats": lambda a: 4 * _ival(a[1]) * _ival(a[2]),
     "pg_norm_bwd_reduce": lambda a: 8 * _ival(a[3]) * _ival(a[4]),                 # dz, y
     "pg_norm_bwd_apply": lambda a: 12 * _ival(a[5]) * _ival(a[6]),                 # dz (read + write), y
+    "pg_norm_bwd_apply_ex": lambda a: 14 * _ival(a[5]) * _ival(a[6]),              # + the bf16 copy of dy
     "pg_adam": lambda a: 28 * _ival(a[4]),                                           # p, g, m, v read; p, m, v written
     "pg_adam_ex": lambda a: 28 * _ival(a[5]),
     "pg_nn_loss": lambda a: 12 * _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * _ival(a[5]),       # P, G read; dP written
@@ -141,6 +142,7 @@ HBM_MODELS = {
                           + 256 * _ival(a[2]) * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
                           * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
     "pg_stem_conv_bf16": lambda a: HBM_MODELS["pg_small_cin_conv"](a),
+    "pg_stem_conv_bf16_ex": lambda a: HBM_MODELS["pg_small_cin_conv"](a) * (1.5 if _ival(a[11]) else 1.0),    # + bf16 copy
     "pg_stem_wgrad_bf16": lambda a: HBM_MODELS["pg_small_cin_wgrad"](a),
     # last conv (256 -> 3): tap tensor (27 -> 32 columns) + NCHW image; data-gradient: im2col'd gradient + fwd read / grad write
     "pg_tap_gather": lambda a: _ival(a[1]) * _ival(a[2]) * _ival(a[3]) * (27 * 4 + 12),

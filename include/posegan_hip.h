@@ -206,6 +206,11 @@ int64_t pg_stem_pack_elems(int32_t K, int32_t Cin);
 int pg_stem_pack_bf16(const float* W, int32_t K, int32_t Cin, uint16_t* Wp, void* stream);
 int pg_stem_conv_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                       int32_t pad, const uint16_t* Wp, const float* bias, float* out, void* stream);
+/* the same; `out_bf16` (NULL = none): also write bf16(act(out)) NHWC — the activated operand the next layer's contraction
+ * reads on the bf16 data path (saves its pg_materialise_bf16 pass over `out`); act = PG_ACT_* */
+int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                         int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
+                         void* stream);
 int pg_stem_wgrad_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                        int32_t pad, const float* dY, float* dW, float* workspace, int64_t workspace_floats, void* stream);
 

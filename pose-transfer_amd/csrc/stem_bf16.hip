@@ -35,6 +35,8 @@ struct StemK {
   const unsigned short* Wp;   // conv: packed bf16 weights (pg_stem_pack_bf16)
   const float* bias;
   float* out;                 // conv: NHWC [N][Ho][Wo][64]
+  unsigned short* out_bf16;   // conv, optional: bf16(act(out)) NHWC, act slope `slope` (the next layer's operand)
+  float slope;
   const float* dY;            // wgrad: NHWC [N][Ho][Wo][64]
   float* part;                // wgrad: per-workgroup partial results [blocks][64][npad]
   int npad;
@@ -185,6 +187,27 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
           o[32] = acc[i][1][r] + bias1;
         }
       }
+    // ---- optional second output: the activated bf16 operand of the next layer (saves its pg_materialise_bf16 pass).  Lane
+    //      pairs exchange one value so that every lane stores 4 bytes: even lanes (channel c, c+1) of row r, odd lanes of r+1.
+    if (p.out_bf16) {
+#pragma unroll
+      for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float bj = j ? bias1 : bias0;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float va = apply_act_s(acc[i][j][r] + bj, p.slope), vb = apply_act_s(acc[i][j][r + 1] + bj, p.slope);
+            const float got = __shfl_xor((lane & 1) ? va : vb, 1, 64);
+            const int rr = r + (lane & 1);
+            const unsigned pk = (lane & 1) ? pack_bf16(got, vb) : pack_bf16(va, got);
+            const int m = (rr & 3) + 8 * (rr >> 2) + 4 * lhi;
+            const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
+            if (oy < p.Ho && ox < p.Wo)
+              *reinterpret_cast<unsigned*>(p.out_bf16 + (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + j * 32 + (l31 & ~1)) = pk;
+          }
+        }
+    }
   }
 }
 
@@ -436,14 +459,26 @@ extern "C" int pg_stem_pack_bf16(const float* W, int32_t K, int32_t Cin, uint16_
   return 0;
 }
 
+extern "C" int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                                    int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
+                                    void* stream);
+
 extern "C" int pg_stem_conv_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                                  int32_t pad, const uint16_t* Wp, const float* bias, float* out, void* stream) {
+  return pg_stem_conv_bf16_ex(src, nsrc, N, Hi, Wi, K, stride, pad, Wp, bias, out, nullptr, PG_ACT_NONE, stream);
+}
+
+extern "C" int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                                    int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
+                                    void* stream) {
   PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && Wp && out, "pg_stem_conv_bf16: bad arguments");
   PG_REQUIRE((K == 3 && stride == 1) || (K == 4 && stride == 2), "pg_stem_conv_bf16: only k3s1 / k4s2 (got k%d s%d)", K, stride);
   pg::StemK k;
   PG_REQUIRE(pg::stem_fill(k, src, nsrc, N, Hi, Wi, K, stride, pad) == 0, "pg_stem_conv_bf16: sources must not carry aff / mask");
   PG_REQUIRE(k.Ctot <= 80 && k.Ho > 0 && k.Wo > 0 && N > 0, "pg_stem_conv_bf16: Cin <= 80 and a non-empty output required");
   k.Wp = Wp; k.bias = bias; k.out = out;
+  k.out_bf16 = out_bf16;
+  k.slope = act == PG_ACT_RELU ? 0.f : (act == PG_ACT_LEAKY ? 0.2f : 1.f);
   const int CG = pg_stem_group_channels(k.Ctot);
   k.ngroups = (k.Ctot + CG - 1) / CG;
   hipStream_t st = (hipStream_t)stream;

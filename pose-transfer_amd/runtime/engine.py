@@ -393,6 +393,7 @@ def _conv_dgrad(gy_src, N, Hi, Wi, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, d
 
 
 NORM_BWD_BF16 = os.environ.get("PG_NO_NORM_BWD_BF16") is None    # ablation switch: separate materialisation of dy
+STEM_EMIT_BF16 = os.environ.get("PG_NO_STEM_EMIT_BF16") is None  # ablation switch: separate materialisation of the level-0 output
 STEM_BF16 = os.environ.get("PG_NO_STEM_BF16") is None     # ablation switch: fp32 first-layer kernels on the bf16 data path
 
 
@@ -401,14 +402,21 @@ def stem_pack_floats(K, cin):
     return max(cin * K * K * 64, (int(L.load().pg_stem_pack_elems(K, cin)) + 1) // 2)
 
 
-def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out):
-    """First-layer convolution (few NCHW input channels -> 64 NHWC): repack the weights, then the patch kernel."""
+def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out, next_act=None, bf_ptr=None):
+    """First-layer convolution (few NCHW input channels -> 64 NHWC): repack the weights, then the patch kernel.
+    `next_act`: activation of the layer that reads the output next — on the bf16 data path the kernel then also writes that
+    layer's bf16 operand into the pass's operand cache."""
     cin = sum(a.C for a in acts)
     if PRECISION == 3 and STEM_BF16 and cin <= 80:
         L.call("pg_stem_pack_bf16", L.ptr(W), K, cin, L.ptr(wt_buf), L.stream())
         arr = (L.Src * len(acts))(*[a.src() for a in acts])
-        L.call("pg_stem_conv_bf16", arr, len(acts), N, Hi, Wi, K, stride, pad, L.ptr(wt_buf), L.ptr(bias),
-               out if isinstance(out, int) else L.ptr(out), L.stream())
+        optr = out if isinstance(out, int) else L.ptr(out)
+        bf = bf_ptr                      # a slice of an operand the caller reserved itself (discriminator: one call per pair)
+        if bf is None and next_act is not None and _BF_CTX is not None and STEM_EMIT_BF16:
+            Ho, Wo = (Hi + 2 * pad - K) // stride + 1, (Wi + 2 * pad - K) // stride + 1
+            bf = L.ptr(_BF_CTX.reserve(optr, 64, next_act, None, None, N * Ho * Wo * 64, W.device))
+        L.call("pg_stem_conv_bf16_ex", arr, len(acts), N, Hi, Wi, K, stride, pad, L.ptr(wt_buf), L.ptr(bias), optr, bf,
+               next_act if bf is not None else L.ACT_NONE, L.stream())
         return
     L.call("pg_repack_small_cin", L.ptr(W), K, K, 64, cin, L.ptr(wt_buf), L.stream())
     arr = (L.Src * len(acts))(*[a.src() for a in acts])
@@ -835,7 +843,7 @@ class GeneratorEngine:
             s0 = self._enc_in_src(e, inp)
             if self.enc[0] == 64:
                 _small_cin_conv([s0], N, H, W, 3, 1, 1, A.p(e + ".net.0.weight"), A.p(e + ".net.0.bias"), self.wt0[e],
-                                self.e_raw[e][0])
+                                self.e_raw[e][0], next_act=L.ACT_LEAKY)
             else:
                 _conv([s0.src()], N, H, W, L.ACT_NONE, 0, 3, 1, 1, H, W, A.p(e + ".net.0.weight"), self.enc[0], s0.C,
                       scalar_in=True, out=self.e_raw[e][0], bias=A.p(e + ".net.0.bias"))
@@ -1068,12 +1076,18 @@ class DiscriminatorEngine:
         self.inputs = pairs
         self.nscr.sums.zero_()
         off = 0
+        bf0 = None
+        if PRECISION == 3 and STEM_BF16 and STEM_EMIT_BF16 and _BF_CTX is not None and 3 + 2 * self.P + 3 <= 80:
+            bf0 = _BF_CTX.reserve(L.ptr(self.raw[0]), 64, L.ACT_LEAKY, None, None, self.M * self.hs[0] * self.ws[0] * 64,
+                                  self.raw[0].device)
         for pair in pairs:
             n = pair[0].shape[0]
             assert all(t.is_contiguous() and t.dtype == torch.float32 for t in pair)
             srcs = self._stem_srcs(pair)
             out_ptr = self.raw[0].data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
-            _small_cin_conv(srcs, n, H, W, 4, 2, 0, A.p("net.0.weight"), A.p("net.0.bias"), self.wt0, out_ptr)
+            _small_cin_conv(srcs, n, H, W, 4, 2, 0, A.p("net.0.weight"), A.p("net.0.bias"), self.wt0, out_ptr,
+                            next_act=L.ACT_LEAKY,
+                            bf_ptr=None if bf0 is None else bf0.data_ptr() + 2 * off * self.hs[0] * self.ws[0] * 64)
             off += n
         assert off == self.M
         for j in range(1, self.nblk):

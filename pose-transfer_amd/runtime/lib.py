@@ -72,6 +72,7 @@ _PROTOS = {
     "pg_stem_pack_elems": [_i32, _i32],
     "pg_stem_pack_bf16": [_vp, _i32, _i32, _vp, _vp],
     "pg_stem_conv_bf16": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "pg_stem_conv_bf16_ex": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "pg_stem_wgrad_bf16": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
     "pg_bias_grad": [_vp, _i64, _i64, _i32, _i64, _i64, _i64, _vp, _vp],
     "pg_cords_to_map": [_vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _i64, _i64, _i64, _i64, _vp],

@@ -751,7 +751,15 @@ def test_stem_bf16_conv_and_wgrad(kname, sname, monkeypatch):
         dw = case.run_wgrad()
         monkeypatch.setattr(L, "CALL_HOOK", None)
         torch.cuda.synchronize()
-        assert "pg_stem_conv_bf16" in hooked and "pg_stem_wgrad_bf16" in hooked, hooked
+        assert "pg_stem_conv_bf16_ex" in hooked and "pg_stem_wgrad_bf16" in hooked, hooked
+        # second output: the next layer's activated bf16 operand (exactly bf16(leaky(out)))
+        arr = (L.Src * len(acts))(*[a_.src() for a_ in acts])
+        out2 = torch.full_like(out, float("nan"))
+        o16 = torch.full(out.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.call("pg_stem_conv_bf16_ex", arr, len(acts), case.N, case.H, case.W, case.K, case.stride, case.pad, L.ptr(wt), L.ptr(bd),
+               L.ptr(out2), L.ptr(o16), L.ACT_LEAKY, L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out) and torch.equal(o16, F.leaky_relu(out2, 0.2).to(torch.bfloat16)), case.name
         assert rel(nchw(out.cpu()), ref.detach()) < 1e-4, (case.name, float(rel(nchw(out.cpu()), ref.detach())))
         assert rel(dw, dw_ref) < 1e-4, (case.name, float(rel(dw, dw_ref)))
 
