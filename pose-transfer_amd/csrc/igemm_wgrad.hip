@@ -9,6 +9,7 @@
 // single ds_write_b128.  X carries the forward prologue (deferred per-sample norm, dropout mask, activation) and
 // the virtual concat of up to 4 sources.  K is split across workgroups (float atomics into the zeroed dW).
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace pg {
@@ -637,7 +638,8 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   int ks = d->ksplit;
   if (ks <= 0) {
     const long tiles = (long)mt * nt * k.ntaps;
-    ks = (int)((1024 + tiles - 1) / tiles);
+    static const int target = getenv("PG_WG_TARGET") ? atoi(getenv("PG_WG_TARGET")) : 1024;
+    ks = (int)((target + tiles - 1) / tiles);
     const int kmax = nkt / 2 > 0 ? nkt / 2 : 1;
     if (ks > kmax) ks = kmax;
     if (ks > 512) ks = 512;
