@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16", "bf16_data"],
                     help="MFMA operand format of the fwd/dgrad contractions (default f32 = the reference's arithmetic; "
                          "the other modes are extra, non-headline measurements)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the iteration as ONE captured HIP graph (runtime/graph.py; single GPU only) — an extra, "
+                         "non-default measurement of the host-bound small-batch configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--launch-table", default=None, help="write one line per contraction launch of the profiled iteration here")
@@ -248,14 +251,22 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graphed = None
+    if args.graph:
+        assert world == 1, "--graph is single-GPU only"
+        from pose_transfer_amd.runtime.graph import GraphedIteration
+        graphed = GraphedIteration(model, batches, od, warmup=max(2, args.warmup))
+    step = graphed.replay if graphed is not None else (lambda: iteration(model, batches, od))
     for _ in range(args.warmup):
-        iteration(model, batches, od)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        iteration(model, batches, od)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if graphed is not None:
+        graphed.close()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -326,7 +337,7 @@ def main():
                                       " (BASELINE.json configs[1])" if (args.size, P, args.batch) == (256, 18, 4) else ""),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size,
-                       "precision": args.precision},
+                       "precision": args.precision, **({"hip_graph": True} if args.graph else {})},
             "step_tflops": round(sf * ips / 1e12, 2),
             "step_frac_of_f32_mfma_peak": round(sf * ips / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,

@@ -319,6 +319,18 @@ int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float b1, f
 int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m, float* v, int64_t n, float b1, float b2, float eps,
                float step_size, float bc2_sqrt, float grad_scale, void* p_bf16, void* stream);
 
+/* ---- replay-safe scalars (HIP-graph capture of the iteration, runtime/graph.py): a captured graph freezes kernel
+ * arguments, so the two per-iteration scalars of the step — the dropout key and Adam's step number — come from a device
+ * counter that the graph itself increments once per replay.
+ *   pg_counter_add       : *ctr += inc (one thread)
+ *   pg_dropout_mask_ctr  : pg_dropout_mask with key' = mix64(key + *ctr * golden-ratio constant)
+ *   pg_adam_ctr          : pg_adam_ex with step = step0 + *ctr; bias corrections 1 - b^step evaluated in double on the device
+ *                          (torch.optim.Adam semantics, reference models/pose_gan.py:50-51) */
+int pg_counter_add(uint64_t* ctr, uint64_t inc, void* stream);
+int pg_dropout_mask_ctr(float* out, int64_t n, uint64_t key, float p, const uint64_t* ctr, void* stream);
+int pg_adam_ctr(float* p, const float* g, const void* g_bf16, float* m, float* v, int64_t n, double b1, double b2, float eps,
+                float lr, int64_t step0, const uint64_t* ctr, float grad_scale, void* p_bf16, void* stream);
+
 /* Weight gradient of a k4/s2/p1 Block convolution on the bf16 data path (autograd of nn.Conv2d / nn.ConvTranspose2d+crop
  * weights, models/networks.py:154-157), straight from pixel-major bf16 operands with transposing LDS reads
  * (csrc/wgrad_bf16.hip): dW[16 taps][Cout][ldw] fp32, columns [col_off, col_off + Cx) (+)= sum over pixels dY * X for ONE

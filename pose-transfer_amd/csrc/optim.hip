@@ -45,7 +45,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 template <bool GBF, bool WBF>
 __global__ __launch_bounds__(256) void adam_ex_kernel(float* p, const float* g, const unsigned short* gb, float* m, float* v,
                                                       long n, float b1, float b2, float eps, float step_size, float bc2_sqrt,
-                                                      float grad_scale, unsigned short* pb) {
+                                                      float grad_scale, unsigned short* pb, const unsigned long long* ctr = nullptr,
+                                                      long step0 = 0, double b1d = 0.0, double b2d = 0.0) {
+  if (ctr != nullptr) {       // replay-safe form (pg_adam_ctr): step = step0 + *ctr, `step_size` carries the plain learning rate
+    const double st = (double)(step0 + (long)ctr[0]);
+    step_size = (float)((double)step_size / (1.0 - pow(b1d, st)));
+    bc2_sqrt = (float)sqrt(1.0 - pow(b2d, st));
+  }
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -87,9 +93,10 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
   return x ^ (x >> 31);
 }
 
-__global__ void dropout_mask_kernel(float* out, long n, unsigned long long key, float p) {
+__global__ void dropout_mask_kernel(float* out, long n, unsigned long long key, float p, const unsigned long long* ctr = nullptr) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (ctr != nullptr) key = mix64(key + ctr[0] * 0x9E3779B97F4A7C15ULL);      // replay-safe form: a fresh stream per replay
   const unsigned long long bits = mix64((unsigned long long)i * 0xD1342543DE82EF95ULL + key);
   const double u = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
   out[i] = ((float)u >= p) ? 1.f / (1.f - p) : 0.f;
@@ -345,5 +352,45 @@ extern "C" int pg_channel_major_bf16(const float* x, const float* aff, const flo
   hipLaunchKernelGGL(pg::channel_major_bf16_kernel, dim3((unsigned)(K / 64), (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      x, aff, mask, act, N, H, W, C, sub, py, px, Hq, Wq, Wp, (long)K, reinterpret_cast<unsigned short*>(out_bf16));
   PG_LAUNCH_OK("pg_channel_major_bf16");
+  return 0;
+}
+
+// ---- replay-safe scalars: a HIP graph freezes kernel arguments, so the two per-iteration scalars of the training step —
+// the dropout key and Adam's step number — are derived on the device from a counter the graph itself increments.
+__global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long inc) { ctr[0] += inc; }
+
+extern "C" int pg_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {
+  PG_REQUIRE(ctr, "pg_counter_add: null counter");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(ctr),
+                     (unsigned long long)inc);
+  PG_LAUNCH_OK("pg_counter_add");
+  return 0;
+}
+
+extern "C" int pg_dropout_mask_ctr(float* out, int64_t n, uint64_t key, float p, const uint64_t* ctr, void* stream) {
+  PG_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f && ctr, "pg_dropout_mask_ctr: bad arguments");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
+                     (unsigned long long)key, p, reinterpret_cast<const unsigned long long*>(ctr));
+  PG_LAUNCH_OK("pg_dropout_mask_ctr");
+  return 0;
+}
+
+extern "C" int pg_adam_ctr(float* p, const float* g, const void* g_bf16, float* m, float* v, int64_t n, double b1, double b2,
+                           float eps, float lr, int64_t step0, const uint64_t* ctr, float grad_scale, void* p_bf16, void* stream) {
+  PG_REQUIRE(p && (g || g_bf16) && m && v && n > 0 && n % 4 == 0 && ctr && step0 >= 1, "pg_adam_ctr: bad arguments");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const unsigned short* gb = reinterpret_cast<const unsigned short*>(g_bf16);
+  unsigned short* pb = reinterpret_cast<unsigned short*>(p_bf16);
+  const unsigned long long* c = reinterpret_cast<const unsigned long long*>(ctr);
+#define PG_ADAM_CTR(G, W)                                                                                              \
+  hipLaunchKernelGGL((adam_ex_kernel<G, W>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, gb, m, v, (long)n, \
+                     (float)b1, (float)b2, eps, lr, 1.0f, grad_scale, pb, c, (long)step0, b1, b2)
+  if (gb && pb) PG_ADAM_CTR(true, true);
+  else if (gb) PG_ADAM_CTR(true, false);
+  else if (pb) PG_ADAM_CTR(false, true);
+  else PG_ADAM_CTR(false, false);
+#undef PG_ADAM_CTR
+  PG_LAUNCH_OK("pg_adam_ctr");
   return 0;
 }

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from ..runtime import dp as DP
+from ..runtime import engine as E
 from ..runtime import lib as L
 from ..utils import pose_utils, synth
 from .networks import Deformable_Generator, Discriminator, Generator, Stacked_Generator, xavier_weights_init
@@ -122,7 +123,9 @@ class DeformablePose_GAN(nn.Module):
         return self._bufs[key]
 
     def _drop_setup(self, eng, drop_masks, stage, call):
-        eng.drop_stream = "drop/r%d/i%d/%s/s%d" % (DP.rank(), self.iteration, call, stage)
+        # (in a HIP-graph replay session the iteration number comes from the device counter, not from this string)
+        it = 0 if E.REPLAY_CTR is not None else self.iteration
+        eng.drop_stream = "drop/r%d/i%d/%s/s%d" % (DP.rank(), it, call, stage)
         eng._drop_counter = 0
         eng.set_dropout(drop_masks, train=True, seed=self.seed)
 

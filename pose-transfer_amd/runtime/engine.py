@@ -183,6 +183,20 @@ class ParamArena:
         grads_bf16: read the (all-reduced) bf16 gradient sums instead of the fp32 arena (runtime/dp.py bf16 buckets)."""
         self.step += 1
         self._bump_version()
+        if REPLAY_CTR is not None:
+            # replay-safe form: the graph freezes arguments, so the step number is step_base + the device counter (the first
+            # optimiser step recorded in replay mode has counter 0); host bookkeeping (self.step) is kept by runtime/graph.py
+            if getattr(self, "replay_base", None) is None:
+                self.replay_base = self.step
+            want_bf16 = PRECISION == 3 and self.params.is_cuda
+            if want_bf16 and self.params_bf16 is None:
+                self.params_bf16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.params.device)
+            L.call("pg_adam_ctr", L.ptr(self.params), L.ptr(self.grads), L.ptr(grads_bf16), L.ptr(self.m), L.ptr(self.v),
+                   self.total, float(b1), float(b2), eps, lr, self.replay_base, L.ptr(REPLAY_CTR), grad_scale,
+                   L.ptr(self.params_bf16) if want_bf16 else None, L.stream())
+            if want_bf16:
+                self.bf16_version = self.version()
+            return
         bc1 = 1.0 - b1 ** self.step
         bc2 = 1.0 - b2 ** self.step
         want_bf16 = PRECISION == 3 and self.params.is_cuda
@@ -390,6 +404,9 @@ def _conv_dgrad(gy_src, N, Hi, Wi, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, d
     (A per-tap pre-transposed weight copy was measured: no gain over reading the [k][n] operand directly.)"""
     _conv([gy_src], N, Hi, Wi, L.ACT_NONE, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, transposed=True, dsts=dsts,
           ksplit=ksplit)
+
+
+REPLAY_CTR = None         # device uint64 counter of a HIP-graph replay session (runtime/graph.py); None = host-side scalars
 
 
 NORM_BWD_BF16 = os.environ.get("PG_NO_NORM_BWD_BF16") is None    # ablation switch: separate materialisation of dy
@@ -809,7 +826,10 @@ class GeneratorEngine:
             for i, d in enumerate(self.drop):
                 self._drop_counter += 1
                 key = int(synth._stream_key(seed, "%s/N%d/%d/%d" % (self.drop_stream, self.N, self._drop_counter, i)))
-                L.call("pg_dropout_mask", L.ptr(d), d.numel(), key, 0.5, L.stream())
+                if REPLAY_CTR is not None:     # the key is frozen into the graph: the device counter makes every replay differ
+                    L.call("pg_dropout_mask_ctr", L.ptr(d), d.numel(), key, 0.5, L.ptr(REPLAY_CTR), L.stream())
+                else:
+                    L.call("pg_dropout_mask", L.ptr(d), d.numel(), key, 0.5, L.stream())
 
     def forward(self, inp, warps=None, masks=None):
         global _BF_CTX

@@ -511,3 +511,59 @@ def test_two_ranks_equal_global_batch_step(tmp_path):
         assert float((res[k] - ref[k]).abs().max()) < 2e-4 * float(ref[k].abs().max()), k
     for k in ("gen", "disc"):
         assert float((res[k] - ref[k]).abs().max()) <= 4 * 2e-4 + 1e-7, k
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16_data"])
+def test_hip_graph_replay_matches_eager(prec, monkeypatch):
+    """runtime/graph.py: dis_update + gen_update captured into ONE HIP graph; the dropout key and Adam's step number come
+    from a device counter (pg_dropout_mask_ctr / pg_adam_ctr).  With explicit dropout masks the graph session (1 eager warm-up
+    + 3 replays) must land on the same parameters as 4 eager iterations up to run-to-run summation noise; with device dropout two replays must differ (fresh key per replay)."""
+    from pose_transfer_amd.runtime.graph import GraphedIteration
+    monkeypatch.setattr(E, "PRECISION", PREC[prec])
+    P, H, W, N = 18, 64, 64, 2
+    enc, dec = synth.nfilters((H, W))
+    opt = _opt((H, W), P, N)
+    od = dict(vars(opt), lazy_losses=True)
+
+    def fresh():
+        m = DeformablePose_GAN(opt, device=DEV)
+        m.gen.load_state_dict(tp(synth.init_params(91, "graph/gen", synth.generator_spec(P, enc, dec), 0.1)))
+        m.disc.load_state_dict(tp(synth.init_params(91, "graph/disc", synth.discriminator_spec(3 + 2 * P + 3), 0.1)))
+        return m
+
+    batches = [dev(*[t(a) for a in synth.batch(91, "graph/%s" % s, N, P, H, W)]) for s in "ABC"]
+    dA = dev(*[t(m) for m in synth.dropout_masks(91, "graph/dA", N)])
+    dC = dev(*[t(m) for m in synth.dropout_masks(91, "graph/dC", N)])
+    eager = fresh()
+    for _ in range(4):
+        a, b, c = batches
+        eager.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3], "drop_masks": dA}, b[0], b[1], od)
+        eager.gen_update(c[0], c[1], {"warps": c[2], "masks": c[3], "drop_masks": dC}, od)
+    g_model = fresh()
+    g = GraphedIteration(g_model, batches, od, warmup=1, drop_masks=(dA, dC))
+    for _ in range(3):
+        out, dl, gl = g.replay()
+    torch.cuda.synchronize()
+    g.close()
+    assert g_model.gen.arena.step == eager.gen.arena.step == 4 and g_model.disc.arena.step == 4
+    # Two runs of the same step differ by fp32 summation order (float atomics in the weight gradients); Adam's first steps
+    # (~lr * sign(g)) turn that into O(lr) on single parameters (DESIGN.md section 4).  Bar: no parameter further apart than
+    # 1.5 * steps * lr, the typical one at rounding level (bf16 data path: bf16-rounded operands, looser median).
+    lr, steps = float(opt.learning_rate), 4
+    for me, mg in ((eager.gen, g_model.gen), (eager.disc, g_model.disc)):
+        d = (me.arena.params - mg.arena.params).abs()
+        assert float(d.max()) <= 1.5 * steps * lr, float(d.max())
+        assert float(d.median()) <= (2e-5 if prec == "f32" else 2e-4), float(d.median())      # lr = 2e-4
+    assert torch.isfinite(out).all() and torch.isfinite(dl).all() and torch.isfinite(gl).all()
+    # device dropout: two replays of a fresh session see different masks (the counter feeds the key)
+    m2 = fresh()
+    g2 = GraphedIteration(m2, batches, od, warmup=1)
+    eng = m2.gen.engine(N)
+    g2.replay(); torch.cuda.synchronize(); d1 = [d.clone() for d in eng.drop]
+    g2.replay(); torch.cuda.synchronize(); d2 = [d.clone() for d in eng.drop]
+    g2.close()
+    assert any(not torch.equal(x, y) for x, y in zip(d1, d2))
+    # and eager mode still works afterwards (host-side scalars again)
+    a, b, c = batches
+    m2.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3]}, b[0], b[1], od)
+    assert m2.disc.arena.step == 4
