@@ -1577,11 +1577,11 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     //   T(c) = rounds(c) * (t_iter * ceil(ktot / c) + t_fixed) + [c > 1] * (2 c out_bytes / BW + t_launch)
     // rounds = ceil(blocks c / 512) (two co-resident workgroups x 256 CUs), t_iter = the K-tile time of one workgroup at
     // the sustained rate of the operand format, t_fixed = prologue + epilogue of a workgroup, the last term = partial
-    // tiles written and read back by the fix-up kernel.  tools/r2_gpu11.sh sweeps the two constants (PG_SPLITK_* override): flat within 2 % over 4-30 us and 1.5-3 TB/s;
+    // tiles written and read back by the fix-up kernel.  tools/sweep_splitk_model.sh sweeps the two constants (PG_SPLITK_* override): flat within 2 % over 4-30 us and 1.5-3 TB/s;
     // configs[2] (224^2, P = 32, batch 8): fp32 167 -> 210 img/s, bf16 data path 446 -> 681 img/s against the round-1 rule.
     static const double t_fixed = getenv("PG_SPLITK_FIXED_US") ? atof(getenv("PG_SPLITK_FIXED_US")) : 12.0;
     static const double bw_tbs = getenv("PG_SPLITK_BW_TBS") ? atof(getenv("PG_SPLITK_BW_TBS")) : 3.0;
-    static const double t_launch = 6.0;
+    static const double t_launch = getenv("PG_SPLITK_LAUNCH_US") ? atof(getenv("PG_SPLITK_LAUNCH_US")) : 6.0;
     const double rate_tf = d->precision == PG_PREC_F32 ? 125.0 : (d->precision == PG_PREC_BF16X3 ? 250.0 : 650.0);
     const double t_iter = 2.0 * BMs[cfg] * BNs[cfg] * ((amode == A_VEC) ? bke : BK) / (rate_tf * 1e6 / 512.0);      // us
     const long blocks = (long)mt * nt * (tb ? tb->gtaps : k.nphase);

@@ -311,7 +311,7 @@ extern "C" int pg_wgrad_bf16(const void* x_bf16, int32_t Cx, const void* dy_bf16
   if (ks <= 0) {
     // ~128 workgroups per launch (half a round of the 256 CUs), >= 16 K tiles per workgroup.  Weight gradients run on the
     // side stream NEXT TO the data-gradient chain: a launch that wants every CU only takes them from the main stream, and
-    // every extra split adds a full set of float atomics on dW.  Swept on the box (tools/r2_gpu21.sh), img/s at 256^2 batch
+    // every extra split adds a full set of float atomics on dW.  Swept on the box (tools/sweep_wgrad_bf16_target.sh), img/s at 256^2 batch
     // 32 / batch 4 / 224^2 P=32 batch 8: target 768 -> 776 / 464 / 704, 256 -> 788 / 465 / 713, 128 -> 793 / 475 / 724,
     // 64 -> 681 / 439 / 656.
     const long base = (long)mt * nt * 16;
