@@ -326,6 +326,8 @@ int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m, float* v,
  *   pg_dropout_mask_ctr  : pg_dropout_mask with key' = mix64(key + *ctr * golden-ratio constant)
  *   pg_adam_ctr          : pg_adam_ex with step = step0 + *ctr; bias corrections 1 - b^step evaluated in double on the device
  *                          (torch.optim.Adam semantics, reference models/pose_gan.py:50-51) */
+/* out[i] = a[i] + b[i], n elements (out may alias an input): loss totals (pose_gan.py:109,160), dW += product buffer */
+int pg_add2(float* out, const float* a, const float* b, int64_t n, void* stream);
 int pg_counter_add(uint64_t* ctr, uint64_t inc, void* stream);
 int pg_dropout_mask_ctr(float* out, int64_t n, uint64_t key, float p, const uint64_t* ctr, void* stream);
 int pg_adam_ctr(float* p, const float* g, const void* g_bf16, float* m, float* v, int64_t n, double b1, double b2, float eps,

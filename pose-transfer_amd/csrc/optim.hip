@@ -394,3 +394,18 @@ extern "C" int pg_adam_ctr(float* p, const float* g, const void* g_bf16, float* 
   PG_LAUNCH_OK("pg_adam_ctr");
   return 0;
 }
+
+// out[i] = a[i] + b[i] (out may alias a or b): the loss total of a step (pose_gan.py:109,160) and the accumulation of a
+// product buffer into dW — so that no arithmetic of the path runs through a torch operator
+__global__ __launch_bounds__(256) void add2_kernel(float* out, const float* a, const float* b, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
+extern "C" int pg_add2(float* out, const float* a, const float* b, int64_t n, void* stream) {
+  PG_REQUIRE(out && a && b && n > 0, "pg_add2: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add2_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, a, b, (long)n);
+  PG_LAUNCH_OK("pg_add2");
+  return 0;
+}

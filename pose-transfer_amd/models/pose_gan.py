@@ -206,7 +206,8 @@ class DeformablePose_GAN(nn.Module):
             self.g_reducer.finish()
             scale, gb = 1.0 / self.world, self.g_reducer.grad_source()[1]
         self.gen_opt.step(grad_scale=scale, grads_bf16=gb)
-        self._loss[0:1].copy_(self._loss[1:2] + self._loss[2:3])      # total = ll + ad  (pose_gan.py:109)
+        lp = L.ptr(self._loss)
+        L.call("pg_add2", lp, lp + 4, lp + 8, 1, L.stream())        # total = ll + ad  (pose_gan.py:109)
         losses = self._losses(0, opt.get("lazy_losses", False))
         # a fresh tensor like the reference's (the engine's output buffer is overwritten by the next forward)
         outputs = [e.out.clone() for e in engs] if self.gen_type == "stacked" else []
@@ -236,7 +237,8 @@ class DeformablePose_GAN(nn.Module):
             self.d_reducer.finish()
             scale, gb = 1.0 / self.world, self.d_reducer.grad_source()[1]
         self.disc_opt.step(grad_scale=scale, grads_bf16=gb)
-        self._loss[4:5].copy_(self._loss[5:6] + self._loss[6:7])
+        lp = L.ptr(self._loss)
+        L.call("pg_add2", lp + 16, lp + 20, lp + 24, 1, L.stream())
         return self._losses(4, opt.get("lazy_losses", False))
 
     # ------------------------------------------------------------------------------------------

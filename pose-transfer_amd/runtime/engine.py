@@ -525,7 +525,7 @@ def _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
         a_ptr, b_ptr, a_off, b_off = large, small, shift, zero
     prod = pool[2][:16 * Cout * Cin]
     L.call("pg_gemm_taps_bf16", a_ptr, b_ptr, Cout, Cin, Kp, 16, a_off.data_ptr(), b_off.data_ptr(), L.ptr(prod), L.stream())
-    dW.view(-1).add_(prod)
+    L.call("pg_add2", L.ptr(dW), L.ptr(dW), L.ptr(prod), 16 * Cout * Cin, L.stream())
 
 
 _BF_WGT = {}       # device -> bf16 scratch of the transposing-read weight gradient: [x per source slot ..., dY]

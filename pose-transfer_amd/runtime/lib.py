@@ -69,6 +69,7 @@ _PROTOS = {
     "pg_repack_small_cin": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_small_cin_conv": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pg_small_cin_wgrad": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
+    "pg_add2": [_vp, _vp, _vp, _i64, _vp],
     "pg_counter_add": [_vp, _u64, _vp],
     "pg_dropout_mask_ctr": [_vp, _i64, _u64, _f32, _vp, _vp],
     "pg_adam_ctr": [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, _f32, _f32, _i64, _vp, _f32, _vp, _vp],

@@ -548,11 +548,12 @@ def test_hip_graph_replay_matches_eager(prec, monkeypatch):
     assert g_model.gen.arena.step == eager.gen.arena.step == 4 and g_model.disc.arena.step == 4
     # Two runs of the same step differ by fp32 summation order (float atomics in the weight gradients); Adam's first steps
     # (~lr * sign(g)) turn that into O(lr) on single parameters.  Bar: no parameter further apart than
-    # 1.5 * steps * lr, the typical one at rounding level (bf16 data path: bf16-rounded operands, looser median).
+    # 2.5 * steps * lr (opposite update signs in every step = 2 lr per step, Adam's early |m/sqrt(v)| slightly above 1), the
+    # typical one at rounding level (bf16 data path: bf16-rounded operands, looser median).
     lr, steps = float(opt.learning_rate), 4
     for me, mg in ((eager.gen, g_model.gen), (eager.disc, g_model.disc)):
         d = (me.arena.params - mg.arena.params).abs()
-        assert float(d.max()) <= 1.5 * steps * lr, float(d.max())
+        assert float(d.max()) <= 2.5 * steps * lr, float(d.max())
         assert float(d.median()) <= (2e-5 if prec == "f32" else 2e-4), float(d.median())      # lr = 2e-4
     assert torch.isfinite(out).all() and torch.isfinite(dl).all() and torch.isfinite(gl).all()
     # device dropout: two replays of a fresh session see different masks (the counter feeds the key)
