@@ -9,7 +9,8 @@ advancing offset.  As soon as a bucket worth of gradients is complete its all-re
 stream that waits — through HIP events recorded at that moment — for exactly the work that produced the bucket: the main
 stream (data-gradient chain) and the weight-gradient side stream.  Neither of them waits for the collective; only the
 optimiser step at the end of the pass does (`finish()`).  The 1/world scaling is folded into the fused Adam kernel
-(grad_scale).  xGMI is point-to-point (7 links x ~153 GB/s): a few large buckets keep every link busy with few launches.
+(grad_scale).  xGMI is point-to-point (7 links x ~153 GB/s): large buckets keep every link busy with few launches; the bucket size shrinks
+towards the end of the arena (`_threshold`) so that what is left for `finish()` — the exposed tail — is a few MB.
 
 Transport: on the device the collective is RCCL behind the C ABI (`pg_comm_*`, include/posegan_hip.h; the rendezvous
 token travels over the torch.distributed store that torch.distributed.run already set up).  `PG_DP_BACKEND=torch` or a
@@ -90,9 +91,10 @@ def destroy_comms():
 class GradReducer:
     """Bucketed SUM all-reduce of a flat gradient arena, issued as buckets complete during backward."""
 
-    def __init__(self, arena, world, bucket_bytes=64 << 20, group=None, backend=None, grad_dtype=None):
+    def __init__(self, arena, world, bucket_bytes=64 << 20, group=None, backend=None, grad_dtype=None, min_bucket_bytes=2 << 20):
         self.arena, self.world, self.group = arena, world, group
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.min_bucket_elems = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.keys = list(arena.keys)
         self.index = {k: i for i, k in enumerate(self.keys)}
         self.on_device = arena.grads.is_cuda
@@ -135,8 +137,17 @@ class GradReducer:
         while self.next_key < len(self.keys) and self.ready[self.next_key]:
             self.next_key += 1
         upto = self._end_offset(self.next_key)
-        if upto - self.launched >= self.bucket_elems:
+        if upto - self.launched >= self._threshold():
             self._launch(upto)
+
+    def _threshold(self):
+        """Bucket size that shrinks towards the end of the arena: a quarter of what is still unreduced, between
+        min_bucket and bucket.  The deep layers hold most of the parameters and finish EARLY in the backward pass, the
+        high-resolution layers that finish last hold almost none — with a fixed 64 MB bucket the last 36 MB of the
+        generator's 164 MB waited for finish() and their all-reduce ran after the backward pass, exposed; with the
+        shrinking bucket at most min_bucket (2 MB) is left for finish()."""
+        remaining = self.arena.total - self.launched
+        return min(self.bucket_elems, max(self.min_bucket_elems, remaining // 4))
 
     def _wait_producers(self):
         """The communication stream waits for the work enqueued SO FAR on the main stream and on the weight-gradient

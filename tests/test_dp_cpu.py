@@ -75,6 +75,26 @@ def test_grad_reducer_two_ranks():
         assert launches[-1] >= 2 and launches[0] == 0      # several buckets, issued while "backward" was running
 
 
+def test_grad_reducer_bucket_shrinks_towards_the_end():
+    """The deep layers (most parameters) finish first, the high-resolution layers (few parameters) last: the bucket
+    threshold shrinks with what is still unreduced, so that finish() — the all-reduce that cannot overlap the backward
+    pass — is left with at most min_bucket."""
+    import pta_bootstrap
+    pta_bootstrap.load()
+    from pose_transfer_amd.runtime import dp
+    sizes = [1 << 22, 1 << 22, 1 << 21, 1 << 21, 1 << 20, 1 << 19, 1 << 18, 1 << 16, 1 << 14, 1 << 12, 1 << 10, 576]   # ~52 MB of fp32
+    arena = FakeArena(sizes)
+    red = dp.GradReducer(arena, 1, bucket_bytes=16 << 20, min_bucket_bytes=1 << 20)
+    fixed = dp.GradReducer(arena, 1, bucket_bytes=16 << 20, min_bucket_bytes=16 << 20)      # the round-1 rule
+    for k in arena.keys[:-1]:
+        red.mark_ready([k]); fixed.mark_ready([k])
+    left, left_fixed = arena.total - red.launched, arena.total - fixed.launched
+    assert left * 4 <= (1 << 20) + 4 * 640 and left_fixed > 4 * left, (left, left_fixed)
+    assert red.launch_count <= 16                          # still a handful of collectives, not one per tensor
+    red.mark_ready([arena.keys[-1]]); red.finish()
+    assert red.launched == arena.total
+
+
 def _dp_worker(rank, world, port, q):
     try:
         _dp_worker_impl(rank, world, port, q)
