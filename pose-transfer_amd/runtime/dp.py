@@ -149,22 +149,31 @@ class GradReducer:
         remaining = self.arena.total - self.launched
         return min(self.bucket_elems, max(self.min_bucket_elems, remaining // 4))
 
-    def _wait_producers(self):
-        """The communication stream waits for the work enqueued SO FAR on the main stream and on the weight-gradient
-        side stream (events recorded now); the producers themselves do not wait for anything."""
+    def _wait_producers(self, final=False):
+        """The communication stream waits — through events recorded now — for the producers of the range it is about to
+        reduce; the producers themselves do not wait for anything.
+
+        Weight gradients are written by the side stream.  The few gradients the MAIN stream writes (norm gamma / beta, conv
+        biases) are enqueued before the same layer's weight-gradient call, and that call makes the side stream wait for
+        the main stream (engine._wgrad) — so "the side stream has reached this point" already implies them, and a bucket
+        launched from a `_ready` hook only needs the side-stream event.  (An event on the main stream per bucket cost 4 %
+        of the iteration on one GPU: 170 -> 163 img/s)  The last launch (finish) and runs without a
+        side stream wait for the main stream as well; PG_DP_WAIT_MAIN=1 restores the conservative form everywhere."""
         from . import engine as E
         dev = self.arena.grads.device
         cs = self.comm_stream
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        cs.wait_event(ev)
         side = E._SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
-        if E.SIDE_STREAM and side is not None:
+        side_on = E.SIDE_STREAM and side is not None
+        if final or not side_on or os.environ.get("PG_DP_WAIT_MAIN") == "1":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            cs.wait_event(ev)
+        if side_on:
             ev2 = torch.cuda.Event()
             ev2.record(side)
             cs.wait_event(ev2)
 
-    def _launch(self, upto):
+    def _launch(self, upto, final=False):
         if upto <= self.launched:
             return
         lo, n = self.launched, upto - self.launched
@@ -174,7 +183,7 @@ class GradReducer:
             if self.world > 1:
                 self.works.append(dist.all_reduce(self.arena.grads[lo:upto], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
-        self._wait_producers()
+        self._wait_producers(final)
         buf = self.arena.grads[lo:upto]
         with torch.cuda.stream(self.comm_stream):
             if self.bf16:
@@ -190,7 +199,7 @@ class GradReducer:
     def finish(self):
         """Issue whatever is left (keys never reported count as ready: e.g. unused parameters) and make the optimiser's
         stream wait for the collectives."""
-        self._launch(self.arena.total)
+        self._launch(self.arena.total, final=True)
         for w in self.works:
             w.wait()
         self.works = []
