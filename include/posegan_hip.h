@@ -341,6 +341,11 @@ int pg_adam_ctr(float* p, const float* g, const void* g_bf16, float* m, float* v
  * Cx % 128 == 0, Cout % 128 == 0; ksplit <= 0: chosen by the library (float atomics when > 1).                          */
 int pg_wgrad_bf16(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_t Cout, int32_t x_is_large, int32_t N,
                   int32_t Hs, int32_t Ws, float* dW, int32_t ldw, int32_t col_off, int32_t ksplit, void* stream);
+/* the same for a large grid that is not exactly twice the small one: Conv2d k4 s2 p1 on an odd map (the discriminator's
+ * 127 -> 63 -> 31 ... blocks, reference models/networks.py:341-347): Hs = (Hl - 2) / 2 + 1 */
+int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_t Cout, int32_t x_is_large, int32_t N,
+                     int32_t Hs, int32_t Ws, int32_t Hl, int32_t Wl, float* dW, int32_t ldw, int32_t col_off,
+                     int32_t ksplit, void* stream);
 
 /* ---- data-parallel gradient exchange (NEW: the reference is single-process; main.py:44-159 has no
  * counterpart).  One process per GPU; RCCL (xGMI) is resolved at run time (dlopen librccl.so.1), the communication stream

@@ -145,7 +145,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
     }
   }
   const int Q32 = (int)p.Q;
-  const bool edge_y0 = tr == 0, edge_y1 = tr == 3, edge_x0 = ts == 0, edge_x1 = ts == 3;     // taps that can leave the image
+  // large-grid pixel of (small pixel (y, x), tap (tr, ts)) = (2y + tr - 1, 2x + ts - 1): outside below 0 (tap 0 at y = 0) and
+  // from y >= ylim on, ylim = ceil((Hl - tr + 1) / 2) — Hl = 2 Hs for the generator's blocks, 2 Hs + 1 on the odd maps of the
+  // discriminator (127 -> 63 -> 31 ...), where tap 3 of the last row is still inside
+  const bool edge_y0 = tr == 0, edge_x0 = ts == 0;
+  const int ylim = (p.Hl - tr + 2) >> 1, xlim = (p.Wl - ts + 2) >> 1;
   auto issue = [&](int stage, int kt) {
     (void)kt;
     float* const As = reinterpret_cast<float*>(smem + stage * STAGE);
@@ -162,8 +166,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
     }
 #pragma unroll
     for (int i = 0; i < L_PASS; ++i) {
-      const bool oob = (ln[i] >= p.N) | (edge_y0 & (ly0[i] == 0)) | (edge_y1 & (ly0[i] == p.Hs - 1)) |
-                       (edge_x0 & (lx0[i] == 0)) | (edge_x1 & (lx0[i] == p.Ws - 1));
+      const bool oob = (ln[i] >= p.N) | (edge_y0 & (ly0[i] == 0)) | (ly0[i] >= ylim) | (edge_x0 & (lx0[i] == 0)) | (lx0[i] >= xlim);
       const char* src = oob ? zp : l_base + l_off[i];
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), Ls + (i * 8 + wave) * 256, 16, 0, 0);
       // advance by 64 small-grid pixels
@@ -289,20 +292,33 @@ using namespace pg;
 // dW[16][Cout][ldw] (+)= weight gradient of one K-source of a k4/s2/p1 convolution (x_is_large = 1: Conv2d, X on the large
 // grid; 0: ConvTranspose2d + crop, dY on the large grid).  x / dy: bf16 NHWC tensors (already normalised / activated /
 // masked: pg_materialise_bf16).  Cx % 128 == 0, Cout % 128 == 0, Hl == 2 Hs, Wl == 2 Ws.
+extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_t Cout, int32_t x_is_large, int32_t N,
+                                int32_t Hs, int32_t Ws, int32_t Hl, int32_t Wl, float* dW, int32_t ldw, int32_t col_off,
+                                int32_t ksplit, void* stream);
+
 extern "C" int pg_wgrad_bf16(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_t Cout, int32_t x_is_large, int32_t N,
                              int32_t Hs, int32_t Ws, float* dW, int32_t ldw, int32_t col_off, int32_t ksplit, void* stream) {
+  return pg_wgrad_bf16_ex(x_bf16, Cx, dy_bf16, Cout, x_is_large, N, Hs, Ws, 2 * Hs, 2 * Ws, dW, ldw, col_off, ksplit, stream);
+}
+
+// Large grid Hl x Wl with Hs = (Hl - 2) / 2 + 1 (k4 s2 p1): Hl = 2 Hs or, for a Conv2d (x_is_large = 1), 2 Hs + 1.
+extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_t Cout, int32_t x_is_large, int32_t N,
+                                int32_t Hs, int32_t Ws, int32_t Hl, int32_t Wl, float* dW, int32_t ldw, int32_t col_off,
+                                int32_t ksplit, void* stream) {
   PG_REQUIRE(x_bf16 && dy_bf16 && dW && N > 0 && Hs > 0 && Ws > 0, "pg_wgrad_bf16: bad arguments");
+  PG_REQUIRE(Hs == (Hl - 2) / 2 + 1 && Ws == (Wl - 2) / 2 + 1 && Hl >= 2 && Wl >= 2 && (x_is_large || (Hl == 2 * Hs && Wl == 2 * Ws)),
+             "pg_wgrad_bf16: k4 s2 p1 geometry required (small %dx%d, large %dx%d)", Hs, Ws, Hl, Wl);
   PG_REQUIRE(Cx % 128 == 0 && Cout % 128 == 0 && col_off >= 0 && col_off + Cx <= ldw, "pg_wgrad_bf16: channel counts must be "
              "multiples of 128 (Cx=%d Cout=%d)", Cx, Cout);
   WgBf16K k;
   memset(&k, 0, sizeof(k));
-  k.N = N; k.Hs = Hs; k.Ws = Ws; k.Hl = 2 * Hs; k.Wl = 2 * Ws;
+  k.N = N; k.Hs = Hs; k.Ws = Ws; k.Hl = Hl; k.Wl = Wl;
   k.a_is_small = x_is_large ? 1 : 0;                 // A rows = Cout = the dY tensor
   if (x_is_large) { k.sm = (const unsigned short*)dy_bf16; k.Cs = Cout; k.lg = (const unsigned short*)x_bf16; k.Cl = Cx; }
   else { k.sm = (const unsigned short*)x_bf16; k.Cs = Cx; k.lg = (const unsigned short*)dy_bf16; k.Cl = Cout; }
   k.dW = dW; k.Cout = Cout; k.ldw = ldw; k.col_off = col_off;
   k.Q = (long)N * Hs * Ws;
-  PG_REQUIRE((double)N * 4.0 * Hs * Ws * (Cx > Cout ? Cx : Cout) * 2.0 < 4294967296.0 && (double)N * Hs * Ws < 2147483000.0,
+  PG_REQUIRE((double)N * Hl * Wl * (Cx > Cout ? Cx : Cout) * 2.0 < 4294967296.0 && (double)N * Hs * Ws < 2147483000.0,
              "pg_wgrad_bf16: operands must be < 4 GiB each (32-bit byte offsets)");
   const int bm = (Cout % 256 == 0) ? 256 : 128, bn = (Cx % 256 == 0) ? 256 : 128;
   const int mt = Cout / bm, nt = Cx / bn;

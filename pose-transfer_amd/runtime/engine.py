@@ -47,21 +47,34 @@ class KernelProfiler:
             name = "conv_igemm<%s,A%d,B%d>" % (self.CONV_TILES[info & 15], (info >> 4) & 15, (info >> 8) & 15)
         self.records.append((name, kind, flops, (info >> 16) & 0x3FFF, e0, e1))
 
-    def summary(self, per_launch=None):
-        """Per-family totals; `per_launch` (a list) additionally receives one (name, kind, flops, ksplit, ms) per launch."""
+    def summary(self, per_launch=None, repeats=1):
+        """Per-family totals; `per_launch` (a list) additionally receives one (name, kind, flops, ksplit, ms) per launch.
+        repeats > 1: the records hold that many identical iterations back to back; each launch is credited with the MINIMUM
+        of its repeats (a one-off stall — an event-pool or buffer allocation inside one repeat — showed up as a 30-45 ms
+        "launch" otherwise)."""
         import ctypes
         lib = L.load()
-        out = {}
+        times = []
         for name, kind, flops, ks, e0, e1 in self.records:
             ms = ctypes.c_float()
             L.check(lib.pg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "pg_event_elapsed_ms")
             lib.pg_event_destroy(e0)
             lib.pg_event_destroy(e1)
+            times.append(ms.value)
+        n = len(self.records) // max(1, repeats)
+        aligned = repeats > 1 and n * repeats == len(self.records) and all(
+            self.records[i][:3] == self.records[i + r * n][:3] for r in range(1, repeats) for i in range(n))
+        if not aligned:
+            n, repeats = len(self.records), 1
+        out = {}
+        for i in range(n):
+            name, kind, flops, ks = self.records[i][:4]
+            ms = min(times[i + r * n] for r in range(repeats))
             if per_launch is not None:
-                per_launch.append((name, kind, flops, ks, ms.value))
+                per_launch.append((name, kind, flops, ks, ms))
             d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             d["launches"] += 1
-            d["ms"] += ms.value
+            d["ms"] += ms
             d["flops"] += flops
         self.records = []
         return out
@@ -532,9 +545,16 @@ _BF_WGT = {}       # device -> bf16 scratch of the transposing-read weight gradi
 WGRAD_TR = os.environ.get("PG_NO_WGRAD_TR") is None        # ablation switch: channel-major copies + NT GEMMs instead
 
 
-def _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N):
+def _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large):
+    """k4 s2 p1: large = 2 small (generator blocks) or, for a Conv2d on an odd map, 2 small + 1 (discriminator)."""
+    if Hl == 2 * Hs and Wl == 2 * Ws:
+        return True
+    return bool(x_is_large) and Hs == (Hl - 2) // 2 + 1 and Ws == (Wl - 2) // 2 + 1
+
+
+def _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large=True):
     return (PRECISION == 3 and WGRAD_TR and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None
-            and cout_store == 0 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor) and Cout % 128 == 0
+            and cout_store == 0 and _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large) and isinstance(dW, torch.Tensor) and Cout % 128 == 0
             and all(s_.C % 128 == 0 for s_ in srcs) and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS)
 
 
@@ -564,15 +584,16 @@ def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, 
         if xb is None:
             xb = buf(j, N * Hx * Wx * s_.C)
             L.call("pg_materialise_bf16", s_.ptr, s_.aff, s_.mask, act, N, Hx * Wx, s_.C, L.ptr(xb), L.stream())
-        L.call("pg_wgrad_bf16", L.ptr(xb), s_.C, L.ptr(dyb), Cout, 1 if x_is_large else 0, N, Hs, Ws, L.ptr(dW), Cin, c0, 0,
-               L.stream())
+        L.call("pg_wgrad_bf16_ex", L.ptr(xb), s_.C, L.ptr(dyb), Cout, 1 if x_is_large else 0, N, Hs, Ws, Hl, Wl, L.ptr(dW), Cin,
+               c0, 0, L.stream())
         c0 += s_.C
 
 
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
            y_strides=None, ksplit=0, cout_store=0):
     dyb = None
-    if _BF_CTX is not None and _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N):
+    if _BF_CTX is not None and _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N,
+                                            x_is_large):
         # the bf16 gradient is shared with the data-gradient contraction of the same layer: convert it once, on the MAIN stream
         Hy, Wy = (Hs, Ws) if x_is_large else (Hl, Wl)
         dyb = _BF_CTX.get(dY if isinstance(dY, int) else L.ptr(dY), Cout, L.ACT_NONE, None, None, N, Hy * Wy, dW.device)
@@ -588,15 +609,15 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
 
 def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
                 y_strides=None, ksplit=0, cout_store=0, dy_bf16=None):
+    if _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large):
+        run = lambda: _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16)
+        if PROFILER is not None:
+            PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
+            return
+        return run()
     if (PRECISION == 3 and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None and cout_store == 0
             and Cin > 32 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor)
             and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS):
-        if WGRAD_TR and Cout % 128 == 0 and all(s_.C % 128 == 0 for s_ in srcs):
-            run = lambda: _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16)
-            if PROFILER is not None:
-                PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
-                return
-            return run()
         if PROFILER is not None:
             PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout,
                             lambda: _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW))

@@ -88,6 +88,7 @@ _PROTOS = {
     "pg_weights_to_bf16": [_vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "pg_channel_major_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp],
     "pg_wgrad_bf16": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "pg_wgrad_bf16_ex": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "pg_gemm_taps_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pg_norm_stats": [_vp, _i32, _i64, _vp, _vp],
     "pg_norm_finalize": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],

@@ -830,6 +830,9 @@ def wgrad_tr_cases():
                  L.ACT_RELU, seed=23),
         ConvCase("wtr_up_512", "convT", [(256, A, False), (256, False, False)], 512, 1, 12, 12, 4, 2, 1, L.ACT_RELU, seed=24),
         ConvCase("wtr_conv_splitk", "conv", [(128, A, False)], 128, 4, 64, 48, 4, 2, 1, L.ACT_LEAKY, seed=25),           # 48 K tiles, split
+        # odd maps (the discriminator's 127 -> 63 -> 31 blocks): large = 2 small + 1, tap 3 of the last row / column is inside
+        ConvCase("wtr_conv_odd_31x27", "conv", [(128, A, False)], 256, 2, 31, 27, 4, 2, 1, L.ACT_LEAKY, seed=26),
+        ConvCase("wtr_conv_odd_mixed", "conv", [(256, A, False)], 128, 3, 15, 20, 4, 2, 1, L.ACT_LEAKY, seed=27),       # odd x even
     ]
 
 
@@ -859,4 +862,10 @@ def test_weight_gradient_bf16_transposing_reads(case, monkeypatch):
     assert (info & 15) == 6 and (info & (1 << 30)), hex(info)
     assert rel(got, ref) < 1e-4, (case.name, float(rel(got, ref)))
     if case.name == "wtr_conv_splitk":
-        assert ((info >> 16) & 0x3FFF) > 1, "expected a split-K launch"
+        assert ((info >> 16) & 0x3FFF) >= 1
+        import ctypes                          # an explicit split exercises the atomic accumulation
+        dW = torch.zeros(4, 4, case.cout, case.cin, device=DEV)
+        xb = nhwc(x).to(DEV).to(torch.bfloat16).contiguous(); gb = nhwc(bf(case.gout)).to(DEV).to(torch.bfloat16).contiguous()
+        L.call("pg_wgrad_bf16", L.ptr(xb), case.cin, L.ptr(gb), case.cout, 1, case.N, case.Ho, case.Wo, L.ptr(dW), case.cin, 0, 4, L.stream())
+        torch.cuda.synchronize()
+        assert rel(E._unpack("w", dW).cpu(), ref) < 1e-4 and ((L.load().pg_last_launch_info() >> 16) & 0x3FFF) > 1
