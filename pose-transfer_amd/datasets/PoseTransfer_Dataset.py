@@ -228,9 +228,9 @@ class BatchPipeline:
         for r in raws:
             pose_transform._check_torso(r[2], self.ds.pose_dim), pose_transform._check_torso(r[3], self.ds.pose_dim)
         pi, pk = self.pin_img[slot], self.pin_kp[slot]
-        for j, r in enumerate(raws):
-            pi[j].copy_(torch.from_numpy(r[0])); pi[n + j].copy_(torch.from_numpy(r[1]))
-            pk[j].copy_(torch.from_numpy(r[2])); pk[n + j].copy_(torch.from_numpy(r[3]))
+        for j, r in enumerate(raws):        # (np.copyto into the pinned buffers: decoded arrays may be read-only views)
+            np.copyto(pi[j].numpy(), r[0], casting="unsafe"); np.copyto(pi[n + j].numpy(), r[1], casting="unsafe")
+            np.copyto(pk[j].numpy(), r[2], casting="unsafe"); np.copyto(pk[n + j].numpy(), r[3], casting="unsafe")
         # this slot's tensors were handed out RING batches ago; their consumers are already enqueued on the training
         # stream, so the side stream only has to wait for the work enqueued there so far (it then runs under the NEXT step)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
