@@ -45,9 +45,15 @@ __device__ __forceinline__ void lds_tr64(unsigned long long& v, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
+// LDS chunk swizzle of a pixel row of CPR 16-byte chunks (8 channels each): rows of >= 16 chunks XOR the pixel's low two bits
+// into chunk bits 2..3; a 64-channel row has only 8 chunks (128 B = half the bank space): pixels 0 / 2 and 1 / 3 of a
+// transposing read would meet in the same banks, so bit 1 of the pixel flips chunk bit 2 (the other 64-byte half).
+template <int CPR>
+__device__ __forceinline__ int wg_swz(int pixel) { return CPR >= 16 ? ((pixel & 3) << 2) : (((pixel >> 1) & 1) << 2); }
+
 template <int BM, int BN, int AS>
 __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) {
-  constexpr int WGN = (BN == 256) ? 4 : (BM == 256 ? 2 : 4);
+  constexpr int WGN = (BN == 64) ? 2 : (BM == 64 ? 4 : ((BN == 256) ? 4 : (BM == 256 ? 2 : 4)));
   constexpr int WGM = 8 / WGN;
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   static_assert(TM >= 1 && TN >= 1, "tile");
@@ -98,8 +104,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
   // ---- DMA: thread -> (pixel row within the tile, 16-byte slot); chunk = slot ^ ((pixel & 3) << 2)
   const int a_row = wave * A_RPI + lane / A_CPR, a_slot = lane % A_CPR;
   const int b_row = wave * B_RPI + lane / B_CPR, b_slot = lane % B_CPR;
-  const int a_ch = m0 + ((a_slot ^ ((a_row & 3) << 2)) << 3);        // first channel of the chunk this lane moves
-  const int b_ch = n0 + ((b_slot ^ ((b_row & 3) << 2)) << 3);
+  const int a_ch = m0 + ((a_slot ^ wg_swz<A_CPR>(a_row)) << 3);        // first channel of the chunk this lane moves
+  const int b_ch = n0 + ((b_slot ^ wg_swz<B_CPR>(b_row)) << 3);
   const int hw = p.Hs * p.Ws;
 
   // Loader state = 32-bit BYTE offsets against wave-uniform bases, advanced by 64 small-grid pixels per K tile with adds
@@ -188,12 +194,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int chunk = ((wm0 + 32 * t) >> 3) + 2 * mb + (cq >> 1);
-    fa[t] = lds0 + (unsigned)((8 * kh + r4) * (BM * 2)) + (unsigned)(((chunk ^ (r4 << 2)) << 4) + ((cq & 1) << 3));
+    fa[t] = lds0 + (unsigned)((8 * kh + r4) * (BM * 2)) + (unsigned)(((chunk ^ wg_swz<A_CPR>(r4)) << 4) + ((cq & 1) << 3));
   }
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int chunk = ((wn0 + 32 * t) >> 3) + 2 * mb + (cq >> 1);
-    fb[t] = lds0 + A_ST + (unsigned)((8 * kh + r4) * (BN * 2)) + (unsigned)(((chunk ^ (r4 << 2)) << 4) + ((cq & 1) << 3));
+    fb[t] = lds0 + A_ST + (unsigned)((8 * kh + r4) * (BN * 2)) + (unsigned)(((chunk ^ wg_swz<B_CPR>(r4)) << 4) + ((cq & 1) << 3));
   }
   typedef unsigned long long u64;
   struct Frag { u64 lo, hi; };
@@ -308,8 +314,9 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   PG_REQUIRE(x_bf16 && dy_bf16 && dW && N > 0 && Hs > 0 && Ws > 0, "pg_wgrad_bf16: bad arguments");
   PG_REQUIRE(Hs == (Hl - 2) / 2 + 1 && Ws == (Wl - 2) / 2 + 1 && Hl >= 2 && Wl >= 2 && (x_is_large || (Hl == 2 * Hs && Wl == 2 * Ws)),
              "pg_wgrad_bf16: k4 s2 p1 geometry required (small %dx%d, large %dx%d)", Hs, Ws, Hl, Wl);
-  PG_REQUIRE(Cx % 128 == 0 && Cout % 128 == 0 && col_off >= 0 && col_off + Cx <= ldw, "pg_wgrad_bf16: channel counts must be "
-             "multiples of 128 (Cx=%d Cout=%d)", Cx, Cout);
+  PG_REQUIRE(Cx % 64 == 0 && Cout % 64 == 0 && (Cx % 128 == 0 || Cx == 64) && (Cout % 128 == 0 || Cout == 64) &&
+             !(Cx == 64 && Cout == 64) && col_off >= 0 && col_off + Cx <= ldw,
+             "pg_wgrad_bf16: channel counts must be multiples of 128, or 64 on one side (Cx=%d Cout=%d)", Cx, Cout);
   WgBf16K k;
   memset(&k, 0, sizeof(k));
   k.N = N; k.Hs = Hs; k.Ws = Ws; k.Hl = Hl; k.Wl = Wl;
@@ -320,7 +327,7 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   k.Q = (long)N * Hs * Ws;
   PG_REQUIRE((double)N * Hl * Wl * (Cx > Cout ? Cx : Cout) * 2.0 < 4294967296.0 && (double)N * Hs * Ws < 2147483000.0,
              "pg_wgrad_bf16: operands must be < 4 GiB each (32-bit byte offsets)");
-  const int bm = (Cout % 256 == 0) ? 256 : 128, bn = (Cx % 256 == 0) ? 256 : 128;
+  const int bm = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0 ? 128 : 64), bn = (Cx % 256 == 0) ? 256 : (Cx % 128 == 0 ? 128 : 64);
   const int mt = Cout / bm, nt = Cx / bn;
   const int ktot = (int)((k.Q + 63) / 64);
   int ks = ksplit;
@@ -352,6 +359,8 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   if (bm == 256 && bn == 256) PGW_LAUNCH(256, 256);
   else if (bm == 128 && bn == 256) PGW_LAUNCH(128, 256);
   else if (bm == 256 && bn == 128) PGW_LAUNCH(256, 128);
+  else if (bn == 64) { if (bm == 256) PGW_LAUNCH(256, 64); else PGW_LAUNCH(128, 64); }         // 64-channel X (encoder level 1)
+  else if (bm == 64) { if (bn == 256) PGW_LAUNCH(64, 256); else PGW_LAUNCH(64, 128); }         // 64-channel dY (last decoder block)
   else PGW_LAUNCH(128, 128);
 #undef PGW_LAUNCH
   PG_LAUNCH_OK("pg_wgrad_bf16");

@@ -542,7 +542,16 @@ def _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
 
 
 _BF_WGT = {}       # device -> bf16 scratch of the transposing-read weight gradient: [x per source slot ..., dY]
+WGRAD_TR64 = os.environ.get("PG_NO_WGRAD_TR64") is None    # ablation switch: 64-channel layers through channel-major copies + NT GEMMs
 WGRAD_TR = os.environ.get("PG_NO_WGRAD_TR") is None        # ablation switch: channel-major copies + NT GEMMs instead
+
+
+def _tr_channels_ok(Cout, cs):
+    """pg_wgrad_bf16 tiles: multiples of 128 channels on both operands, or exactly 64 on ONE of them (per source launch)."""
+    big = lambda c: c % 128 == 0
+    if big(Cout):
+        return all(big(c) or (c == 64 and WGRAD_TR64) for c in cs)
+    return WGRAD_TR64 and Cout == 64 and all(big(c) for c in cs)
 
 
 def _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large):
@@ -554,8 +563,8 @@ def _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large):
 
 def _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large=True):
     return (PRECISION == 3 and WGRAD_TR and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None
-            and cout_store == 0 and _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large) and isinstance(dW, torch.Tensor) and Cout % 128 == 0
-            and all(s_.C % 128 == 0 for s_ in srcs) and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS)
+            and cout_store == 0 and _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large) and isinstance(dW, torch.Tensor)
+            and _tr_channels_ok(Cout, [s_.C for s_ in srcs]) and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS)
 
 
 def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16=None):

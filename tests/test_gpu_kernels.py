@@ -833,13 +833,19 @@ def wgrad_tr_cases():
         # odd maps (the discriminator's 127 -> 63 -> 31 blocks): large = 2 small + 1, tap 3 of the last row / column is inside
         ConvCase("wtr_conv_odd_31x27", "conv", [(128, A, False)], 256, 2, 31, 27, 4, 2, 1, L.ACT_LEAKY, seed=26),
         ConvCase("wtr_conv_odd_mixed", "conv", [(256, A, False)], 128, 3, 15, 20, 4, 2, 1, L.ACT_LEAKY, seed=27),       # odd x even
+        # 64 channels on one side (8-chunk pixel rows, their own LDS swizzle): encoder level 1, the discriminator's second
+        # block (odd map), the last decoder block (64 output channels, three sources)
+        ConvCase("wtr_conv_x64_128", "conv", [(64, A, False)], 128, 2, 24, 20, 4, 2, 1, L.ACT_LEAKY, seed=28),
+        ConvCase("wtr_conv_x64_256_odd", "conv", [(64, False, False)], 256, 2, 31, 27, 4, 2, 1, L.ACT_LEAKY, seed=29),
+        ConvCase("wtr_up_y64_3src", "convT", [(128, A, M), (128, False, False), (256, A, False)], 64, 2, 10, 9, 4, 2, 1,
+                 L.ACT_RELU, seed=30),
     ]
 
 
 @pytest.mark.parametrize("case", wgrad_tr_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
 def test_weight_gradient_bf16_transposing_reads(case, monkeypatch):
     """pg_wgrad_bf16 (csrc/wgrad_bf16.hip): weight gradient straight from pixel-major bf16 tensors, operand fragments by
-    ds_read_b64_tr_b16.  All tile shapes (256x256, 128x256, 256x128, 128x128), both geometries (Conv2d: x large; ConvT +
+    ds_read_b64_tr_b16.  All tile shapes (256x256, 128x256, 256x128, 128x128, and 64 channels on one side), both geometries (Conv2d: x large; ConvT +
     crop: x small), multi-source x with prologue, a partial last K tile, split-K atomics and accumulation into a non-zero
     dW.  Tight check against torch autograd on the bf16-ROUNDED operands."""
     monkeypatch.setattr(E, "PRECISION", 3)

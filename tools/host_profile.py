@@ -9,6 +9,8 @@ import bench  # noqa: E402
 from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
 from pose_transfer_amd.utils import synth
 
+from pose_transfer_amd.runtime import engine as E
+E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[sys.argv[1] if len(sys.argv) > 1 else "f32"]
 args = SimpleNamespace(size=256, batch=4, content_loss_layer="none", nn_loss_area_size=1, l1_penalty_weight=100.0)
 opt = bench.make_opt(args)
 model = DeformablePose_GAN(opt, device="cuda:0", init_seed=0)
