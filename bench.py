@@ -141,6 +141,8 @@ HBM_MODELS = {
     "pg_small_cin_wgrad": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * 4 * sum(a[0][i].C for i in range(_ival(a[1])))
                           + 256 * _ival(a[2]) * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
                           * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
+    # gradient towards nc image channels: dY (256 B per stem-output pixel) read, nc x 4 B per image pixel written
+    "pg_small_cin_dgrad": lambda a: _ival(a[2]) * (256 * _ival(a[3]) * _ival(a[4]) + 4 * _ival(a[12]) * _ival(a[8]) * _ival(a[9])),
     "pg_stem_conv_bf16": lambda a: HBM_MODELS["pg_small_cin_conv"](a),
     "pg_stem_conv_bf16_ex": lambda a: HBM_MODELS["pg_small_cin_conv"](a) * (1.5 if _ival(a[11]) else 1.0),    # + bf16 copy
     "pg_stem_wgrad_bf16": lambda a: HBM_MODELS["pg_small_cin_wgrad"](a),

@@ -214,6 +214,14 @@ int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t H
 int pg_stem_wgrad_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                        int32_t pad, const float* dY, float* dW, float* workspace, int64_t workspace_floats, void* stream);
 
+/* data-gradient of a first-layer convolution (64 output channels, dY NHWC) towards `nc` <= 4 of its input channels
+ * [c_off, c_off + nc), written (not accumulated) through (oN,oC,oH,oW) element strides — d loss / d generated image through
+ * the discriminator's stem in gen_update (reference models/pose_gan.py:95-98; autograd of networks.py:341), and the
+ * stage-to-stage chain of the stacked generator (networks.py:186).  W packed [K][K][64][Cin]. */
+int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t stride,
+                       int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out,
+                       int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream);
+
 /* db[c] += sum over rows of a strided [rows][C] view (bias gradient; torch autograd of conv bias). */
 int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,
                  int64_t s_inner, int64_t sC, float* db, void* stream);

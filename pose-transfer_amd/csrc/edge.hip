@@ -427,3 +427,80 @@ extern "C" int pg_small_cin_conv(const pg_src_t* src, int32_t nsrc, int32_t N, i
   PG_LAUNCH_OK("pg_small_cin_conv");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Data-gradient of a first-layer convolution towards a FEW of its input channels, written into an NCHW image:
+//   out[n][c][y][x] = sum_{r,s,co : (y+pad-r) % S == 0, (x+pad-s) % S == 0} dY[n][(y+pad-r)/S][(x+pad-s)/S][co] * W[r][s][co][c_off+c]
+// (gen_update: d loss / d generated image through the discriminator's stem, reference models/pose_gan.py:95-98 -> autograd
+// of networks.py:341; also the chain link of the stacked generator through a stage's first convolution).
+// As a pg_conv launch this is GEMM-N = 3 in a 32-wide tile with scalar weight loads: 0.7 ms for 3.2 GFLOP at batch 32.
+// Streaming form: 16 lanes per output pixel (4 output channels of dY each: one 256-byte row per tap, coalesced), the
+// weights of the <= 4 wanted input channels in LDS as [tap][c][co], a 4-stage cross-lane sum per channel.
+namespace pg {
+
+struct SmallCinDgradK {
+  const float* dY;     // NHWC [N][Ho][Wo][64]
+  const float* W;      // packed [K*K][64][Cin]
+  float* out;
+  long oN, oC, oH, oW;
+  int N, Ho, Wo, Hi, Wi, K, S, pad, Cin, c_off, nc;
+};
+
+__global__ __launch_bounds__(256) void small_cin_dgrad_kernel(const SmallCinDgradK p) {
+  __shared__ __attribute__((aligned(16))) float wl[16 * 4 * 64];          // [tap][c (4)][co]
+  const int T = p.K * p.K;
+  for (int i = threadIdx.x; i < T * 4 * 64; i += 256) {
+    const int co = i & 63, c = (i >> 6) & 3, tap = i >> 8;
+    wl[i] = c < p.nc ? p.W[((long)tap * 64 + co) * p.Cin + p.c_off + c] : 0.f;
+  }
+  __syncthreads();
+  const int l16 = threadIdx.x & 15;
+  const long npix = (long)p.N * p.Hi * p.Wi;
+  for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
+    const int n = (int)(pix / ((long)p.Hi * p.Wi));
+    const int rem = (int)(pix - (long)n * p.Hi * p.Wi);
+    const int y = rem / p.Wi, x = rem - y * p.Wi;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < p.K; ++r) {
+      const int ty = y + p.pad - r;
+      if (ty < 0 || ty % p.S != 0 || ty / p.S >= p.Ho) continue;
+      for (int s2 = 0; s2 < p.K; ++s2) {
+        const int tx = x + p.pad - s2;
+        if (tx < 0 || tx % p.S != 0 || tx / p.S >= p.Wo) continue;
+        const float4 g = *reinterpret_cast<const float4*>(p.dY + (((long)n * p.Ho + ty / p.S) * p.Wo + tx / p.S) * 64 + l16 * 4);
+        const float* wt = wl + (r * p.K + s2) * 256 + l16 * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wt + c * 64);
+          acc[c] = fmaf(g.x, w4.x, fmaf(g.y, w4.y, fmaf(g.z, w4.z, fmaf(g.w, w4.w, acc[c]))));
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+    if (l16 < p.nc) {
+      const float v = l16 == 0 ? acc[0] : (l16 == 1 ? acc[1] : (l16 == 2 ? acc[2] : acc[3]));
+      p.out[(long)n * p.oN + (long)l16 * p.oC + (long)y * p.oH + (long)x * p.oW] = v;
+    }
+  }
+}
+
+}  // namespace pg
+
+extern "C" int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t stride,
+                                  int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out,
+                                  int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream) {
+  PG_REQUIRE(dY && W && out && N > 0 && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0, "pg_small_cin_dgrad: bad arguments");
+  PG_REQUIRE(K >= 1 && K <= 4 && stride >= 1 && stride <= 2 && nc >= 1 && nc <= 4 && c_off >= 0 && c_off + nc <= Cin,
+             "pg_small_cin_dgrad: k <= 4, stride <= 2, 1..4 channels (got k%d s%d nc=%d c_off=%d Cin=%d)", K, stride, nc, c_off, Cin);
+  pg::SmallCinDgradK k;
+  k.dY = dY; k.W = W; k.out = out; k.oN = oN; k.oC = oC; k.oH = oH; k.oW = oW;
+  k.N = N; k.Ho = Ho; k.Wo = Wo; k.Hi = Hi; k.Wi = Wi; k.K = K; k.S = stride; k.pad = pad; k.Cin = Cin; k.c_off = c_off; k.nc = nc;
+  long blocks = ((long)N * Hi * Wi + 15) / 16;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(pg::small_cin_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  PG_LAUNCH_OK("pg_small_cin_dgrad");
+  return 0;
+}

@@ -483,6 +483,7 @@ def _join_side():
 
 OUT_CONV_STREAM = os.environ.get("PG_NO_OUT_CONV_STREAM") is None   # ablation switch: K=32 pg_conv launch instead
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
+SMALL_CIN_DGRAD = os.environ.get("PG_NO_SMALL_CIN_DGRAD") is None   # ablation switch: GEMM-N = 3 pg_conv launch instead
 SMALL_CIN_WGRAD = os.environ.get("PG_NO_SMALL_CIN_WGRAD") is None   # ablation switch: generic per-tap kernel
 SMALL_CIN_WGRAD_WS = 512 * 64 * 704     # floats: per-workgroup partials of the first-layer weight gradient (<= PG_SMALL_CIN_WGRAD_WS)
 _SCW_WS = {}
@@ -1041,9 +1042,13 @@ class GeneratorEngine:
             if image_grad is not None and e in ("encoder_app", "encoder"):
                 # data-gradient of the k3/s1/p1 first convolution restricted to its 3 image channels, written NCHW
                 assert image_grad.is_contiguous() and tuple(image_grad.shape) == (N, 3, H, W)
-                _conv([Act(dz, self.enc[0]).src()], N, H, W, L.ACT_NONE, 1, 3, 1, 1, H, W, A.p(e + ".net.0.weight"),
-                      self.enc[0], s0.C, transposed=True, out=image_grad, out_strides=(3 * H * W, H * W, W, 1),
-                      n_off=0, n_cnt=3)
+                if self.enc[0] == 64 and SMALL_CIN_DGRAD:
+                    L.call("pg_small_cin_dgrad", L.ptr(dz), L.ptr(A.p(e + ".net.0.weight")), N, H, W, 3, 1, 1, H, W, s0.C, 0, 3,
+                           L.ptr(image_grad), 3 * H * W, H * W, W, 1, L.stream())
+                else:
+                    _conv([Act(dz, self.enc[0]).src()], N, H, W, L.ACT_NONE, 1, 3, 1, 1, H, W, A.p(e + ".net.0.weight"),
+                          self.enc[0], s0.C, transposed=True, out=image_grad, out_strides=(3 * H * W, H * W, W, 1),
+                          n_off=0, n_cnt=3)
 
 
 # ------------------------------------------------------------------------------------------ discriminator
@@ -1212,8 +1217,12 @@ class DiscriminatorEngine:
                 g = image_grad[pi]
                 s = L.Src()
                 s.ptr, s.C = dptr, 64
-                _conv([s], n, self.hs[0], self.ws[0], L.ACT_NONE, 1, 4, 2, 0, H, W, A.p("net.0.weight"), 64, cin,
-                      transposed=True, out=g, out_strides=(3 * H * W, H * W, W, 1), n_off=3 + self.P, n_cnt=3)
+                if SMALL_CIN_DGRAD:       # streaming kernel: 16 lanes per image pixel (GEMM-N = 3 wastes a 32-wide MFMA tile)
+                    L.call("pg_small_cin_dgrad", dptr, L.ptr(A.p("net.0.weight")), n, self.hs[0], self.ws[0], 4, 2, 0, H, W, cin,
+                           3 + self.P, 3, L.ptr(g), 3 * H * W, H * W, W, 1, L.stream())
+                else:
+                    _conv([s], n, self.hs[0], self.ws[0], L.ACT_NONE, 1, 4, 2, 0, H, W, A.p("net.0.weight"), 64, cin,
+                          transposed=True, out=g, out_strides=(3 * H * W, H * W, W, 1), n_off=3 + self.P, n_cnt=3)
             off += n
         if need_wgrad:
             self._ready("net.0.")

@@ -710,6 +710,27 @@ def test_small_cin_patch_conv(name):
         assert rel(nchw(out.cpu()), out_ref) < 1e-5, hw
 
 
+@pytest.mark.parametrize("K,S,pad,cin,c_off,nc", [(4, 2, 0, 42, 21, 3), (3, 1, 1, 21, 0, 3), (4, 2, 0, 70, 35, 3), (3, 1, 1, 35, 4, 4)])
+def test_small_cin_data_gradient(K, S, pad, cin, c_off, nc):
+    """pg_small_cin_dgrad (csrc/edge.hip): d/d(a few input channels) of a first-layer convolution from its NHWC output
+    gradient, written NCHW — the discriminator-stem -> generated-image gradient of gen_update and the stacked generator's
+    stage link — vs torch autograd, incl. odd sizes (k4 s2 p0 leaves the last row / column without a tap)."""
+    for (H, W), N in (((16, 14), 2), ((33, 19), 1), ((64, 48), 3)):
+        Ho, Wo = (H + 2 * pad - K) // S + 1, (W + 2 * pad - K) // S + 1
+        w = t(synth.xavier_uniform(31, "scd/w%d" % K, (64, cin, K, K)))
+        gy = t(synth.normal(31, "scd/g%dx%d" % (H, W), (N, 64, Ho, Wo)))
+        x = torch.zeros(N, cin, H, W, requires_grad=True)
+        (ref,) = torch.autograd.grad((F.conv2d(x, w, None, stride=S, padding=pad) * gy).sum(), x)
+        wp = E._pack("w", w).to(DEV)
+        gyd = nhwc(gy).to(DEV)
+        out = torch.full((N, nc + 2, H, W), float("nan"), device=DEV)          # written into a channel slice of a larger image
+        L.call("pg_small_cin_dgrad", L.ptr(gyd), L.ptr(wp), N, Ho, Wo, K, S, pad, H, W, cin, c_off, nc,
+               out.data_ptr() + 4 * H * W, (nc + 2) * H * W, H * W, W, 1, L.stream())
+        torch.cuda.synchronize()
+        assert rel(out[:, 1:1 + nc].cpu(), ref[:, c_off:c_off + nc]) < 1e-5, (K, H, W)
+        assert torch.isnan(out[:, 0]).all() and torch.isnan(out[:, -1]).all()
+
+
 STEM_SRCS = {
     "p18_app": [(21, False, False)], "p18_pose": [(18, False, False)],
     "p18_disc": [(21, False, False), (18, False, False), (3, False, False)],            # 42 channels, pairs straddle sources
