@@ -185,7 +185,7 @@ int pg_small_cin_conv(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, 
                       int32_t pad, const float* Wt, const float* bias, float* out, void* stream);
 /* their weight gradient (autograd of the same two layers): dW packed [KH][KW][64][Cin] += sum over pixels of
  * dY[n,oy,ox,co] * x[n,ci,oy*stride+r-pad,ox*stride+s-pad]; dY NHWC [N][Ho][Wo][64].  All taps share one pass over dY,
- * the input patch of a pixel tile is gathered from LDS (csrc/small_cin_wgrad.hip).  k3s1: Cin <= 35; k4s2: Cin <= 44.
+ * the input patch of a pixel tile is gathered from LDS (csrc/small_cin_wgrad.hip).  k3s1: Cin <= 35; k4s2: Cin <= 88.
  * `workspace` (optional, PG_SMALL_CIN_WGRAD_WS floats cover every supported shape): per-workgroup partial results that
  * a second kernel reduces; without it the workgroups add into dW with float atomics (slower). */
 #define PG_SMALL_CIN_WGRAD_WS (768L * 64 * 704)

@@ -44,13 +44,14 @@ __global__ __launch_bounds__(256, 2) void small_cin_wgrad_kernel(const SmallCinW
   const int l31 = lane & 31, lhi = lane >> 5;
   const int mt = wave & 1;                                  // output-channel rows mt*32 .. +31
   const int ntot = T * p.Ctot;
+  const int nt_base = blockIdx.y * (2 * NTW);               // column group of this workgroup (wide filters: Cin > 44 at k4)
 
   // lane constants: n = (tap, ci) of this lane in each of the wave's tiles -> patch offset (+ lhi: the odd pixel of a
   // k pair is one column further)
   int base[NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
-    const int n = ((wave >> 1) + 2 * i) * 32 + l31;
+    const int n = (nt_base + (wave >> 1) + 2 * i) * 32 + l31;
     const bool ok = n < ntot;
     const int tap = ok ? n / p.Ctot : 0;
     const int ci = ok ? n - tap * p.Ctot : 0;
@@ -136,10 +137,10 @@ __global__ __launch_bounds__(256, 2) void small_cin_wgrad_kernel(const SmallCinW
   }
   // ---- dW[tap][co][ci] += acc   (rows = co, lane column = (tap, ci))
   if (p.part) {                                             // plain coalesced stores; small_cin_wgrad_reduce adds them up
-    float* o = p.part + (long)blockIdx.x * 64 * p.npad + (long)(mt * 32 + 4 * lhi) * p.npad + (wave >> 1) * 32 + l31;
+    float* o = p.part + (long)blockIdx.x * 64 * p.npad + (long)(mt * 32 + 4 * lhi) * p.npad + (nt_base + (wave >> 1)) * 32 + l31;
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
-      if (((wave >> 1) + 2 * i) * 32 < p.npad) {
+      if ((nt_base + (wave >> 1) + 2 * i) * 32 < p.npad) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * p.npad + i * 64] = acc[i][r];
       }
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void small_cin_wgrad_kernel(const SmallCinW
   }
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
-    const int n = ((wave >> 1) + 2 * i) * 32 + l31;
+    const int n = (nt_base + (wave >> 1) + 2 * i) * 32 + l31;
     if (n >= ntot) continue;
     const int tap = n / p.Ctot;
     float* o = p.dW + (long)tap * 64 * p.Ctot + (n - tap * p.Ctot);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void small_cin_wgrad_reduce_kernel(const float
 }
 
 template <int K, int S, int TH, int NTW>
-static int launch_small_cin_wgrad(SmallCinWgK& k, float* ws, long ws_floats, hipStream_t st) {
+static int launch_small_cin_wgrad(SmallCinWgK& k, float* ws, long ws_floats, hipStream_t st, int groups = 1) {
   constexpr int PH = (TH - 1) * S + K, PWU = 15 * S + K, PWS = (S == 1) ? PWU : (PWU + 1) / 2;
   constexpr int ROWF = (S == 1) ? PWS : 2 * PWS;
   k.CS = (PH * ROWF) | 1;
@@ -208,7 +209,7 @@ static int launch_small_cin_wgrad(SmallCinWgK& k, float* ws, long ws_floats, hip
   } else {
     k.part = ws;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, k);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)groups), dim3(256), lds, st, k);
   if (k.part) {
     const int ry = blocks >= 32 ? 16 : 1;
     hipLaunchKernelGGL(small_cin_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256),
@@ -242,8 +243,10 @@ extern "C" int pg_small_cin_wgrad(const pg_src_t* src, int32_t nsrc, int32_t N, 
     rc = (tiles <= 12) ? pg::launch_small_cin_wgrad<3, 1, 8, 3>(k, workspace, workspace_floats, st)
                        : pg::launch_small_cin_wgrad<3, 1, 8, 5>(k, workspace, workspace_floats, st);     // P = 32: 3 + 32 channels
   } else {
-    PG_REQUIRE(tiles <= 44, "pg_small_cin_wgrad: k4 supports Cin <= 44 (got %d)", c);
-    rc = (tiles <= 24) ? pg::launch_small_cin_wgrad<4, 2, 4, 6>(k, workspace, workspace_floats, st) : pg::launch_small_cin_wgrad<4, 2, 4, 11>(k, workspace, workspace_floats, st);
+    PG_REQUIRE(tiles <= 88, "pg_small_cin_wgrad: k4 supports Cin <= 88 (got %d)", c);
+    if (tiles <= 24) rc = pg::launch_small_cin_wgrad<4, 2, 4, 6>(k, workspace, workspace_floats, st);
+    else if (tiles <= 44) rc = pg::launch_small_cin_wgrad<4, 2, 4, 11>(k, workspace, workspace_floats, st);
+    else rc = pg::launch_small_cin_wgrad<4, 2, 4, 11>(k, workspace, workspace_floats, st, 2);      // P = 32: 70 channels, two column groups
   }
   PG_REQUIRE(rc == 0, "pg_small_cin_wgrad: patch does not fit LDS");
   pg::last_info() = 5 | (1 << 4) | (1 << 16) | (1 << 30);     // tile code 5 = all-taps patch kernel, scalar X

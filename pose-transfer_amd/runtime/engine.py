@@ -636,7 +636,7 @@ def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stri
     if (scalar_x and x_is_large and Cout == 64 and y_strides is None and cout_store == 0 and ksplit == 0
             and act == L.ACT_NONE and SMALL_CIN_WGRAD
             and ((K == 3 and stride == 1 and Cin <= (36 if PRECISION == 3 and STEM_BF16 else 35))
-                 or (K == 4 and stride == 2 and Cin <= (72 if PRECISION == 3 and STEM_BF16 else 44)))):
+                 or (K == 4 and stride == 2 and Cin <= (72 if PRECISION == 3 and STEM_BF16 else 88)))):
         # first layers (raw NCHW inputs): all taps in one pass over dY, patch gathered from LDS
         arr = (L.Src * len(srcs))(*srcs)
         dYp = dY if isinstance(dY, int) else L.ptr(dY)

@@ -661,7 +661,8 @@ def test_output_conv_reassociated():
 
 @pytest.mark.parametrize("name", ["first_k3", "stem_k4p0"])
 @pytest.mark.parametrize("srcs", [None, [(18, False, False)], [(3, False, False), (16, False, False), (3, False, False), (16, False, False)],
-                                  [(35, False, False)], [(32, False, False)]])
+                                  [(35, False, False)], [(32, False, False)],
+                                  [(35, False, False), (32, False, False), (3, False, False)]])       # P = 32 discriminator stem: 70
 def test_small_cin_patch_wgrad(name, srcs):
     """First-layer weight gradients through the all-taps LDS-patch kernel (csrc/small_cin_wgrad.hip) vs autograd, incl.
     ragged tiles, several persistent tiles per workgroup and other channel counts; must agree with the generic kernel."""
