@@ -327,9 +327,16 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   k.Q = (long)N * Hs * Ws;
   PG_REQUIRE((double)N * Hl * Wl * (Cx > Cout ? Cx : Cout) * 2.0 < 4294967296.0 && (double)N * Hs * Ws < 2147483000.0,
              "pg_wgrad_bf16: operands must be < 4 GiB each (32-bit byte offsets)");
-  const int bm = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0 ? 128 : 64), bn = (Cx % 256 == 0) ? 256 : (Cx % 128 == 0 ? 128 : 64);
-  const int mt = Cout / bm, nt = Cx / bn;
+  int bm = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0 ? 128 : 64), bn = (Cx % 256 == 0) ? 256 : (Cx % 128 == 0 ? 128 : 64);
   const int ktot = (int)((k.Q + 63) / 64);
+  // few pixels (deep layers at small batch): K cannot be split (>= 16 K tiles per workgroup), so 256-wide tiles leave most
+  // of the chip idle (64 workgroups for a 512 x 512 filter) — halve the tile sides until ~128 workgroups exist
+  static const bool small_tiles = getenv("PG_WGTR_NO_SMALL_TILES") == nullptr;
+  if (small_tiles && ksplit <= 0 && ktot < 32) {
+    if ((long)(Cout / bm) * (Cx / bn) * 16 < 128 && bn == 256) bn = 128;
+    if ((long)(Cout / bm) * (Cx / bn) * 16 < 128 && bm == 256) bm = 128;
+  }
+  const int mt = Cout / bm, nt = Cx / bn;
   int ks = ksplit;
   if (ks <= 0) {
     // ~128 workgroups per launch (half a round of the 256 CUs), >= 16 K tiles per workgroup.  Weight gradients run on the

@@ -543,6 +543,9 @@ def _wgrad_bf16(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW):
 
 
 _BF_WGT = {}       # device -> bf16 scratch of the transposing-read weight gradient: [x per source slot ..., dY]
+# pixel-count floor of the transposing-read weight gradient (0 = none): with the small-tile rule of pg_wgrad_bf16 for few-pixel
+# layers, routing them to the fp32 kernel instead measured the same (batch 4: 505 vs 507 img/s)
+WGRAD_TR_MIN_PIXELS = int(os.environ.get("PG_WGTR_MIN_PIXELS", "0"))
 WGRAD_TR64 = os.environ.get("PG_NO_WGRAD_TR64") is None    # ablation switch: 64-channel layers through channel-major copies + NT GEMMs
 WGRAD_TR = os.environ.get("PG_NO_WGRAD_TR") is None        # ablation switch: channel-major copies + NT GEMMs instead
 
@@ -565,7 +568,8 @@ def _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large):
 def _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large=True):
     return (PRECISION == 3 and WGRAD_TR and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None
             and cout_store == 0 and _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large) and isinstance(dW, torch.Tensor)
-            and _tr_channels_ok(Cout, [s_.C for s_ in srcs]) and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS)
+            and _tr_channels_ok(Cout, [s_.C for s_ in srcs]) and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS
+            and N * Hs * Ws >= WGRAD_TR_MIN_PIXELS)
 
 
 def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16=None):
