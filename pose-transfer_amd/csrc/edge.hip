@@ -446,36 +446,48 @@ struct SmallCinDgradK {
   int N, Ho, Wo, Hi, Wi, K, S, pad, Cin, c_off, nc;
 };
 
+// K, S compile-time: the tap loops unroll, and for S = 2 only the K/2 x K/2 taps of the pixel's parity class are visited
+// (the generic form spent most of its instructions on runtime divisions and parity tests: 73 us for 4 images).
+template <int K, int S>
 __global__ __launch_bounds__(256) void small_cin_dgrad_kernel(const SmallCinDgradK p) {
-  __shared__ __attribute__((aligned(16))) float wl[16 * 4 * 64];          // [tap][c (4)][co]
-  const int T = p.K * p.K;
-  for (int i = threadIdx.x; i < T * 4 * 64; i += 256) {
+  __shared__ __attribute__((aligned(16))) float wl[K * K * 4 * 64];          // [tap][c (4)][co]
+  for (int i = threadIdx.x; i < K * K * 4 * 64; i += 256) {
     const int co = i & 63, c = (i >> 6) & 3, tap = i >> 8;
     wl[i] = c < p.nc ? p.W[((long)tap * 64 + co) * p.Cin + p.c_off + c] : 0.f;
   }
   __syncthreads();
   const int l16 = threadIdx.x & 15;
-  const long npix = (long)p.N * p.Hi * p.Wi;
+  const int hw = p.Hi * p.Wi;
+  const long npix = (long)p.N * hw;
+  constexpr int NR = (S == 1) ? K : K / 2;                 // taps per axis that can hit a given pixel
   for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
-    const int n = (int)(pix / ((long)p.Hi * p.Wi));
-    const int rem = (int)(pix - (long)n * p.Hi * p.Wi);
+    const int n = (int)(pix / hw);
+    const int rem = (int)(pix - (long)n * hw);
     const int y = rem / p.Wi, x = rem - y * p.Wi;
+    const int ry0 = (S == 1) ? 0 : ((y + p.pad) & 1), rx0 = (S == 1) ? 0 : ((x + p.pad) & 1);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < p.K; ++r) {
-      const int ty = y + p.pad - r;
-      if (ty < 0 || ty % p.S != 0 || ty / p.S >= p.Ho) continue;
-      for (int s2 = 0; s2 < p.K; ++s2) {
-        const int tx = x + p.pad - s2;
-        if (tx < 0 || tx % p.S != 0 || tx / p.S >= p.Wo) continue;
-        const float4 g = *reinterpret_cast<const float4*>(p.dY + (((long)n * p.Ho + ty / p.S) * p.Wo + tx / p.S) * 64 + l16 * 4);
-        const float* wt = wl + (r * p.K + s2) * 256 + l16 * 4;
+    float4 g[NR * NR];
+    const float* wt[NR * NR];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 w4 = *reinterpret_cast<const float4*>(wt + c * 64);
-          acc[c] = fmaf(g.x, w4.x, fmaf(g.y, w4.y, fmaf(g.z, w4.z, fmaf(g.w, w4.w, acc[c]))));
-        }
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+      for (int b = 0; b < NR; ++b) {
+        const int r = ry0 + a * S, s2 = rx0 + b * S;
+        const int ty = y + p.pad - r, tx = x + p.pad - s2;          // multiples of S by construction
+        const int oy = (S == 1) ? ty : (ty >> 1), ox = (S == 1) ? tx : (tx >> 1);
+        const bool ok = (ty >= 0) & (tx >= 0) & (oy < p.Ho) & (ox < p.Wo);
+        const long off = ok ? (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + l16 * 4 : 0;
+        g[a * NR + b] = *reinterpret_cast<const float4*>(p.dY + off);
+        if (!ok) g[a * NR + b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wt[a * NR + b] = wl + (r * K + s2) * 256 + l16 * 4;
       }
-    }
+#pragma unroll
+    for (int q = 0; q < NR * NR; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wt[q] + c * 64);
+        acc[c] = fmaf(g[q].x, w4.x, fmaf(g[q].y, w4.y, fmaf(g[q].z, w4.z, fmaf(g[q].w, w4.w, acc[c]))));
+      }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -493,14 +505,15 @@ extern "C" int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, in
                                   int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out,
                                   int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream) {
   PG_REQUIRE(dY && W && out && N > 0 && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0, "pg_small_cin_dgrad: bad arguments");
-  PG_REQUIRE(K >= 1 && K <= 4 && stride >= 1 && stride <= 2 && nc >= 1 && nc <= 4 && c_off >= 0 && c_off + nc <= Cin,
-             "pg_small_cin_dgrad: k <= 4, stride <= 2, 1..4 channels (got k%d s%d nc=%d c_off=%d Cin=%d)", K, stride, nc, c_off, Cin);
+  PG_REQUIRE(((K == 3 && stride == 1) || (K == 4 && stride == 2)) && nc >= 1 && nc <= 4 && c_off >= 0 && c_off + nc <= Cin,
+             "pg_small_cin_dgrad: k3 s1 or k4 s2, 1..4 channels (got k%d s%d nc=%d c_off=%d Cin=%d)", K, stride, nc, c_off, Cin);
   pg::SmallCinDgradK k;
   k.dY = dY; k.W = W; k.out = out; k.oN = oN; k.oC = oC; k.oH = oH; k.oW = oW;
   k.N = N; k.Ho = Ho; k.Wo = Wo; k.Hi = Hi; k.Wi = Wi; k.K = K; k.S = stride; k.pad = pad; k.Cin = Cin; k.c_off = c_off; k.nc = nc;
   long blocks = ((long)N * Hi * Wi + 15) / 16;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(pg::small_cin_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  if (K == 3) hipLaunchKernelGGL((pg::small_cin_dgrad_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL((pg::small_cin_dgrad_kernel<4, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_small_cin_dgrad");
   return 0;
 }
