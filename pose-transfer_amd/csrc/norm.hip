@@ -7,6 +7,7 @@
 // reductions around it: one read of the activation for the statistics; backward reads (dz, y) once for the two
 // per-sample sums and once more to rewrite dz -> dy in place.
 #include "common.h"
+#include <cstdlib>
 
 namespace pg {
 
@@ -154,9 +155,13 @@ static int norm_blocks_bwd(long L, int N) {
 }
 
 static int norm_blocks(long L) {
-  long b = (L / 4 + 256 * 8 - 1) / (256 * 8);
+  // streaming passes on this chip prefer MANY workgroups with one 16-byte chunk per lane over few deep ones (swept at batch
+  // 32: 8 chunks per lane / 512 workgroups per sample 2.04 ms, 1 / 8192: 1.87 ms for the norm-backward apply passes of a step)
+  static const int per = getenv("PG_NORM_PER") ? atoi(getenv("PG_NORM_PER")) : 1;
+  static const int cap = getenv("PG_NORM_CAP") ? atoi(getenv("PG_NORM_CAP")) : 8192;
+  long b = (L / 4 + 256 * per - 1) / (256 * per);
   if (b < 1) b = 1;
-  if (b > 512) b = 512;
+  if (b > cap) b = cap;
   return (int)b;
 }
 
