@@ -5,6 +5,7 @@
 //  * dropout_mask: channel-dropout multipliers (nn.Dropout2d, models/networks.py:161) from a stateless counter hash
 //    (same mixer as pose_transfer_amd/utils/synth.py, so the host can reproduce a mask bit-for-bit).
 #include "common.h"
+#include <cstdlib>
 
 namespace pg {
 
@@ -141,7 +142,7 @@ extern "C" int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
                        float step_size, float bc2_sqrt, float grad_scale, void* stream) {
   PG_REQUIRE(p && g && m && v && n > 0, "pg_adam: bad arguments");
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  { static const long cap = getenv("PG_ADAM_CAP") ? atol(getenv("PG_ADAM_CAP")) : 131072; if (blocks > cap) blocks = cap; }
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, b1, b2,
                      eps, step_size, bc2_sqrt, grad_scale);
@@ -153,7 +154,7 @@ extern "C" int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m
                           float eps, float step_size, float bc2_sqrt, float grad_scale, void* p_bf16, void* stream) {
   PG_REQUIRE(p && (g || g_bf16) && m && v && n > 0 && n % 4 == 0, "pg_adam_ex: bad arguments (n %% 4 == 0)");
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  { static const long cap = getenv("PG_ADAM_CAP") ? atol(getenv("PG_ADAM_CAP")) : 131072; if (blocks > cap) blocks = cap; }
   const unsigned short* gb = reinterpret_cast<const unsigned short*>(g_bf16);
   unsigned short* pb = reinterpret_cast<unsigned short*>(p_bf16);
 #define PG_ADAM_EX(G, W)                                                                                               \
@@ -379,7 +380,7 @@ extern "C" int pg_adam_ctr(float* p, const float* g, const void* g_bf16, float* 
                            float eps, float lr, int64_t step0, const uint64_t* ctr, float grad_scale, void* p_bf16, void* stream) {
   PG_REQUIRE(p && (g || g_bf16) && m && v && n > 0 && n % 4 == 0 && ctr && step0 >= 1, "pg_adam_ctr: bad arguments");
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  { static const long cap = getenv("PG_ADAM_CAP") ? atol(getenv("PG_ADAM_CAP")) : 131072; if (blocks > cap) blocks = cap; }
   const unsigned short* gb = reinterpret_cast<const unsigned short*>(g_bf16);
   unsigned short* pb = reinterpret_cast<unsigned short*>(p_bf16);
   const unsigned long long* c = reinterpret_cast<const unsigned long long*>(ctr);
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void add2_kernel(float* out, const float* a, c
 extern "C" int pg_add2(float* out, const float* a, const float* b, int64_t n, void* stream) {
   PG_REQUIRE(out && a && b && n > 0, "pg_add2: bad arguments");
   long blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  { static const long cap = getenv("PG_ADAM_CAP") ? atol(getenv("PG_ADAM_CAP")) : 131072; if (blocks > cap) blocks = cap; }
   hipLaunchKernelGGL(add2_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, a, b, (long)n);
   PG_LAUNCH_OK("pg_add2");
   return 0;
