@@ -1596,6 +1596,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
       if (c > 1) t += 2.0 * c * out_bytes / (bw_tbs * 1e6) + t_launch;
       if (t < best * 0.98) { best = t; ks = c; }             // a further split must buy 2 %
     }
+    if (getenv("PG_SPLITK_DEBUG")) fprintf(stderr, "[splitk] M=%d N=%d ktot=%d blocks=%ld cfg=%d -> ks=%d (T=%.0f us)\n", k.M, k.n_cnt, ktot_min, blocks, cfg, ks, best);
   }
   if (d->out_act != PG_OUT_NONE) ks = 1;
   if (d->epilogue == 0) {   // split-K accumulates atomically into a zeroed, dense NHWC output only
