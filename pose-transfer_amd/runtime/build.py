@@ -63,7 +63,24 @@ def build_lib(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    build_example()
     return LIB
+
+
+EXAMPLE = os.path.join(LIBDIR, "cabi_smoke")
+
+
+def build_example():
+    """examples/cabi_smoke.cpp: a plain C++ consumer of the C ABI (no Python, no torch), next to the library."""
+    src = os.path.join(os.path.dirname(PKG), "examples", "cabi_smoke.cpp")
+    if not os.path.exists(src) or not _newer(src, EXAMPLE, (LIB, os.path.join(INCLUDE, "posegan_hip.h"))):
+        return EXAMPLE
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + INCLUDE, src, "-L" + LIBDIR, "-lposegan_hip",
+           "-Wl,-rpath,$ORIGIN", "-o", EXAMPLE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building examples/cabi_smoke.cpp failed:\n%s" % r.stderr[-4000:])
+    return EXAMPLE
 
 
 if __name__ == "__main__":

@@ -21,6 +21,16 @@ def rel(a, b):
 
 
 # ----------------------------------------------------------------------------------------- layout / misc
+def test_c_abi_from_plain_cpp():
+    """examples/cabi_smoke.cpp: the library driven by a plain C++ program (HIP runtime + include/posegan_hip.h only — no
+    Python, no torch in the process): heat-maps, L1 loss + gradient and Adam against host loops, and the error path."""
+    import subprocess
+    from pose_transfer_amd.runtime import build as B
+    exe = B.build_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_transposes_roundtrip():
     x = t(synth.normal(1, "tr", (3, 21, 17, 13))).to(DEV)
     y = torch.empty(3, 17, 13, 21, device=DEV)
