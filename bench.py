@@ -107,11 +107,17 @@ def cpu_baseline(args):
         times.append(iteration())
     dt = sum(times) / len(times)
     return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "work": "4 F_G + 8 F_D port (the reference as written executes 6 F_G + 9 F_D: its dis_update also back-propagates "
+                    "through the generator, pose_gan.py:129,166 — the reference itself would be ~1.4x slower than this baseline)",
             "sample": "%d timed iteration(s) after 1 warm-up (%.1f s) of dis_update+gen_update, %dx%d, batch %d, fp32, "
                       "oracle/ref_cpu.py on torch-CPU (%d threads), %.1f s per iteration"
                       % (len(times), warm, size, size, n, cores, dt)}
 
 
+PREC_TEXT = {"f32": "fp32", "bf16x3": "fp32 storage, bf16x3 split MFMA operands", "bf16": "fp32 storage, bf16 MFMA operands",
+             "bf16_data": "bf16 data path (bf16 operand tensors, fp32 accumulate / master weights)"}
+DTYPE_TEXT = {"f32": "f32", "bf16x3": "f32 storage/accumulate, bf16x3 MFMA operands",
+              "bf16": "f32 storage/accumulate, bf16 MFMA operands", "bf16_data": "bf16 operands, f32 accumulate"}
 PEAK_HBM_TBS = 8.0                # HBM3E peak, same guide (6.3 TB/s is what a float4 copy achieves)
 
 
@@ -195,25 +201,26 @@ class HbmProfiler:
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/round2_pmc.json, made by
-    tools/pmc_bench.sh on the default workload): 2*FETCH_SIZE + WRITE_SIZE, in bytes (MI355X_MICROARCH.md: FETCH_SIZE
-    reads half of a wide coalesced stream on gfx950).  None when no PMC summary is available."""
-    try:
-        path = os.path.join(ROOT, "profiles", "round2_pmc.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "round1_pmc.json")
-        d = json.load(open(path))
-        k = d["kernels"].get(kernel)
-        return None if k is None else int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024)
-    except Exception:
-        return None
+    """(HBM bytes per launch of `kernel`, source file) from the COMMITTED rocprofv3 PMC passes (profiles/round*_pmc.json,
+    made by tools/pmc_bench.sh on the default workload — counters cannot be collected from inside this process):
+    2*FETCH_SIZE + WRITE_SIZE, in bytes (MI355X_MICROARCH.md: FETCH_SIZE reads half of a wide coalesced stream on
+    gfx950).  (None, None) when no PMC summary is available."""
+    for name in ("round3_pmc.json", "round2_pmc.json", "round1_pmc.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            k = d["kernels"].get(kernel)
+            if k is not None:
+                return int((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # SURVEY.md §8d: >= 10 warm-up + >= 50 timed iterations
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE.json configs[1]: 4)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--pose_dim", type=int, default=18)
@@ -301,9 +308,11 @@ def main():
             # bf16 operand modes run their forward / data-gradient (and, on the data path, weight-gradient) contractions
             # on the bf16 matrix pipe: they are priced against its dense peak
             peak = PEAK_BF16_MFMA_TFLOPS if args.precision in ("bf16", "bf16_data") else PEAK_F32_MFMA_TFLOPS
+            traffic, traffic_src = pmc_traffic(name) if args.precision == "f32" else (None, None)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": pmc_traffic(name) if args.precision == "f32" else None,
+                    "traffic": traffic, "traffic_source": traffic_src,     # committed PMC summary, NOT measured in this run
+                    "gpu_event_ms_total": round(sum(v["ms"] for v in fam.values()), 3),   # HIP-event time of all contraction launches of ONE iteration
                     "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "flops_per_launch_avg": d["flops"] / d["launches"],
                     "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
@@ -333,11 +342,11 @@ def main():
             "metric": "GAN train images/sec (gen+disc step) at %dx%d" % (args.size, args.size),
             "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 storage/accumulate, %s MFMA operands"
-            % args.precision, "data": "synthetic",
-            "config": {"workload": "src_deformable warp_skip=mask gen_type=baseline, %dx%d, %d kpts, batch %d/GPU, fp32%s"
-                                   % (args.size, args.size, P, args.batch,
-                                      " (BASELINE.json configs[1])" if (args.size, P, args.batch) == (256, 18, 4) else ""),
+            "vs_baseline": None, "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
+            "config": {"workload": "src_deformable warp_skip=mask gen_type=baseline, %dx%d, %d kpts, batch %d/GPU, %s%s"
+                                   % (args.size, args.size, P, args.batch, PREC_TEXT[args.precision],
+                                      " (BASELINE.json configs[1])"
+                                      if (args.size, P, args.batch, args.precision) == (256, 18, 4, "f32") else ""),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size,
                        "precision": args.precision, **({"hip_graph": True} if args.graph else {})},

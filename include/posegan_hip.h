@@ -386,6 +386,10 @@ int pg_event_record(void* ev, void* stream);
 int pg_event_elapsed_ms(void* start, void* stop, float* ms);  /* synchronises on `stop` */
 int pg_event_destroy(void* ev);
 
+/* Test aid (no reference counterpart): one lane busy-waits ~`microseconds` (0..50000) on `stream`, delaying whatever is
+ * enqueued behind it — used by the stream-ordering stress test of the data-parallel reducer (runtime/dp.py). */
+int pg_debug_spin(int32_t microseconds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

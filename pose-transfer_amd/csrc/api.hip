@@ -37,3 +37,18 @@ extern "C" int pg_event_destroy(void* ev) {
   PG_HIP(hipEventDestroy((hipEvent_t)ev));
   return 0;
 }
+
+// Test aid (tests/test_gpu_round3.py: stream-ordering stress of the data-parallel reducer): ONE lane busy-waits for about
+// `microseconds` (bounded to 50 ms) on `stream`, delaying everything enqueued behind it on that stream.
+namespace pg {
+__global__ void debug_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();            // constant 100 MHz counter
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace pg
+extern "C" int pg_debug_spin(int32_t microseconds, void* stream) {
+  PG_REQUIRE(microseconds >= 0 && microseconds <= 50000, "pg_debug_spin: 0..50000 us");
+  hipLaunchKernelGGL(pg::debug_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+  PG_LAUNCH_OK("pg_debug_spin");
+  return 0;
+}

@@ -170,6 +170,21 @@ class PoseTransfer_Dataset:
         return tuple(t[0] for t in self.collate([raw]))
 
 
+def shard_indices(n_items, batch, rank, world, seed, shuffle, order, epoch, cursor):
+    """Indices of this rank's next batch -> (indices, order, epoch, cursor).  The epoch permutation depends on (seed, epoch)
+    ONLY — every rank must pass the same seed — and rank r takes rows [r*batch, (r+1)*batch) of each global batch of
+    batch*world items, so that over an epoch the rank slices are disjoint and cover the permutation (minus a dropped tail)."""
+    if order is None or cursor + batch * world > len(order):
+        g = np.random.RandomState(seed + epoch)
+        order = g.permutation(n_items) if shuffle else np.arange(n_items)
+        epoch += 1
+        cursor = 0
+        if len(order) < batch * world:      # tiny data sets: sample with replacement
+            order = g.randint(0, n_items, size=batch * world)
+    lo = cursor + rank * batch
+    return order[lo:lo + batch], order, epoch, cursor + batch * world
+
+
 class BatchPipeline:
     """Prefetching batch source: `next()` returns device tensors of the next batch; decode (worker threads), pinned
     staging, H2D copy and the device-side sample construction of batch k+1.. run on a side stream while step k trains.
@@ -203,16 +218,9 @@ class BatchPipeline:
             self._stage()
 
     def _indices(self):
-        if self.order is None or self.cursor + self.n * self.world > len(self.order):
-            g = np.random.RandomState(self.seed + self.epoch)
-            self.order = g.permutation(len(self.ds)) if self.shuffle else np.arange(len(self.ds))
-            self.epoch += 1
-            self.cursor = 0
-            if len(self.order) < self.n * self.world:      # tiny data sets: sample with replacement
-                self.order = g.randint(0, len(self.ds), size=self.n * self.world)
-        lo = self.cursor + self.rank * self.n
-        self.cursor += self.n * self.world
-        return self.order[lo:lo + self.n]
+        idx, self.order, self.epoch, self.cursor = shard_indices(len(self.ds), self.n, self.rank, self.world, self.seed,
+                                                                 self.shuffle, self.order, self.epoch, self.cursor)
+        return idx
 
     def _submit(self):
         idx = self._indices()

@@ -57,8 +57,10 @@ def make_sources(opt, device):
     if opt.synthetic:
         return SyntheticSource(opt, device, "train"), SyntheticSource(opt, device, "test")
     from pose_transfer_amd.datasets.PoseTransfer_Dataset import PoseTransfer_Dataset, BatchPipeline
+    # every rank builds the SAME epoch permutation (seed + epoch) and takes its own slice of each global batch: the rank
+    # slices of an epoch are disjoint and their union is the permutation (tests/test_host_cpu.py)
     train = BatchPipeline(PoseTransfer_Dataset(vars(opt), "train"), opt.batch_size, device, shuffle=True,
-                          seed=opt.seed + dp.rank(), workers=opt.num_workers, rank=dp.rank(), world=dp.world_size())
+                          seed=opt.seed, workers=opt.num_workers, rank=dp.rank(), world=dp.world_size())
     test = BatchPipeline(PoseTransfer_Dataset(vars(opt), "test"), opt.batch_size, device, shuffle=True,
                          seed=opt.seed + 7919 + dp.rank(), workers=max(1, opt.num_workers // 2))
     return train, test

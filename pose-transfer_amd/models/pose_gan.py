@@ -125,7 +125,13 @@ class DeformablePose_GAN(nn.Module):
     def _drop_setup(self, eng, drop_masks, stage, call):
         # (in a HIP-graph replay session the iteration number comes from the device counter, not from this string)
         it = 0 if E.REPLAY_CTR is not None else self.iteration
-        eng.drop_stream = "drop/r%d/i%d/%s/s%d" % (DP.rank(), it, call, stage)
+        # repeated calls within ONE iteration (--training_ratio > 1: several dis_update per gen_update, main.py:78-88)
+        # draw fresh masks, as the reference's Dropout2d does: the k-th repeat of a (call, stage) gets its own stream
+        if getattr(self, "_drop_it", None) != it:
+            self._drop_it, self._drop_n = it, {}
+        k = self._drop_n.get((call, stage), 0)
+        self._drop_n[(call, stage)] = k + 1
+        eng.drop_stream = "drop/r%d/i%d/%s%s/s%d" % (DP.rank(), it, call, "" if k == 0 else ".%d" % k, stage)
         eng._drop_counter = 0
         eng.set_dropout(drop_masks, train=True, seed=self.seed)
 
@@ -204,7 +210,7 @@ class DeformablePose_GAN(nn.Module):
         scale, gb = 1.0, None
         if self.g_reducer is not None:
             self.g_reducer.finish()
-            scale, gb = 1.0 / self.world, self.g_reducer.grad_source()[1]
+            scale, gb = 1.0 / self.g_reducer.divisor, self.g_reducer.grad_source()[1]
         self.gen_opt.step(grad_scale=scale, grads_bf16=gb)
         lp = L.ptr(self._loss)
         L.call("pg_add2", lp, lp + 4, lp + 8, 1, L.stream())        # total = ll + ad  (pose_gan.py:109)
@@ -235,7 +241,7 @@ class DeformablePose_GAN(nn.Module):
         scale, gb = 1.0, None
         if self.d_reducer is not None:
             self.d_reducer.finish()
-            scale, gb = 1.0 / self.world, self.d_reducer.grad_source()[1]
+            scale, gb = 1.0 / self.d_reducer.divisor, self.d_reducer.grad_source()[1]
         self.disc_opt.step(grad_scale=scale, grads_bf16=gb)
         lp = L.ptr(self._loss)
         L.call("pg_add2", lp + 16, lp + 20, lp + 24, 1, L.stream())

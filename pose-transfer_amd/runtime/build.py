@@ -79,7 +79,9 @@ def build_example():
            "-Wl,-rpath,$ORIGIN", "-o", EXAMPLE]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("building examples/cabi_smoke.cpp failed:\n%s" % r.stderr[-4000:])
+        # an example must not break the library build: warn (tests/test_gpu_kernels.py::test_c_abi_from_plain_cpp fails
+        # loudly if the binary is missing)
+        print("[build] WARNING: examples/cabi_smoke.cpp did not build:\n%s" % r.stderr[-2000:], file=sys.stderr)
     return EXAMPLE
 
 

@@ -15,8 +15,15 @@ towards the end of the arena (`_threshold`) so that what is left for `finish()` 
 Transport: on the device the collective is RCCL behind the C ABI (`pg_comm_*`, include/posegan_hip.h; the rendezvous
 token travels over the torch.distributed store that torch.distributed.run already set up).  `PG_DP_BACKEND=torch` or a
 CPU arena (the gloo tests) use `torch.distributed.all_reduce` instead.
-Gradient format: fp32 buckets by default; `PG_DP_GRAD_DTYPE=bf16` (default on the bf16 data path) packs each finished
-range to bf16 (pg_pack_bf16), reduces half the bytes and lets Adam read the bf16 sums (pg_adam_ex).
+Gradient format: fp32 buckets on the fp32 paths; on the bf16 data path (engine.PRECISION == 3) the default is bf16 buckets:
+each finished range is packed to bf16 (pg_pack_bf16), reduced at half the bytes, and Adam reads the bf16 sums (pg_adam_ex).
+`PG_DP_GRAD_DTYPE=f32|bf16` overrides either default.  What the bf16 sum costs in accuracy is measured by
+tests/test_dp_cpu.py::test_bf16_bucket_sum_of_8_ranks_parameter_error (8 gloo ranks, gradients spread over 4 decades).
+
+Debugging aid: `PG_DP_DEBUG_PEER=1` (single rank, PG_FORCE_REDUCER=1) makes every bucket's "all-reduce" non-trivial by
+adding the bucket to itself on the communication stream — the sum a second rank with identical gradients would give — and
+reports a divisor of 2, so a bucket that is reduced before its last producer has finished changes the result
+(tests/test_gpu_round3.py::test_reducer_stream_order_under_main_stream_delay).
 """
 import ctypes
 import os
@@ -29,6 +36,9 @@ from . import lib as L
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+dist_world = world_size
 
 
 def rank():
@@ -101,10 +111,15 @@ class GradReducer:
         if backend is None:
             backend = os.environ.get("PG_DP_BACKEND", "rccl" if self.on_device else "torch")
         self.backend = backend if self.on_device else "torch"
-        self.grad_dtype = grad_dtype or os.environ.get("PG_DP_GRAD_DTYPE", "f32")
+        if grad_dtype is None:
+            from . import engine as E
+            grad_dtype = os.environ.get("PG_DP_GRAD_DTYPE", "bf16" if (E.PRECISION == 3 and self.on_device) else "f32")
+        self.grad_dtype = grad_dtype
         assert self.grad_dtype in ("f32", "bf16")
-        self.bf16 = self.grad_dtype == "bf16" and self.on_device
+        self.bf16 = self.grad_dtype == "bf16"
         self.packed = torch.empty(arena.total, dtype=torch.bfloat16, device=arena.grads.device) if self.bf16 else None
+        self.debug_peer = os.environ.get("PG_DP_DEBUG_PEER") == "1" and self.on_device and dist_world() == 1
+        self.divisor = max(1, dist_world()) * (2 if self.debug_peer else 1)      # what the optimiser divides the sums by
         self.comm_stream = torch.cuda.Stream(device=arena.grads.device) if self.on_device else None
         self.comm = None
         if self.backend == "rccl" and (world > 1 or os.environ.get("PG_FORCE_REDUCER") == "1"):
@@ -160,6 +175,8 @@ class GradReducer:
         of the iteration on one GPU: 170 -> 163 img/s)  The last launch (finish) and runs without a
         side stream wait for the main stream as well; PG_DP_WAIT_MAIN=1 restores the conservative form everywhere."""
         from . import engine as E
+        if os.environ.get("PG_DP_DEBUG_NO_WAIT") == "1":      # negative control of the ordering stress test: no producer events
+            return
         dev = self.arena.grads.device
         cs = self.comm_stream
         side = E._SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
@@ -180,12 +197,18 @@ class GradReducer:
         self.launched = upto
         self.launch_count += 1
         if not self.on_device:                      # CPU arenas (gloo tests)
+            buf = self.arena.grads[lo:upto]
+            if self.bf16:                           # same data flow as on the device: pack, reduce the bf16 bucket
+                self.packed[lo:upto] = buf.to(torch.bfloat16)
+                buf = self.packed[lo:upto]
             if self.world > 1:
-                self.works.append(dist.all_reduce(self.arena.grads[lo:upto], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         self._wait_producers(final)
         buf = self.arena.grads[lo:upto]
         with torch.cuda.stream(self.comm_stream):
+            if self.debug_peer:                     # the sum a second rank with identical gradients would contribute
+                L.call("pg_add2", L.ptr(buf), L.ptr(buf), L.ptr(buf), n, L.stream())
             if self.bf16:
                 pk = self.packed[lo:upto]
                 L.call("pg_pack_bf16", L.ptr(buf), L.ptr(pk), n, L.stream())     # arena offsets are multiples of 64 elements

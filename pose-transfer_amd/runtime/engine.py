@@ -461,8 +461,12 @@ _SPLITK_WS = {}
 # on a SIDE stream: the small deep layers leave most CUs idle (one short round of workgroups), and the weight-gradient
 # of layer l then overlaps the data-gradient of layer l and the norm backward of layer l-1 on the main stream
 # (+1.4 % fp32, +3 % on the bf16 data path; running the two encoders of the forward pass on two streams: +-0).
-# Order: the side stream waits for the main stream at the call (dz complete); the main stream waits for the side
-# stream before a gradient range is reported ready to the data-parallel reducer and at the end of the pass.
+# Order: the side stream waits for the main stream at the call (dz complete, and with it every parameter gradient the
+# main stream wrote for the same layer before the call: norm gamma / beta, biases); the main stream waits for the side
+# stream at the end of the pass only.  A gradient range handed to the data-parallel reducer is ordered by the reducer's
+# own events (runtime/dp.py: _wait_producers): the invariant it relies on — every main-stream write into the gradient
+# arena of a layer is enqueued BEFORE that layer's _wgrad call, and _ready() for the layer comes after it — is stress-tested
+# by tests/test_gpu_round3.py::test_reducer_stream_order_under_main_stream_delay.
 SIDE_STREAM = os.environ.get("PG_NO_SIDE_STREAM") is None
 _SIDE = {}
 
@@ -675,6 +679,17 @@ def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stri
     L.check(L.load().pg_conv_wgrad(d, L.stream()), "pg_conv_wgrad")
 
 
+# Test aid (tests/test_gpu_round3.py): PG_DEBUG_MAIN_DELAY_US=n puts a busy-wait of n microseconds on the MAIN stream in front
+# of every gradient the main stream writes into the parameter-gradient arena (norm gamma / beta, conv biases), i.e. it makes
+# those writes LATE relative to everything the side and communication streams do — the stress case of dp._wait_producers.
+_MAIN_DELAY_US = int(os.environ.get("PG_DEBUG_MAIN_DELAY_US", "0"))
+
+
+def _debug_delay():
+    if _MAIN_DELAY_US > 0:
+        L.call("pg_debug_spin", _MAIN_DELAY_US, L.stream())
+
+
 class NormScratch:
     """All per-sample statistics buffers of one engine in ONE allocation, so that a forward (backward) pass zeroes
     them with a single memset instead of one tiny fill launch per norm layer."""
@@ -724,6 +739,7 @@ class NormState:
         cache for, so their materialisation pass (4 B read + 2 B write per element) does not run."""
         if not self.shared:
             self.bsums.zero_()
+        _debug_delay()
         L.call("pg_norm_bwd_reduce", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), L.stream())
         bf = None
         if PRECISION == 3 and NORM_BWD_BF16 and _BF_CTX is not None and C > 0 and C % 64 == 0:
@@ -979,6 +995,7 @@ class GeneratorEngine:
         srcs = self._dec_sources(i)
         cin = sum(a.C for _, _, a in srcs)
         wkey = "decoder.net.%d.weight" % (i + 1)
+        _debug_delay()
         L.call("pg_bias_grad", L.ptr(dpre), N, H * W, 3, 3 * H * W, 1, H * W, L.ptr(A.g("decoder.net.%d.bias" % (i + 1))),
                L.stream())
         L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
@@ -1038,6 +1055,7 @@ class GeneratorEngine:
         for e in self.encs:
             dz = self.e_dz[e][0]
             s0 = self._enc_in_src(e, self.input)
+            _debug_delay()
             L.call("pg_bias_grad", L.ptr(dz), N * H * W, 1, self.enc[0], self.enc[0], 0, 1,
                    L.ptr(A.g(e + ".net.0.bias")), L.stream())
             _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
@@ -1208,6 +1226,7 @@ class DiscriminatorEngine:
         dz0 = self.dz[0]
         cin = 3 + 2 * self.P + 3
         if need_wgrad:
+            _debug_delay()
             L.call("pg_bias_grad", L.ptr(dz0), M * self.hs[0] * self.ws[0], 1, 64, 64, 0, 1, L.ptr(A.g("net.0.bias")),
                    L.stream())
         off = 0

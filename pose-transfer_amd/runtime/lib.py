@@ -120,6 +120,7 @@ _PROTOS = {
     "pg_event_record": [_vp, _vp],
     "pg_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
     "pg_event_destroy": [_vp],
+    "pg_debug_spin": [_i32, _vp],
     "pg_version": [],
     "pg_last_launch_info": [],
 }

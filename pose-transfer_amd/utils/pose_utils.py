@@ -90,17 +90,22 @@ def load_pose_cords_from_strings(y_str, x_str):
     return np.stack([np.asarray(json.loads(y_str)), np.asarray(json.loads(x_str))], axis=1)
 
 
-def peak_cords(cords, img_size=None):
-    """What the reference obtains by rendering key-points to heat-maps and reading the peaks back (map_to_cord,
-    pose_utils.py:57-76): the integer pixel nearest to each (possibly fractional) key-point — ties go to the smaller
-    coordinate because np.where lists the equal maxima in row-major order and the first one is kept; missing (-1) stays
-    missing.  Integer in-image key-points are returned unchanged."""
+def peak_cords(cords, img_size=None, threshold=0.1, sigma=6):
+    """What the reference obtains by rendering key-points to heat-maps and reading the peaks back (cords_to_map ->
+    map_to_cord, pose_utils.py:57-86): the integer pixel nearest to each (possibly fractional) key-point — ties go to the
+    smaller coordinate because np.where lists the equal maxima in row-major order and the first one is kept; missing (-1)
+    stays missing.  A key-point outside the frame peaks at the nearest in-image pixel with the value
+    exp(-d^2 / (2 sigma^2)); map_to_cord keeps a peak only above `threshold`, so a key-point about 12.9 px or more outside
+    (d^2 >= 165.8) becomes MISSING.  Integer in-image key-points are returned unchanged."""
     c = np.asarray(cords, dtype=np.float64)
     missing = (c[:, 0] == MISSING_VALUE) | (c[:, 1] == MISSING_VALUE)
     out = np.ceil(c - 0.5).astype(np.int64)
     if img_size is not None:
         out[:, 0] = np.clip(out[:, 0], 0, img_size[0] - 1)
         out[:, 1] = np.clip(out[:, 1], 0, img_size[1] - 1)
+        d2 = ((out - c) ** 2).sum(axis=1)
+        peak = np.exp(-d2 / (2 * sigma ** 2)).astype(np.float32)          # the heat-map is float32 (pose_utils.py:80)
+        missing |= ~(peak > np.float32(threshold))
     out[missing] = MISSING_VALUE
     return out
 

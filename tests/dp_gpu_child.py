@@ -36,21 +36,34 @@ def main(out_path):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     sl = slice(rank * n, rank * n + n)
     res = {"losses": []}
+    div = lambda red: 1 if red is None else red.divisor
+
+    def reduced(red, arena):
+        """what the optimiser read: the all-reduced sums (bf16 buckets: the packed copy) divided by the reducer's divisor"""
+        if red is None:
+            return arena.grads.cpu()
+        g32, g16 = red.grad_source()
+        return ((g16.float() if g16 is not None else g32) / red.divisor).cpu()
+
     for it in range(2):
         b = [[t(a)[sl].contiguous().to(dev) for a in synth.batch(55, "dp/it%d/%s" % (it, s), G, P, H, W)] for s in "ABC"]
         d = [[t(m)[sl].contiguous().to(dev) for m in synth.dropout_masks(55, "dp/it%d/d%s" % (it, s), G)] for s in "AC"]
         dl = model.dis_update(b[0][0], b[0][1], {"warps": b[0][2], "masks": b[0][3], "drop_masks": d[0]}, b[1][0], b[1][1], od)
         if it == 0:
-            res["disc_grads"] = (model.disc.arena.grads / world).cpu()
+            res["disc_grads"] = (model.disc.arena.grads / div(model.d_reducer)).cpu()
+            res["disc_grads_reduced"] = reduced(model.d_reducer, model.disc.arena)
         _, _, gl = model.gen_update(b[2][0], b[2][1], {"warps": b[2][2], "masks": b[2][3], "drop_masks": d[1]}, od)
         if it == 0:
-            res["gen_grads"] = (model.gen.arena.grads / world).cpu()
+            res["gen_grads"] = (model.gen.arena.grads / div(model.g_reducer)).cpu()
+            res["gen_grads_reduced"] = reduced(model.g_reducer, model.gen.arena)
         res["losses"].append((dl, gl))
     torch.cuda.synchronize()
     res["gen"] = model.gen.arena.params.cpu()
     res["disc"] = model.disc.arena.params.cpu()
     res["buckets"] = 0 if model.g_reducer is None else model.g_reducer.launch_count
     res["world"] = world
+    res["divisor"] = div(model.g_reducer)
+    res["grad_dtype"] = "none" if model.g_reducer is None else model.g_reducer.grad_dtype
     if rank == 0:
         torch.save(res, out_path)
     if torch.distributed.is_initialized():

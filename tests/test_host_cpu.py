@@ -106,11 +106,17 @@ def test_synthetic_source_shapes():
 def test_peak_cords_equals_render_and_read_back():
     """peak_cords == map_to_cord(cords_to_map(.)) — what the reference does for the interpolated poses."""
     H, W = 40, 30
-    cords = np.array([[3, 4], [10.5, 7.25], [-1, -1], [20.49, 29.0], [0.5, 0.5], [39, 0]], dtype=np.float64)
+    # rows 6.. are OUT OF FRAME: map_to_cord's 0.1 threshold (reference pose_utils.py:55-60) keeps those whose nearest
+    # in-image pixel is closer than sqrt(-72 ln 0.1) = 12.88 px and drops the others (ADVICE round 2)
+    cords = np.array([[3, 4], [10.5, 7.25], [-1, -1], [20.49, 29.0], [0.5, 0.5], [39, 0],
+                      [-5.0, 10.0], [45.0, 12.0], [-12.0, 10.0], [-13.0, 10.0], [20.0, 42.5], [50.0, 40.0], [-9.0, -9.0],
+                      [-9.5, -9.5]], dtype=np.float64)
     maps = pose_utils.cords_to_map(cords, (H, W))
     back = pose_utils.map_to_cord(maps, len(cords))
     assert (back == pose_utils.peak_cords(cords, (H, W))).all()
     assert (back[2] == -1).all() and tuple(back[1]) == (10, 7) and tuple(back[4]) == (0, 0)
+    assert tuple(back[6]) == (0, 10) and tuple(back[8]) == (0, 10) and (back[9] == -1).all() and (back[11] == -1).all()
+    assert tuple(back[12]) == (0, 0) and (back[13] == -1).all()
 
 
 def test_compute_interpol_pose_rules():
@@ -165,3 +171,25 @@ def test_dataset_wire_format_parsing(tmp_path):
     assert (ds.raw(1)[1] == 0).all()                       # reference Dataset.py:141-143
     maps, chain = ds.interpol_keypoints(k_from, k_to)
     assert maps.shape == (2, 18, 2) and chain.shape == (3, 18, 2) and (chain[0] == k_from).all()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_rank_shards_of_an_epoch_are_disjoint_and_cover_the_permutation(world):
+    """every rank draws the SAME epoch permutation and takes its own slice of each global batch."""
+    from pose_transfer_amd.datasets.PoseTransfer_Dataset import shard_indices
+    n_items, batch, seed = 203, 3, 11
+    per_epoch = n_items // (batch * world)
+    seen = [[[] for _ in range(2)] for _ in range(world)]
+    for r in range(world):
+        order, epoch, cursor = None, 0, 0
+        for it in range(2 * per_epoch):
+            idx, order, epoch, cursor = shard_indices(n_items, batch, r, world, seed, True, order, epoch, cursor)
+            assert len(idx) == batch
+            seen[r][it // per_epoch] += list(map(int, idx))
+    for ep in range(2):
+        allidx = sum((seen[r][ep] for r in range(world)), [])
+        assert len(allidx) == per_epoch * batch * world
+        assert len(set(allidx)) == len(allidx), "a sample was served to two ranks within one epoch"
+        perm = np.random.RandomState(seed + ep).permutation(n_items)
+        assert set(allidx) == set(map(int, perm[:len(allidx)]))
+    assert seen[0][0] != seen[0][1]           # a new permutation per epoch
