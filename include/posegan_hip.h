@@ -54,8 +54,10 @@ typedef struct {
   int32_t C;
   int32_t act;        /* PG_ACT_* of the consumer that read `fwd`                            */
   int32_t accumulate; /* 1: grad += ...; 0: grad = ...                                       */
-  int32_t _pad;
+  int32_t flags;      /* PG_DST_*: bf16 STORAGE of `grad` / `fwd` (bf16 data path, round 3); 0 = fp32 */
 } pg_dst_t;
+#define PG_DST_GRAD_BF16 1
+#define PG_DST_FWD_BF16 2
 
 /* Implicit-GEMM convolution, fp32 MFMA (v_mfma_f32_32x32x2_f32).
  *   mode 0 "down": out[n,oy,ox,:] = sum_{r,s} W[r][s] . in[n, oy*stride + r - pad, ox*stride + s - pad, :]
@@ -85,8 +87,10 @@ typedef struct {
   pg_dst_t dst[PG_MAX_SRC];
   int32_t ndst;
   int32_t ksplit;           /* 0 = auto; >1 splits K across workgroups (atomic accumulate)         */
-  int32_t precision;        /* PG_PREC_*: MFMA operand format (storage and accumulation stay fp32)  */
-  int32_t reserved0;
+  int32_t precision;        /* PG_PREC_*: MFMA operand format (accumulation stays fp32)              */
+  int32_t out_bf16;         /* 1: `out` (epilogue 0, dense NHWC, no out_act) is a bf16 tensor — bf16 STORAGE of the raw
+                               convolution output on the bf16 data path; the fused statistics still come from the fp32
+                               accumulators.  Needs the workspace for split-K launches.                            */
   double* stats;            /* optional [N][PG_STAT_SLOTS][2], caller-zeroed: per-sample (sum, sum of squares) of the stored output =
                                pg_norm_stats of `out` (the following per-sample norm, models/networks.py:159), fused
                                into the epilogue when the launch is not split-K; epilogue 0, dense NHWC only        */
@@ -389,6 +393,58 @@ int pg_event_destroy(void* ev);
 /* Test aid (no reference counterpart): one lane busy-waits ~`microseconds` (0..50000) on `stream`, delaying whatever is
  * enqueued behind it — used by the stream-ordering stress test of the data-parallel reducer (runtime/dp.py). */
 int pg_debug_spin(int32_t microseconds, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Round 3 — bf16 STORAGE on the bf16 data path (PG_PREC_BF16_DATA).  Raw convolution outputs (the tensors the reference's
+ * Block keeps between conv and norm, models/networks.py:154-169) and the gradients flowing back through them are kept as
+ * bf16 NHWC tensors instead of fp32: every HBM-bound pass around the contractions (norm backward, warp, materialisation,
+ * first / last layers, the epilogues) moves half the bytes.  Statistics, accumulation, master weights, Adam, losses stay
+ * fp32 / double.  pg_conv_t.out_bf16 and pg_dst_t.flags select it per launch for the contractions; the entry points
+ * below are the `_io` forms of the streaming kernels (io_flags bits documented per function; 0 = the fp32 form).
+ * Reference lines replaced are those of the fp32 forms they extend. */
+/* pg_materialise_bf16 with a bf16 raw input (x_is_bf16) and an optional SECOND activated copy (out2_bf16, act2) written in
+ * the same pass: an encoder skip is read through LeakyReLU by the next level (networks.py:150) and through ReLU by the
+ * decoder (networks.py:152). */
+int pg_materialise_bf16_ex(const void* x, int32_t x_is_bf16, const float* aff, const float* mask, int32_t act, int32_t N,
+                           int64_t HW, int32_t C, void* out_bf16, void* out2_bf16, int32_t act2, void* stream);
+/* io_flags: bit 0 = dz is bf16, bit 1 = y is bf16 */
+int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float* mr, int32_t N, int64_t L, double* bsums,
+                          int32_t io_flags, void* stream);
+int pg_norm_bwd_apply_io(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma, int32_t N,
+                         int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags, void* stream);
+/* io_flags: bit 0 = feat is bf16, bit 1 = out is bf16, bit 2 = store relu(out) (the decoder reads the warped skip only
+ * through its ReLU; relu(x) > 0 <=> x > 0 keeps the backward's activation derivative) */
+int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const float* warps, const float* lvl_masks, int32_t N,
+                            int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0, int32_t align_corners,
+                            void* out, uint8_t* argmax, int32_t io_flags, void* stream);
+/* io_flags: bit 0 = gout is bf16, bit 1 = dfeat is bf16 */
+int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, const float* warps, const float* lvl_masks, int32_t N,
+                            int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0, int32_t align_corners,
+                            void* dfeat, int32_t io_flags, void* stream);
+/* first layers: `out` (fp32) may be NULL; up to three bf16 outputs bf16(act_k(conv + bias)), PG_ACT_NONE = the raw tensor */
+int pg_stem_conv_bf16_v3(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                         int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
+                         uint16_t* out2_bf16, int32_t act2, uint16_t* out3_bf16, int32_t act3, void* stream);
+int pg_stem_wgrad_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                          int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* workspace,
+                          int64_t workspace_floats, void* stream);
+/* db[c] += sum over pixels of a dense NHWC bf16 gradient (bias gradient of the first layers, networks.py:186,341) */
+int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, float* db, void* stream);
+/* pg_tap_gather (k3 p1, 3 outputs) over a tap tensor whose pixel rows are `pitch` >= 27 floats apart */
+int pg_tap_gather_pitch(const float* Y, int32_t pitch, int32_t N, int32_t H, int32_t W, const float* bias, int32_t out_act,
+                        float* out, int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream);
+/* pg_out_conv_dgrad that also accumulates the weight gradient dW[27][Ctot] of the output convolution (networks.py:228) in
+ * the same pass: every destination's `fwd` is the ACTIVATED operand of the forward pass (no aff / mask); Ctot = 256;
+ * workspace >= 64 * Ctot * 28 floats. */
+int pg_out_conv_dgrad_wgrad(const float* G, const float* Wt, int32_t N, int32_t H, int32_t W, const pg_dst_t* dst,
+                            int32_t ndst, float* dW, float* workspace, int64_t workspace_floats, void* stream);
+/* bf16 im2col of the output convolution's gradient (pg_im2col_taps with a bf16 G, Cpad = 64) and its weight gradient alone:
+ * dW[27][Ctot] += sum_pixels G[pixel][t] * x[pixel][ci], x = the activated bf16 forward operands given as dst[].fwd.  The data
+ * gradient of that layer is then a plain bf16 pg_conv (K = 64) with the zero-padded weight. */
+int pg_im2col_taps_bf16(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H, int32_t W,
+                        int32_t KH, int32_t KW, int32_t pad, int32_t C, int32_t Cpad, void* G_bf16, void* stream);
+int pg_out_conv_wgrad_bf16(const void* G_bf16, int32_t g_pitch, int32_t N, int32_t H, int32_t W, const pg_dst_t* dst,
+                           int32_t ndst, float* dW, float* workspace, int64_t workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* Y, int N, 
 // runs) and gathers from LDS (pixel stride 27 floats: conflict-free).  The direct version above issues 27 loads per lane
 // with a 108-byte lane stride (0.36 TB/s at batch 32).
 __global__ __launch_bounds__(256) void tap_gather_333_kernel(const float* Y, int N, int H, int W, const float* bias, int out_act,
-                                                             float* out, long oN, long oC, long oH, long oW) {
+                                                             float* out, long oN, long oC, long oH, long oW, int pitch) {
+  // pitch: floats per pixel row of Y (27 = dense; 64 when the 1x1 contraction ran on the bf16 512 x 64 kernel, round 3)
   constexpr int TH = 8, TW = 32, CT = 27;
   __shared__ float tile[(TH + 2) * (TW + 2) * CT];
   const int n = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
@@ -55,10 +56,11 @@ __global__ __launch_bounds__(256) void tap_gather_333_kernel(const float* Y, int
     if (yy < 0 || yy >= H) {
       for (int i = threadIdx.x; i < (TW + 2) * CT; i += 256) trow[i] = 0.f;
     } else {
-      const float* src = Y + (((long)n * H + yy) * W + xlo) * CT;
+      const float* src = Y + (((long)n * H + yy) * W + xlo) * pitch;
       for (int i = threadIdx.x; i < (TW + 2) * CT; i += 256) {
         const int k = i - lpad;
-        trow[i] = (k >= 0 && k < run) ? src[k] : 0.f;
+        const int kp = (pitch == CT) ? k : (k / CT) * pitch + k % CT;
+        trow[i] = (k >= 0 && k < run) ? src[kp] : 0.f;
       }
     }
   }
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(256) void tap_gather_333_kernel(const float* Y, int
 }
 
 // G[n,y,x,(r*KW+s)*C + c] = dY[n,c,y-(r-pad),x-(s-pad)] (0 outside), channels [T*C, Cpad) zero-filled
+// OB: G is a bf16 tensor (round 3: the gradient operand of the output convolution's bf16 contractions, Cpad = 64)
+template <bool OB>
 __global__ __launch_bounds__(256) void im2col_taps_kernel(const float* dY, long yN, long yC, long yH, long yW, int N,
                                                           int H, int W, int KH, int KW, int pad, int C, int Cpad,
                                                           float* G) {
@@ -100,7 +104,13 @@ __global__ __launch_bounds__(256) void im2col_taps_kernel(const float* dY, long 
       const int yy = y - (r - pad), xx = x - (s - pad);
       if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = dY[(long)n * yN + (long)c * yC + (long)yy * yH + (long)xx * yW];
     }
-    G[i] = v;
+    if constexpr (OB) {
+      unsigned r_;
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r_) : "v"(v), "v"(0.f));
+      reinterpret_cast<unsigned short*>(G)[i] = (unsigned short)(r_ & 0xffffu);
+    } else {
+      G[i] = v;
+    }
   }
 }
 
@@ -185,13 +195,23 @@ __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(const SmallDgradK
 
 using namespace pg;
 
+extern "C" int pg_tap_gather_pitch(const float* Y, int32_t pitch, int32_t N, int32_t H, int32_t W, const float* bias,
+                                   int32_t out_act, float* out, int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream) {
+  // the k3 p1 Co = 3 gather over a tap tensor whose pixel rows are `pitch` >= 27 floats apart
+  PG_REQUIRE(Y && out && N > 0 && N <= 65535 && pitch >= 27, "pg_tap_gather_pitch: bad arguments");
+  hipLaunchKernelGGL(tap_gather_333_kernel, dim3((W + 31) / 32, (H + 7) / 8, N), dim3(256), 0, (hipStream_t)stream, Y, N, H, W,
+                     bias, out_act, out, (long)oN, (long)oC, (long)oH, (long)oW, pitch);
+  PG_LAUNCH_OK("pg_tap_gather_pitch");
+  return 0;
+}
+
 extern "C" int pg_tap_gather(const float* Y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad,
                              int32_t Co, const float* bias, int32_t out_act, float* out, int64_t oN, int64_t oC,
                              int64_t oH, int64_t oW, void* stream) {
   PG_REQUIRE(Y && out && N > 0 && Co > 0, "pg_tap_gather: bad arguments");
   if (KH == 3 && KW == 3 && pad == 1 && Co == 3 && N <= 65535) {
     hipLaunchKernelGGL(tap_gather_333_kernel, dim3((W + 31) / 32, (H + 7) / 8, N), dim3(256), 0, (hipStream_t)stream, Y, N, H, W,
-                       bias, out_act, out, (long)oN, (long)oC, (long)oH, (long)oW);
+                       bias, out_act, out, (long)oN, (long)oC, (long)oH, (long)oW, 27);
     PG_LAUNCH_OK("pg_tap_gather");
     return 0;
   }
@@ -209,9 +229,23 @@ extern "C" int pg_im2col_taps(const float* dY, int64_t yN, int64_t yC, int64_t y
   PG_REQUIRE(dY && G && N > 0 && Cpad >= KH * KW * C, "pg_im2col_taps: bad arguments");
   long blocks = ((long)N * H * W * Cpad + 1023) / 1024;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(im2col_taps_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
+  hipLaunchKernelGGL(im2col_taps_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
                      (long)yH, (long)yW, N, H, W, KH, KW, pad, C, Cpad, G);
   PG_LAUNCH_OK("pg_im2col_taps");
+  return 0;
+}
+
+// the same with a bf16 output tensor G [N][H][W][Cpad] (bf16 data path: operand of the output convolution's data- and
+// weight-gradient contractions)
+extern "C" int pg_im2col_taps_bf16(const float* dY, int64_t yN, int64_t yC, int64_t yH, int64_t yW, int32_t N, int32_t H,
+                                   int32_t W, int32_t KH, int32_t KW, int32_t pad, int32_t C, int32_t Cpad, void* G_bf16,
+                                   void* stream) {
+  PG_REQUIRE(dY && G_bf16 && N > 0 && Cpad >= KH * KW * C, "pg_im2col_taps_bf16: bad arguments");
+  long blocks = ((long)N * H * W * Cpad + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(im2col_taps_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
+                     (long)yH, (long)yW, N, H, W, KH, KW, pad, C, Cpad, reinterpret_cast<float*>(G_bf16));
+  PG_LAUNCH_OK("pg_im2col_taps_bf16");
   return 0;
 }
 

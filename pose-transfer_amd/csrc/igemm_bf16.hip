@@ -289,8 +289,12 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
         stat_n0 = nf;
       }
       float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
-      vec_store_64x64<TN>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
-                          p.Ho, p.Wo, ngc, bv, do_stats, stat_n0, st_s, st_q, p.stats);
+      if (p.out_bf16)
+        vec_store_64x64<TN, true>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
+                                  p.Ho, p.Wo, ngc, bv, do_stats, stat_n0, st_s, st_q, p.stats);
+      else
+        vec_store_64x64<TN, false>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
+                                   p.Ho, p.Wo, ngc, bv, do_stats, stat_n0, st_s, st_q, p.stats);
       if (do_stats) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -339,14 +343,15 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     const int ngs = cval ? ngc : 0;
     float* gradp = p.dst[0].grad;
     const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
-    int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0;
+    int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0, dfl = p.dst[0].flags;
 #pragma unroll
     for (int q = 1; q < PG_MAX_SRC; ++q)
       if (q < p.ndst && ngs >= p.dstart[q]) {
         gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
-        C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q];
+        C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags;
       }
     LaneDst ld;
+    ld.grad_bf16 = (dfl & PG_DST_GRAD_BF16) != 0; ld.fwd_bf16 = (dfl & PG_DST_FWD_BF16) != 0;
     ld.has_fwd = fwd0 != nullptr;
     const bool fa_ = aff0 != nullptr && ld.has_fwd;
     ld.has_mask = mask0 != nullptr;
@@ -357,8 +362,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
     ld.accum = dacc != 0;
 #pragma unroll
-    for (int h = 0; h < TM / 2; ++h)
-      vec_scatter_64x64<TN>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+    for (int h = 0; h < TM / 2; ++h) {
+      if (p.dst_io == 0)
+        vec_scatter_64x64<TN, 0>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+      else if (p.dst_io == 1)
+        vec_scatter_64x64<TN, 1>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+      else
+        vec_scatter_64x64<TN, 2>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+    }
   }
 }
 

@@ -40,6 +40,8 @@ struct ConvK {
   int xcd_swizzle;          // bf16 data path: the N tiles of one M tile run back-to-back on ONE XCD (shared L2)
   int vec_dst;              // epilogue 1: every destination has C % 4 == 0, 16-byte aligned pointers, < 2^32 elements
   int vec_out;              // epilogue 0 / partial tiles: dense [pixel][n_cnt] rows, n_cnt % 4 == 0, 16-byte aligned base
+  int out_bf16;             // epilogue 0: `out` is a bf16 NHWC tensor (bf16 STORAGE on the bf16 data path; statistics still from fp32)
+  int dst_io;               // epilogue 1: 0 = every destination fp32, 1 = every gradient and forward tensor bf16, 2 = mixed (flags)
   float* part;              // split-K with a workspace: split s stores its plain partial tile at part + s*part_stride,
   long part_stride;         // laid out [pixel = (n*Ho+oy)*Wo+ox][n_cnt]; splitk_fixup_kernel reduces and applies the epilogue
 };
@@ -76,6 +78,25 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // RNE,
 __device__ __forceinline__ float bf16_lo_f32(unsigned packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16_hi_f32(unsigned packed) { return __uint_as_float(packed & 0xffff0000u); }
 
+// ---- bf16 STORAGE helpers (round 3): 4 consecutive elements of a tensor that is either fp32 (16 bytes) or bf16 (8 bytes);
+// `idx` is the ELEMENT index of the first one.  The branch is wave-uniform (a property of the launch).
+__device__ __forceinline__ float4 ld4_any(const void* base, unsigned idx, bool bf) {
+  if (bf) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    return make_float4(bf16_lo_f32(u.x), bf16_hi_f32(u.x), bf16_lo_f32(u.y), bf16_hi_f32(u.y));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+__device__ __forceinline__ void st4_any(void* base, unsigned long idx, bool bf, float4 v) {
+  if (bf) {
+    uint2 u;
+    u.x = pack_bf16(v.x, v.y); u.y = pack_bf16(v.z, v.w);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = u;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
+  }
+}
+
 template <int OFF>
 __device__ __forceinline__ void lds_read128(f32x4& v, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
@@ -96,7 +117,7 @@ static __device__ __noinline__ void stat_spill(double* stats, int n, float g) {
 // tile (32 rows x 64 columns, pitch 68) a lane gets 4 consecutive columns of a row: 16 float4 stores per wave, a full
 // 256-byte row segment per 16 lanes.  Used for dense [pixel][n_cnt] destinations (forward output incl. bias and the
 // fused statistics, split-K partial tiles).
-template <int TN_>
+template <int TN_, bool OB = false>
 __device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowInfo* rows, int wm0, int lane,
                                                 float* obase, int n_cnt, int Ho, int Wo, int ngc, float4 bv,
                                                 bool do_stats, int stat_n0, float (&st_s)[2], float (&st_q)[2],
@@ -120,7 +141,7 @@ __device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][TN_], flo
       float4 v = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
       if (ri.n >= 0 && cval) {
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        *reinterpret_cast<float4*>(obase + (long)((ri.n * Ho + ri.oy) * Wo + ri.ox) * n_cnt + ngc) = v;
+        st4_any(obase, (unsigned long)((long)((ri.n * Ho + ri.oy) * Wo + ri.ox) * n_cnt + ngc), OB, v);
         if (do_stats) {
           const float s4 = (v.x + v.y) + (v.z + v.w);
           const float q4 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
@@ -144,10 +165,15 @@ __device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][TN_], flo
 struct LaneDst {
   float* gradp; const float* fwdp; const float* affp; const float* maskp;
   int C, c, affmul; float dslope; bool has_fwd, has_mask, accum;
+  bool grad_bf16 = false, fwd_bf16 = false;      // bf16 STORAGE of the gradient / forward tensor (pg_dst_t.flags)
 };
-template <int TN_>
+// IO: 0 = fp32 tensors, 1 = gradient AND forward tensor in bf16 STORAGE (compile-time: the batched loads stay straight-line
+// code), 2 = per-destination run-time flags (mixed launches; the loads sit under wave-uniform branches)
+template <int TN_, int IO = 0>
 __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowInfo* rows, int wm0, int lane,
                                                   const LaneDst& d, bool cval, int Ho, int Wo) {
+  const bool gbf = IO == 1 ? true : (IO == 0 ? false : d.grad_bf16);
+  const bool fbf = IO == 1 ? true : (IO == 0 ? false : d.fwd_bf16);
   constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR;     // lanes per row, rows per pass
   const int l31 = lane & 31, lhi = lane >> 5;
   const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
@@ -173,10 +199,10 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
         const int nn = ok[u] ? ri.n : 0;
         idx[u] = ok[u] ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
         v[u] = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
-        f[u] = *reinterpret_cast<const float4*>(d.fwdp + (d.has_fwd ? idx[u] : (unsigned)d.c));
+        f[u] = ld4_any(d.fwdp, d.has_fwd ? idx[u] : (unsigned)d.c, IO == 2 ? (d.has_fwd ? fbf : gbf) : fbf);
         ab[u] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nn);
         m[u] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nn * d.C + d.c : (d.c & 511)));
-        old[u] = *reinterpret_cast<const float4*>(d.gradp + (d.accum ? idx[u] : (unsigned)d.c));
+        old[u] = ld4_any(d.gradp, d.accum ? idx[u] : (unsigned)d.c, gbf);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -188,7 +214,7 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
           const float z = fmaf(f4[e], ab[u].x, ab[u].y) * m4[e];
           r4[e] = fmaf(g4[e] * m4[e], act_grad_s(z, d.dslope), d.accum ? o4[e] : 0.f);
         }
-        if (ok[u]) *reinterpret_cast<float4*>(d.gradp + idx[u]) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        if (ok[u]) st4_any(d.gradp, idx[u], gbf, make_float4(r4[0], r4[1], r4[2], r4[3]));
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -1114,8 +1114,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       const int ngc = nb0 + wn0 + (lane % (8 * TN)) * 4;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.bias && ngc < p.n_cnt) bv = *reinterpret_cast<const float4*>(p.bias + ngc);
-      vec_store_64x64<TN>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, out_g, p.n_cnt, p.Ho, p.Wo, ngc, bv, do_stats, stat_n0,
-                      st_s, st_q, p.stats);
+      if constexpr (PREC == 3) {      // bf16 STORAGE exists on the bf16 data path only
+        if (p.out_bf16)
+          vec_store_64x64<TN, true>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, out_g, p.n_cnt, p.Ho, p.Wo, ngc, bv, do_stats,
+                                    stat_n0, st_s, st_q, p.stats);
+        else
+          vec_store_64x64<TN, false>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, out_g, p.n_cnt, p.Ho, p.Wo, ngc, bv, do_stats,
+                                     stat_n0, st_s, st_q, p.stats);
+      } else {
+        vec_store_64x64<TN, false>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, out_g, p.n_cnt, p.Ho, p.Wo, ngc, bv, do_stats,
+                                   stat_n0, st_s, st_q, p.stats);
+      }
       vec_done = true;
     }
   }
@@ -1128,14 +1137,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       // constant-index field picks only (a runtime index into the kernel argument would put it in scratch memory)
       float* gradp = p.dst[0].grad;
       const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
-      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0;
+      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0, dfl = p.dst[0].flags;
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q)
         if (q < p.ndst && ngs >= p.dstart[q]) {
           gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
-          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q];
+          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags;
         }
       LaneDst ld;
+      ld.grad_bf16 = (dfl & PG_DST_GRAD_BF16) != 0; ld.fwd_bf16 = (dfl & PG_DST_FWD_BF16) != 0;
       ld.has_fwd = fwd0 != nullptr;
       const bool fa_ = aff0 != nullptr && ld.has_fwd;
       ld.has_mask = mask0 != nullptr;
@@ -1145,7 +1155,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       ld.C = C; ld.c = ngs - cst;
       ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
       ld.accum = dacc != 0;
-      vec_scatter_64x64<TN>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+      if constexpr (PREC == 3) {
+        if (p.dst_io == 0) vec_scatter_64x64<TN, 0>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+        else if (p.dst_io == 1) vec_scatter_64x64<TN, 1>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+        else vec_scatter_64x64<TN, 2>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+      } else {
+        vec_scatter_64x64<TN, 0>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+      }
       vec_done = true;
     }
   }
@@ -1315,6 +1331,7 @@ struct FixupK {
   pg_dst_t dst[PG_MAX_SRC];
   int ndst;
   int dstart[PG_MAX_SRC + 1];
+  int out_bf16;             // epilogue 0: `out` is bf16 (bf16 STORAGE); the destinations of epilogue 1 carry their own flags
 };
 
 // grid (workgroups per sample, N): every lane owns 4 consecutive columns of one pixel, sums the ks partial tiles and
@@ -1355,18 +1372,18 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
     }
     if (p.epilogue == 0) {
       if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-      *reinterpret_cast<float4*>(p.out + off) = v;
+      st4_any(p.out, (unsigned long)off, p.out_bf16 != 0, v);
       st_s += (v.x + v.y) + (v.z + v.w);
       st_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     } else {
       float* gradp = p.dst[0].grad;
       const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
-      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0;
+      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0, dfl = p.dst[0].flags;
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q)
         if (q < p.ndst && col >= p.dstart[q]) {
           gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
-          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q];
+          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags;
         }
       const int c = col - cst;
       const long idx = pixel * C + c;
@@ -1374,7 +1391,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
       float m4[4] = {1.f, 1.f, 1.f, 1.f};
       if (mask0) { const float4 m = *reinterpret_cast<const float4*>(mask0 + (long)n * C + c); m4[0] = m.x; m4[1] = m.y; m4[2] = m.z; m4[3] = m.w; }
       if (fwd0) {
-        const float4 f = *reinterpret_cast<const float4*>(fwd0 + idx);
+        const float4 f = ld4_any(fwd0, (unsigned)idx, (dfl & PG_DST_FWD_BF16) != 0);
         const float a = aff0 ? aff0[2 * n] : 1.f, b = aff0 ? aff0[2 * n + 1] : 0.f;
         const float f4[4] = {f.x, f.y, f.z, f.w};
         const float slope = act_slope(dact);
@@ -1384,9 +1401,9 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) g4[e] *= m4[e];
       }
-      float4* o = reinterpret_cast<float4*>(gradp + idx);
-      if (dacc) { const float4 old = *o; g4[0] += old.x; g4[1] += old.y; g4[2] += old.z; g4[3] += old.w; }
-      *o = make_float4(g4[0], g4[1], g4[2], g4[3]);
+      const bool gbf = (dfl & PG_DST_GRAD_BF16) != 0;
+      if (dacc) { const float4 old = ld4_any(gradp, (unsigned)idx, gbf); g4[0] += old.x; g4[1] += old.y; g4[2] += old.z; g4[3] += old.w; }
+      st4_any(gradp, (unsigned long)idx, gbf, make_float4(g4[0], g4[1], g4[2], g4[3]));
     }
   }
   if (p.stats != nullptr) {
@@ -1648,6 +1665,28 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   }
   k.part = use_part ? reinterpret_cast<float*>(d->workspace) : nullptr;
   k.part_stride = (long)out_elems;
+  {   // bf16 STORAGE of the output / the gradient destinations: only the row-major 8-byte epilogues implement it
+    bool io_bf16 = d->epilogue == 0 && d->out_bf16 != 0;
+    if (d->epilogue == 1)
+      for (int j = 0; j < d->ndst; ++j) io_bf16 = io_bf16 || d->dst[j].flags != 0;
+    k.out_bf16 = (d->epilogue == 0 && d->out_bf16 != 0) ? 1 : 0;
+    k.dst_io = 0;
+    if (d->epilogue == 1) {
+      bool all = true, none = true;
+      for (int j = 0; j < d->ndst; ++j) {
+        const int want = PG_DST_GRAD_BF16 | (d->dst[j].fwd ? PG_DST_FWD_BF16 : 0);
+        if ((d->dst[j].flags & want) != want || (d->dst[j].flags & ~want)) all = false;
+        if (d->dst[j].flags != 0) none = false;
+      }
+      k.dst_io = none ? 0 : (all ? 1 : 2);
+    }
+    if (io_bf16) {
+      PG_REQUIRE(bf16_data && tb == nullptr && cfg != 3 && d->out_act == PG_OUT_NONE && (ks == 1 || use_part) &&
+                 (d->epilogue == 0 ? k.vec_out != 0 : k.vec_dst != 0),
+                 "pg_conv: bf16 storage needs the bf16 data path, a dense 16-byte aligned NHWC output / destinations with "
+                 "C %% 32 == 0, no output activation and (for split-K launches) the workspace (cfg %d ks %d)", cfg, ks);
+    }
+  }
   if (ks > 1 && !use_part) {   // atomic accumulation needs zero-initialised destinations
     if (d->epilogue == 0) {
       PG_REQUIRE(d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
@@ -1703,6 +1742,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     f.part = k.part; f.stride = k.part_stride; f.ks = ks;
     f.ppix = d->Ho * d->Wo; f.n_cnt = k.n_cnt; f.epilogue = d->epilogue;
     f.bias = d->bias; f.out = d->out; f.stats = (d->epilogue == 0) ? d->stats : nullptr;
+    f.out_bf16 = k.out_bf16;
     for (int j = 0; j < PG_MAX_SRC; ++j) f.dst[j] = k.dst[j];
     f.ndst = k.ndst;
     for (int j = 0; j <= PG_MAX_SRC; ++j) f.dstart[j] = k.dstart[j];

@@ -708,6 +708,17 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dY, long ro
 // channel-contiguous (NHWC) gradient with C % 4 == 0 and 256 % (C/4) == 0: every lane streams float4s of its channel
 // quad over the pixels (fully coalesced, each byte read once); the generic kernel above reads 4 useful bytes per
 // 64-byte sector and every channel block re-reads the same lines
+template <bool BF>
+__device__ __forceinline__ float4 bg_ld4(const float* base, long idx) {      // idx = element index; BF: bf16 STORAGE (round 3)
+  if constexpr (BF) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(base + idx);
+  }
+}
+template <bool BF>
 __global__ __launch_bounds__(256) void bias_grad_nhwc_kernel(const float* dY, long npix, int C, float* db) {
   __shared__ float4 red[256];
   const int cq = C >> 2;                       // float4 chunks per pixel
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(256) void bias_grad_nhwc_kernel(const float* dY, lo
   for (; pix + 7 * step < npix; pix += 8 * step) {      // eight independent loads in flight per lane
     float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dY + (pix + u * step) * C + chunk * 4);
+    for (int u = 0; u < 8; ++u) v[u] = bg_ld4<BF>(dY, (pix + u * step) * C + chunk * 4);
 #pragma unroll
     for (int u = 0; u < 8; u += 2) {
       acc.x += v[u].x + v[u + 1].x; acc.y += v[u].y + v[u + 1].y;
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(256) void bias_grad_nhwc_kernel(const float* dY, lo
     }
   }
   for (; pix < npix; pix += step) {
-    const float4 v = *reinterpret_cast<const float4*>(dY + pix * C + chunk * 4);
+    const float4 v = bg_ld4<BF>(dY, pix * C + chunk * 4);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
   red[threadIdx.x] = acc;
@@ -754,7 +765,7 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
     // every workgroup ends with C float atomics on the SAME C addresses: measured ~90 ns per workgroup, serialised
     // (2048 workgroups: 106 us for a 67 MB tensor; 96: 21 us = 3.2 TB/s with eight 16-byte loads in flight per lane)
     if (blocks > 96) blocks = 96;
-    hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
+    hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
     PG_LAUNCH_OK("pg_bias_grad");
     return 0;
   }
@@ -764,5 +775,18 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
   hipLaunchKernelGGL(pg::bias_grad_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, dY, (long)rows_outer,
                      (long)rows_inner, C, (long)s_outer, (long)s_inner, (long)sC, db);
   PG_LAUNCH_OK("pg_bias_grad");
+  return 0;
+}
+
+// db[c] += sum over pixels of a dense NHWC gradient stored as bf16 (bf16 STORAGE on the bf16 data path, round 3)
+extern "C" int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, float* db, void* stream) {
+  PG_REQUIRE(dY_bf16 && db && npix > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ((size_t)dY_bf16 & 7) == 0,
+             "pg_bias_grad_bf16: dense NHWC bf16 tensor with C %% 4 == 0 and 256 %% (C / 4) == 0 required");
+  const int ppb = 256 / (C / 4);
+  long blocks = (npix + (long)ppb * 16 - 1) / ((long)ppb * 16);
+  if (blocks > 96) blocks = 96;
+  hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float*>(dY_bf16), (long)npix, C, db);
+  PG_LAUNCH_OK("pg_bias_grad_bf16");
   return 0;
 }

@@ -55,23 +55,56 @@ __global__ void norm_finalize_kernel(const double* sums, const float* gamma, con
   aff[2 * n + 1] = (float)(b - g * mean * rstd);
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* dz, const float* y, const float* mr, long L,
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {      // RNE, lo -> bits 0..15 (as pg_materialise_bf16)
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// 4 consecutive elements of an fp32 (T = float) or bf16 (T = unsigned short: bf16 STORAGE, round 3) tensor
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T* base, long i4) {
+  if constexpr (sizeof(T) == 4) {
+    return reinterpret_cast<const float4*>(base)[i4];
+  } else {
+    const uint2 u = reinterpret_cast<const uint2*>(base)[i4];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* base, long i4, float4 v) {
+  if constexpr (sizeof(T) == 4) {
+    reinterpret_cast<float4*>(base)[i4] = v;
+  } else {
+    uint2 u;
+    u.x = pack_bf16_rne(v.x, v.y); u.y = pack_bf16_rne(v.z, v.w);
+    reinterpret_cast<uint2*>(base)[i4] = u;
+  }
+}
+template <typename T>
+__device__ __forceinline__ float ld1(const T* base, long i) {
+  if constexpr (sizeof(T) == 4) return base[i];
+  else return __uint_as_float((unsigned)base[i] << 16);
+}
+
+template <typename TD, typename TY>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const TD* dz, const TY* y, const float* mr, long L,
                                                               double* bsums) {
   __shared__ double red[8];
   const int n = blockIdx.y;
   const float mean = mr[2 * n], rstd = mr[2 * n + 1];
-  const float* bd = dz + (long)n * L;
-  const float* by = y + (long)n * L;
+  const TD* bd = dz + (long)n * L;
+  const TY* by = y + (long)n * L;
   float s = 0.f, q = 0.f;
   const long L4 = L >> 2;
   const long stride = (long)gridDim.x * 256;
   long i = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < L4; i += 4 * stride) {           // eight independent 16-byte loads in flight per lane
+  for (; i + 3 * stride < L4; i += 4 * stride) {           // eight independent loads in flight per lane
     float4 d[4], v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      d[u] = reinterpret_cast<const float4*>(bd)[i + u * stride];
-      v[u] = reinterpret_cast<const float4*>(by)[i + u * stride];
+      d[u] = ld4(bd, i + u * stride);
+      v[u] = ld4(by, i + u * stride);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -81,14 +114,14 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* dz, c
     }
   }
   for (; i < L4; i += stride) {
-    const float4 d = reinterpret_cast<const float4*>(bd)[i];
-    const float4 v = reinterpret_cast<const float4*>(by)[i];
+    const float4 d = ld4(bd, i);
+    const float4 v = ld4(by, i);
     s += (d.x + d.y) + (d.z + d.w);
     q += (d.x * ((v.x - mean) * rstd) + d.y * ((v.y - mean) * rstd)) +
          (d.z * ((v.z - mean) * rstd) + d.w * ((v.w - mean) * rstd));
   }
   if (blockIdx.x == 0)
-    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) { s += bd[i]; q += bd[i] * ((by[i] - mean) * rstd); }
+    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) { s += ld1(bd, i); q += ld1(bd, i) * ((ld1(by, i) - mean) * rstd); }
   double ds = wave_sum_d((double)s), dq = wave_sum_d((double)q);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) { red[w] = ds; red[4 + w] = dq; }
@@ -99,13 +132,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* dz, c
   }
 }
 
-__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {      // RNE, lo -> bits 0..15 (as pg_materialise_bf16)
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* dz, const float* y, const float* mr,
+template <typename TD, typename TY>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(TD* dz, const TY* y, const float* mr,
                                                              const double* bsums, const float* gamma, int N, long L,
                                                              float* dgamma, float* dbeta, unsigned short* dy_bf16) {
   const int n = blockIdx.y;
@@ -114,17 +142,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* dz, const fl
   const float m1 = (float)(bsums[2 * n] / (double)L);
   const float m2 = (float)(bsums[2 * n + 1] / (double)L);
   const float k = g * rstd;
-  float* bd = dz + (long)n * L;
-  const float* by = y + (long)n * L;
+  TD* bd = dz + (long)n * L;
+  const TY* by = y + (long)n * L;
   const long L4 = L >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L4; i += (long)gridDim.x * 256) {
-    float4 d = reinterpret_cast<float4*>(bd)[i];
-    const float4 v = reinterpret_cast<const float4*>(by)[i];
+    float4 d = ld4(bd, i);
+    const float4 v = ld4(by, i);
     d.x = k * (d.x - m1 - ((v.x - mean) * rstd) * m2);
     d.y = k * (d.y - m1 - ((v.y - mean) * rstd) * m2);
     d.z = k * (d.z - m1 - ((v.z - mean) * rstd) * m2);
     d.w = k * (d.w - m1 - ((v.w - mean) * rstd) * m2);
-    reinterpret_cast<float4*>(bd)[i] = d;
+    st4(bd, i, d);
     if (dy_bf16) {           // the bf16 operand copy the data- / weight-gradient contractions read (bf16 data path)
       uint2 pk;
       pk.x = pack_bf16_rne(d.x, d.y); pk.y = pack_bf16_rne(d.z, d.w);
@@ -133,8 +161,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* dz, const fl
   }
   if (blockIdx.x == 0)
     for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) {
-      bd[i] = k * (bd[i] - m1 - ((by[i] - mean) * rstd) * m2);
-      if (dy_bf16) dy_bf16[(long)n * L + i] = (unsigned short)(pack_bf16_rne(bd[i], 0.f) & 0xffffu);
+      const float r = k * (ld1(bd, i) - m1 - ((ld1(by, i) - mean) * rstd) * m2);
+      if constexpr (sizeof(TD) == 4) bd[i] = r;
+      else bd[i] = (unsigned short)(pack_bf16_rne(r, 0.f) & 0xffffu);
+      if (dy_bf16) dy_bf16[(long)n * L + i] = (unsigned short)(pack_bf16_rne(r, 0.f) & 0xffffu);
     }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     double sg = 0.0, sb = 0.0;
@@ -186,22 +216,48 @@ extern "C" int pg_norm_finalize(const double* sums, const float* gamma, const fl
   return 0;
 }
 
-extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t N, int64_t L,
-                                  double* bsums, void* stream) {
-  PG_REQUIRE(dz && y && mr && bsums && N > 0 && L > 0 && L % 4 == 0, "pg_norm_bwd_reduce: bad arguments");
-  hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(norm_blocks_bwd(L, N), N), dim3(256), 0, (hipStream_t)stream, dz, y, mr,
-                     (long)L, bsums);
+// io_flags: bit 0 = dz is bf16, bit 1 = y is bf16 (bf16 STORAGE on the bf16 data path; sums stay double)
+extern "C" int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float* mr, int32_t N, int64_t L, double* bsums,
+                                     int32_t io_flags, void* stream) {
+  PG_REQUIRE(dz && y && mr && bsums && N > 0 && L > 0 && L % 4 == 0 && io_flags >= 0 && io_flags <= 3, "pg_norm_bwd_reduce: bad arguments");
+  const dim3 grid(norm_blocks_bwd(L, N), N);
+  typedef unsigned short bf;
+  hipStream_t st = (hipStream_t)stream;
+  switch (io_flags) {
+    case 0: hipLaunchKernelGGL((norm_bwd_reduce_kernel<float, float>), grid, dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums); break;
+    case 1: hipLaunchKernelGGL((norm_bwd_reduce_kernel<bf, float>), grid, dim3(256), 0, st, (const bf*)dz, (const float*)y, mr, (long)L, bsums); break;
+    case 2: hipLaunchKernelGGL((norm_bwd_reduce_kernel<float, bf>), grid, dim3(256), 0, st, (const float*)dz, (const bf*)y, mr, (long)L, bsums); break;
+    default: hipLaunchKernelGGL((norm_bwd_reduce_kernel<bf, bf>), grid, dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums); break;
+  }
   PG_LAUNCH_OK("pg_norm_bwd_reduce");
   return 0;
 }
+extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t N, int64_t L,
+                                  double* bsums, void* stream) {
+  return pg_norm_bwd_reduce_ex(dz, y, mr, N, L, bsums, 0, stream);
+}
 
-extern "C" int pg_norm_bwd_apply_ex(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
-                                    int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, void* stream) {
-  PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0, "pg_norm_bwd_apply: bad arguments");
-  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, dz, y, mr,
-                     bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
+// io_flags as in pg_norm_bwd_reduce_ex; with a bf16 dz the in-place result IS the bf16 operand of the layer's gradient
+// contractions (dy_bf16 = NULL then)
+extern "C" int pg_norm_bwd_apply_io(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma,
+                                    int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags,
+                                    void* stream) {
+  PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0 && io_flags >= 0 && io_flags <= 3, "pg_norm_bwd_apply: bad arguments");
+  const dim3 grid(norm_blocks(L), N);
+  typedef unsigned short bf;
+  hipStream_t st = (hipStream_t)stream;
+  switch (io_flags) {
+    case 0: hipLaunchKernelGGL((norm_bwd_apply_kernel<float, float>), grid, dim3(256), 0, st, (float*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
+    case 1: hipLaunchKernelGGL((norm_bwd_apply_kernel<bf, float>), grid, dim3(256), 0, st, (bf*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
+    case 2: hipLaunchKernelGGL((norm_bwd_apply_kernel<float, bf>), grid, dim3(256), 0, st, (float*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
+    default: hipLaunchKernelGGL((norm_bwd_apply_kernel<bf, bf>), grid, dim3(256), 0, st, (bf*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
+  }
   PG_LAUNCH_OK("pg_norm_bwd_apply");
   return 0;
+}
+extern "C" int pg_norm_bwd_apply_ex(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
+                                    int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, void* stream) {
+  return pg_norm_bwd_apply_io(dz, y, mr, bsums, gamma, N, L, dgamma, dbeta, dy_bf16, 0, stream);
 }
 
 extern "C" int pg_norm_bwd_apply(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,

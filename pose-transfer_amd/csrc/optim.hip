@@ -214,17 +214,30 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
-__global__ __launch_bounds__(256) void materialise_bf16_kernel(const float* x, const float* aff, const float* mask, int act,
-                                                               long HW, int C, uint4* out) {
+// IN_BF16: the raw tensor is stored as bf16 (bf16 STORAGE, round 3): 16 bytes in -> 16 bytes out per 8 elements.  out2 (optional):
+// a SECOND activated copy of the same normalised tensor (act2) — an encoder skip is read through LeakyReLU by the next
+// encoder level and through ReLU by the decoder; one pass over the raw tensor writes both operands.
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void materialise_bf16_kernel(const void* x, const float* aff, const float* mask, int act,
+                                                               long HW, int C, uint4* out, uint4* out2, int act2) {
   const int n = blockIdx.y;
   const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
-  const float slope = act_slope(act);
+  const float slope = act_slope(act), slope2 = act_slope(act2);
   const long per = HW * C / 8;                       // 8 elements (one 16-byte bf16 chunk) per thread-iteration
-  const float* xb = x + (long)n * HW * C;
   uint4* ob = out + (long)n * per;
+  uint4* ob2 = out2 ? out2 + (long)n * per : nullptr;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
-    const float4 v0 = reinterpret_cast<const float4*>(xb)[2 * i], v1 = reinterpret_cast<const float4*>(xb)[2 * i + 1];
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float v[8];
+    if constexpr (IN_BF16) {
+      const uint4 u = (reinterpret_cast<const uint4*>(x) + (long)n * per)[i];
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+    } else {
+      const float* xb = reinterpret_cast<const float*>(x) + (long)n * HW * C;
+      const float4 v0 = reinterpret_cast<const float4*>(xb)[2 * i], v1 = reinterpret_cast<const float4*>(xb)[2 * i + 1];
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    }
     const int c = (int)((i * 8) % C);
     float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (mask) {
@@ -232,12 +245,15 @@ __global__ __launch_bounds__(256) void materialise_bf16_kernel(const float* x, c
       const float4 m1 = *reinterpret_cast<const float4*>(mask + (long)n * C + c + 4);
       m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
     }
+    float r1[8], r2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float t = fmaf(v[e], a, b) * m[e];
-      v[e] = fmaxf(t, slope * t);
+      r1[e] = fmaxf(t, slope * t);
+      r2[e] = fmaxf(t, slope2 * t);
     }
-    ob[i] = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+    ob[i] = make_uint4(pack2_bf16(r1[0], r1[1]), pack2_bf16(r1[2], r1[3]), pack2_bf16(r1[4], r1[5]), pack2_bf16(r1[6], r1[7]));
+    if (ob2) ob2[i] = make_uint4(pack2_bf16(r2[0], r2[1]), pack2_bf16(r2[2], r2[3]), pack2_bf16(r2[4], r2[5]), pack2_bf16(r2[6], r2[7]));
   }
 }
 __global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float* W, int Cout, int Cin, unsigned short* nt,
@@ -264,15 +280,24 @@ __global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float* W, in
 }
 }  // namespace pg
 
-extern "C" int pg_materialise_bf16(const float* x, const float* aff, const float* mask, int32_t act, int32_t N, int64_t HW,
-                                   int32_t C, void* out_bf16, void* stream) {
+extern "C" int pg_materialise_bf16_ex(const void* x, int32_t x_is_bf16, const float* aff, const float* mask, int32_t act, int32_t N,
+                                      int64_t HW, int32_t C, void* out_bf16, void* out2_bf16, int32_t act2, void* stream) {
   PG_REQUIRE(x && out_bf16 && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "pg_materialise_bf16: bad arguments (C %% 8 == 0)");
   long blocks = (HW * C / 8 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pg::materialise_bf16_kernel, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
-                     (long)HW, C, reinterpret_cast<uint4*>(out_bf16));
+  if (x_is_bf16)
+    hipLaunchKernelGGL(pg::materialise_bf16_kernel<true>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
+                       (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2);
+  else
+    hipLaunchKernelGGL(pg::materialise_bf16_kernel<false>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
+                       (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2);
   PG_LAUNCH_OK("pg_materialise_bf16");
   return 0;
+}
+
+extern "C" int pg_materialise_bf16(const float* x, const float* aff, const float* mask, int32_t act, int32_t N, int64_t HW,
+                                   int32_t C, void* out_bf16, void* stream) {
+  return pg_materialise_bf16_ex(x, 0, aff, mask, act, N, HW, C, out_bf16, nullptr, 0, stream);
 }
 
 extern "C" int pg_weights_to_bf16(const float* W, int32_t taps, int32_t Cout, int32_t Cin, void* nt_bf16, void* t_bf16,

@@ -34,10 +34,14 @@ struct StemK {
   int N, Hi, Wi, Ho, Wo, pad;
   const unsigned short* Wp;   // conv: packed bf16 weights (pg_stem_pack_bf16)
   const float* bias;
-  float* out;                 // conv: NHWC [N][Ho][Wo][64]
+  float* out;                 // conv: fp32 NHWC [N][Ho][Wo][64], or NULL (bf16 STORAGE: only bf16 outputs)
   unsigned short* out_bf16;   // conv, optional: bf16(act(out)) NHWC, act slope `slope` (the next layer's operand)
   float slope;
+  unsigned short* obf2;       // conv, optional (round 3): further bf16 outputs bf16(act_k(out)) with slopes slope2 / slope3 —
+  unsigned short* obf3;       //   slope 1 = the raw tensor in bf16 STORAGE, 0.2 / 0 = LeakyReLU / ReLU operands
+  float slope2, slope3;
   const float* dY;            // wgrad: NHWC [N][Ho][Wo][64]
+  int dy_bf16;                // wgrad: dY is a bf16 tensor (bf16 STORAGE)
   float* part;                // wgrad: per-workgroup partial results [blocks][64][npad]
   int npad;
   int tiles_x, tiles_y, ntiles, ngroups;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
-        if (oy < p.Ho && ox < p.Wo) {
+        if (p.out != nullptr && oy < p.Ho && ox < p.Wo) {
           float* o = p.out + (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + l31;
           o[0] = acc[i][0][r] + bias0;
           o[32] = acc[i][1][r] + bias1;
@@ -189,7 +193,11 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
       }
     // ---- optional second output: the activated bf16 operand of the next layer (saves its pg_materialise_bf16 pass).  Lane
     //      pairs exchange one value so that every lane stores 4 bytes: even lanes (channel c, c+1) of row r, odd lanes of r+1.
-    if (p.out_bf16) {
+#pragma unroll
+    for (int ob = 0; ob < 3; ++ob) {
+      unsigned short* const optr = ob == 0 ? p.out_bf16 : (ob == 1 ? p.obf2 : p.obf3);
+      const float oslope = ob == 0 ? p.slope : (ob == 1 ? p.slope2 : p.slope3);
+      if (optr == nullptr) continue;
 #pragma unroll
       for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -197,14 +205,14 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
           const float bj = j ? bias1 : bias0;
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            const float va = apply_act_s(acc[i][j][r] + bj, p.slope), vb = apply_act_s(acc[i][j][r + 1] + bj, p.slope);
+            const float va = apply_act_s(acc[i][j][r] + bj, oslope), vb = apply_act_s(acc[i][j][r + 1] + bj, oslope);
             const float got = __shfl_xor((lane & 1) ? va : vb, 1, 64);
             const int rr = r + (lane & 1);
             const unsigned pk = (lane & 1) ? pack_bf16(got, vb) : pack_bf16(va, got);
             const int m = (rr & 3) + 8 * (rr >> 2) + 4 * lhi;
             const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
             if (oy < p.Ho && ox < p.Wo)
-              *reinterpret_cast<unsigned*>(p.out_bf16 + (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + j * 32 + (l31 & ~1)) = pk;
+              *reinterpret_cast<unsigned*>(optr + (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + j * 32 + (l31 & ~1)) = pk;
           }
         }
     }
@@ -284,6 +292,25 @@ __global__ __launch_bounds__(NW * 64) void stem_wgrad_bf16_kernel(const StemK p)
     // ---- gradient tile: fp32 NHWC -> bf16, one item = 8 channels of a pixel
     {
       constexpr int NI = (TH * TW * 8 + NT - 1) / NT;
+      if (p.dy_bf16) {            // bf16 STORAGE: the tile is copied as it is (16 bytes = 8 channels per item)
+        uint4 v[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+          const int e = tid + NT * u;
+          const int px = e >> 3, sl = e & 7;
+          const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+          const bool ok = (e < TH * TW * 8) & (oy < p.Ho) & (ox < p.Wo);
+          v[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.dY) +
+                                                 (ok ? (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + sl * 8 : 0));
+          if (!ok) v[u] = make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+          const int e = tid + NT * u;
+          const int px = e >> 3, sl = e & 7;
+          if (e < TH * TW * 8) *reinterpret_cast<uint4*>(dyt + px * 128 + ((sl ^ (((px >> 1) & 1) << 2)) << 4)) = v[u];
+        }
+      } else {
       float4 v[NI][2];
 #pragma unroll
       for (int u = 0; u < NI; ++u) {
@@ -303,6 +330,7 @@ __global__ __launch_bounds__(NW * 64) void stem_wgrad_bf16_kernel(const StemK p)
         w.x = pack_bf16(v[u][0].x, v[u][0].y); w.y = pack_bf16(v[u][0].z, v[u][0].w);
         w.z = pack_bf16(v[u][1].x, v[u][1].y); w.w = pack_bf16(v[u][1].z, v[u][1].w);
         if (e < TH * TW * 8) *reinterpret_cast<uint4*>(dyt + px * 128 + ((sl ^ (((px >> 1) & 1) << 2)) << 4)) = w;
+      }
       }
     }
     // ---- input patch, channel-last bf16
@@ -462,6 +490,9 @@ extern "C" int pg_stem_pack_bf16(const float* W, int32_t K, int32_t Cin, uint16_
 extern "C" int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                                     int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
                                     void* stream);
+extern "C" int pg_stem_conv_bf16_v3(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                                    int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
+                                    uint16_t* out2_bf16, int32_t act2, uint16_t* out3_bf16, int32_t act3, void* stream);
 
 extern "C" int pg_stem_conv_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                                  int32_t pad, const uint16_t* Wp, const float* bias, float* out, void* stream) {
@@ -471,7 +502,16 @@ extern "C" int pg_stem_conv_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, i
 extern "C" int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                                     int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
                                     void* stream) {
-  PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && Wp && out, "pg_stem_conv_bf16: bad arguments");
+  PG_REQUIRE(out != nullptr, "pg_stem_conv_bf16: out null");
+  return pg_stem_conv_bf16_v3(src, nsrc, N, Hi, Wi, K, stride, pad, Wp, bias, out, out_bf16, act, nullptr, PG_ACT_NONE, nullptr,
+                              PG_ACT_NONE, stream);
+}
+
+// Round 3 (bf16 STORAGE): `out` (fp32) may be NULL; up to three bf16 outputs bf16(act_k(conv + bias)), act NONE = the raw tensor
+extern "C" int pg_stem_conv_bf16_v3(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                                    int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,
+                                    uint16_t* out2_bf16, int32_t act2, uint16_t* out3_bf16, int32_t act3, void* stream) {
+  PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && Wp && (out || out_bf16 || out2_bf16 || out3_bf16), "pg_stem_conv_bf16: bad arguments");
   PG_REQUIRE((K == 3 && stride == 1) || (K == 4 && stride == 2), "pg_stem_conv_bf16: only k3s1 / k4s2 (got k%d s%d)", K, stride);
   pg::StemK k;
   PG_REQUIRE(pg::stem_fill(k, src, nsrc, N, Hi, Wi, K, stride, pad) == 0, "pg_stem_conv_bf16: sources must not carry aff / mask");
@@ -479,6 +519,8 @@ extern "C" int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N
   k.Wp = Wp; k.bias = bias; k.out = out;
   k.out_bf16 = out_bf16;
   k.slope = act == PG_ACT_RELU ? 0.f : (act == PG_ACT_LEAKY ? 0.2f : 1.f);
+  k.obf2 = out2_bf16; k.slope2 = act2 == PG_ACT_RELU ? 0.f : (act2 == PG_ACT_LEAKY ? 0.2f : 1.f);
+  k.obf3 = out3_bf16; k.slope3 = act3 == PG_ACT_RELU ? 0.f : (act3 == PG_ACT_LEAKY ? 0.2f : 1.f);
   const int CG = pg_stem_group_channels(k.Ctot);
   k.ngroups = (k.Ctot + CG - 1) / CG;
   hipStream_t st = (hipStream_t)stream;
@@ -490,15 +532,25 @@ extern "C" int pg_stem_conv_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N
   return 0;
 }
 
+extern "C" int pg_stem_wgrad_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
+                                     int32_t stride, int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* workspace,
+                                     int64_t workspace_floats, void* stream);
 extern "C" int pg_stem_wgrad_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
                                   int32_t stride, int32_t pad, const float* dY, float* dW, float* workspace,
                                   int64_t workspace_floats, void* stream) {
+  return pg_stem_wgrad_bf16_ex(src, nsrc, N, Hi, Wi, K, stride, pad, dY, 0, dW, workspace, workspace_floats, stream);
+}
+// dy_is_bf16: the gradient of the first layer's output is stored as bf16 (bf16 STORAGE, round 3)
+extern "C" int pg_stem_wgrad_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
+                                     int32_t stride, int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* workspace,
+                                     int64_t workspace_floats, void* stream) {
   PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && dY && dW, "pg_stem_wgrad_bf16: bad arguments");
   PG_REQUIRE((K == 3 && stride == 1) || (K == 4 && stride == 2), "pg_stem_wgrad_bf16: only k3s1 / k4s2 (got k%d s%d)", K, stride);
   pg::StemK k;
   PG_REQUIRE(pg::stem_fill(k, src, nsrc, N, Hi, Wi, K, stride, pad) == 0, "pg_stem_wgrad_bf16: sources must not carry aff / mask");
   PG_REQUIRE(k.Ho > 0 && k.Wo > 0 && N > 0, "pg_stem_wgrad_bf16: empty output");
-  k.dY = dY;
+  k.dY = reinterpret_cast<const float*>(dY);
+  k.dy_bf16 = dy_is_bf16 ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int c = k.Ctot;
   int rc;

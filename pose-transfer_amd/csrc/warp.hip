@@ -16,6 +16,33 @@ namespace pg {
 
 constexpr int MAXT = 32;
 
+// bf16 STORAGE (round 3, bf16 data path): 4 consecutive channels of an fp32 (16 B) or bf16 (8 B) NHWC tensor at a BYTE offset
+template <bool BF>
+__device__ __forceinline__ float4 wld4(const char* base, size_t byte_off) {
+  if constexpr (BF) {
+    const uint2 u = *reinterpret_cast<const uint2*>(base + byte_off);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(base + byte_off);
+  }
+}
+__device__ __forceinline__ unsigned wpack_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+template <bool BF>
+__device__ __forceinline__ void wst4(char* base, size_t byte_off, float4 v) {
+  if constexpr (BF) {
+    uint2 u;
+    u.x = wpack_bf16(v.x, v.y); u.y = wpack_bf16(v.z, v.w);
+    *reinterpret_cast<uint2*>(base + byte_off) = u;
+  } else {
+    *reinterpret_cast<float4*>(base + byte_off) = v;
+  }
+}
+
 template <typename TIn>
 __global__ __launch_bounds__(256) void mask_pyramid_kernel(const TIn* m, int N, int T, int H0, int W0, int h, int w,
                                                            float* out) {
@@ -230,9 +257,13 @@ __device__ __forceinline__ WarpInv invert_warp(const Theta& th, int h, int w, in
 // Arithmetic per output element is unchanged (same operations in the same order, adding a +-0 for a zero-weight tap).
 struct WarpTap { int o[4]; float w[4]; };          // byte offsets into the sample's feature map (x C x 4 applied), weights
 
-__global__ __launch_bounds__(256) void warp_fwd3_kernel(const float* feat, const float* aff, const float* warps,
+template <bool IB, bool OB>
+__global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const float* aff, const float* warps,
                                                         const float* masks, int T, int C, int h, int w, int H0, int W0,
-                                                        int align, int TP, float* out, uint8_t* amax) {
+                                                        int align, int TP, void* out, uint8_t* amax, int relu_out) {
+  // IB / OB: the feature map / the output are bf16 tensors (bf16 STORAGE); relu_out: store max(out, 0) — the decoder reads
+  // the warped skip only through its ReLU, and relu(x) > 0 <=> x > 0 keeps the backward's activation derivative
+  constexpr int ESI = IB ? 2 : 4, ESO = OB ? 2 : 4;
   // TP = pixels per tile (host: 64, fewer on small maps so that the grid still fills the chip)
   extern __shared__ __attribute__((aligned(16))) char wsm[];
   Theta* th = reinterpret_cast<Theta*>(wsm);                   // [MAXT]
@@ -253,7 +284,7 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const float* feat, const
   const int cpp = C >> 2;
   const int ppp = 256 / cpp;                                   // pixels per pass (host: cpp divides 256)
   const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
-  const char* fb = reinterpret_cast<const char*>(feat + (long)n * h * w * C);
+  const char* fb = reinterpret_cast<const char*>(feat) + (size_t)n * h * w * C * ESI;
   const int npix = h * w;
   const int cc = (tid % cpp) * 4, lp = tid / cpp;
   for (int p0 = blockIdx.x * TP; p0 < npix; p0 += gridDim.x * TP) {
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const float* feat, const
         for (int k = 0; k < 4; ++k) {
           const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
           const bool ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h);
-          tp.o[k] = (min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)) * C * 4;
+          tp.o[k] = (min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)) * C * ESI;
           tp.w[k] = ok ? wg[k] : 0.f;
         }
         taps[q] = tp;
@@ -309,7 +340,7 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const float* feat, const
           const WarpTap tp = taps[pl * T + t];
           float4 v[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(fb + (size_t)(unsigned)tp.o[k] + cc * 4);
+          for (int k = 0; k < 4; ++k) v[k] = wld4<IB>(fb, (size_t)(unsigned)tp.o[k] + cc * ESI);
           float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -327,16 +358,23 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const float* feat, const
           if (cand[e] > best[e]) { best[e] = cand[e]; bi[e] = id; }
       }
       const long o = ((long)n * npix + pix) * C + cc;
-      *reinterpret_cast<float4*>(out + o) = make_float4(best[0], best[1], best[2], best[3]);
+      if (relu_out) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], 0.f);
+      }
+      wst4<OB>(reinterpret_cast<char*>(out), (size_t)o * ESO, make_float4(best[0], best[1], best[2], best[3]));
       if (amax) *reinterpret_cast<uchar4*>(amax + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1],
                                                                     (unsigned char)bi[2], (unsigned char)bi[3]);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* gout, const uint8_t* amax, const float* warps,
+template <bool GB, bool DB>
+__global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, const uint8_t* amax, const float* warps,
                                                               const float* masks, int T, int C, int h, int w, int H0, int W0,
-                                                              int align, float* dfeat) {
+                                                              int align, void* dfeat) {
+  // GB / DB: the incoming gradient / the written input gradient are bf16 tensors (bf16 STORAGE)
+  constexpr int ESG = GB ? 2 : 4, ESD = DB ? 2 : 4;
   constexpr int FLAT = GATHER_T * GATHER_CAP;             // worst case per input pixel: no overflow possible
   __shared__ Theta th[MAXT];
   __shared__ WarpInv inv[MAXT];
@@ -425,7 +463,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* gout,
         wt[u] = val ? e_w[p][ee] : 0.f;
         o[u] = (nb + (pk & 0xffffff)) * C + c4;
         am[u] = *reinterpret_cast<const uchar4*>(amax + o[u]);
-        g[u] = *reinterpret_cast<const float4*>(gout + o[u]);
+        g[u] = wld4<GB>(reinterpret_cast<const char*>(gout), (size_t)o[u] * ESG);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -435,15 +473,16 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const float* gout,
         acc.w += am[u].w == tt[u] ? g[u].w * wt[u] : 0.f;
       }
     }
-    *reinterpret_cast<float4*>(dfeat + (nb + P) * C + c4) = acc;
+    wst4<DB>(reinterpret_cast<char*>(dfeat), (size_t)((nb + P) * C + c4) * ESD, acc);
   }
 }
 
 // Scatter form (float atomics), `wide_only`: only the elements whose selected transform is not "narrow" — the complement
 // of the gather kernel; workgroups of a sample without wide transforms leave at once.
-__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const uint8_t* amax, const float* warps,
+template <bool GB, bool DB>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const void* gout_, const uint8_t* amax, const float* warps,
                                                        const float* masks, int T, int C, int h, int w, int H0, int W0,
-                                                       int align, float* dfeat, int wide_only) {
+                                                       int align, void* dfeat_, int wide_only) {
   __shared__ Theta th[MAXT];
   __shared__ int wide[MAXT];
   __shared__ int any_wide;
@@ -460,7 +499,6 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const 
   // One lane per (pixel, channel): every element has exactly ONE selected transform (the forward argmax), so a lane
   // computes the taps of its own transform and issues its four corner atomics once.
   const long items = (long)h * w * C;
-  float* db = dfeat + (long)n * h * w * C;
   const long nb = (long)n * h * w;
   for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
     const int pix = (int)(it / C);
@@ -469,7 +507,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const 
     const long o = (nb + pix) * C + c;
     const int t = amax[o];
     if (t >= T || !wide[t]) continue;                // 255: no transform won (all masks zero) -> no gradient
-    const float g = gout[o];
+    float g;
+    if constexpr (GB) g = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(gout_)[o] << 16);
+    else g = reinterpret_cast<const float*>(gout_)[o];
     const float m = masks[(nb + pix) * T + t];
     const Taps tp = make_taps(th[t], i, j, h, w, align);
     const float gm = g * m;
@@ -478,7 +518,19 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* gout, const 
     for (int k = 0; k < 4; ++k) {
       const int xx = tp.x0 + (k & 1), yy = tp.y0 + (k >> 1);
       const float v = gm * wg[k];
-      if (v != 0.f && xx >= 0 && xx < w && yy >= 0 && yy < h) atomicAdd(db + ((long)yy * w + xx) * C + c, v);
+      if (v != 0.f && xx >= 0 && xx < w && yy >= 0 && yy < h) {
+        const long e = (nb + (long)yy * w + xx) * C + c;
+        if constexpr (DB) {
+          // packed bf16 atomic: this element's half carries the value, the neighbour's half adds +0
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          const unsigned pk = (c & 1) ? (wpack_bf16(0.f, v)) : (wpack_bf16(v, 0.f));
+          auto* addr = reinterpret_cast<__attribute__((address_space(1))) bf16x2*>(
+              reinterpret_cast<unsigned long long>(reinterpret_cast<unsigned short*>(dfeat_) + (e & ~1l)));
+          __builtin_amdgcn_global_atomic_fadd_v2bf16(addr, __builtin_bit_cast(bf16x2, pk));
+        } else {
+          atomicAdd(reinterpret_cast<float*>(dfeat_) + e, v);
+        }
+      }
     }
   }
 }
@@ -545,50 +597,82 @@ static int warp_grid(int C, int h, int w) {
   return (int)b;
 }
 
-extern "C" int pg_warp_mask_max_fwd(const float* feat, const float* aff, const float* warps, const float* lvl_masks,
-                                    int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
-                                    int32_t align_corners, float* out, uint8_t* argmax, void* stream) {
+// io_flags: bit 0 = `feat` is bf16, bit 1 = `out` is bf16, bit 2 = store relu(out) (bf16 STORAGE on the bf16 data path)
+extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const float* warps, const float* lvl_masks,
+                                       int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
+                                       int32_t align_corners, void* out, uint8_t* argmax, int32_t io_flags, void* stream) {
   PG_REQUIRE(feat && warps && lvl_masks && out, "pg_warp_mask_max_fwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_fwd: need T<=32, C%%4==0 (T=%d C=%d)", T, C);
   static const bool v1 = getenv("PG_WARP_FWD_V1") != nullptr;      // ablation switch: the round-1 per-lane walk
   const int cpp = C / 4;
   const size_t lds = ((MAXT * sizeof(Theta) + (size_t)(w + h + 64 * T) * 4 + 15) / 16) * 16 + (size_t)64 * T * sizeof(WarpTap);
+  const bool ib = io_flags & 1, ob = io_flags & 2;
+  const int relu = (io_flags & 4) ? 1 : 0;
   if (v1 || cpp > 256 || 256 % cpp != 0 || lds > 64 * 1024 || (double)h * w * C * 4.0 >= 2147483648.0) {
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, feat, aff, warps,
-                       lvl_masks, T, C, h, w, H0, W0, align_corners, out, argmax);
+    PG_REQUIRE(io_flags == 0, "pg_warp_mask_max_fwd: bf16 storage needs the tiled kernel (C / 4 must divide 256)");
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, (const float*)feat, aff, warps,
+                       lvl_masks, T, C, h, w, H0, W0, align_corners, (float*)out, argmax);
   } else {
     int tp = 64;
     const int ppp = 256 / cpp;
     while (tp > 8 && tp / 2 >= ppp && (((long)h * w + tp - 1) / tp) * N < 1024) tp /= 2;
     long tiles = ((long)h * w + tp - 1) / tp;
     if (tiles > 1024) tiles = 1024;
-    hipLaunchKernelGGL(warp_fwd3_kernel, dim3((unsigned)tiles, N), dim3(256), lds, (hipStream_t)stream, feat, aff, warps,
-                       lvl_masks, T, C, h, w, H0, W0, align_corners, tp, out, argmax);
+    const dim3 grid((unsigned)tiles, N);
+    hipStream_t st = (hipStream_t)stream;
+#define PGW_FWD(IB_, OB_)                                                                                                     \
+  hipLaunchKernelGGL((warp_fwd3_kernel<IB_, OB_>), grid, dim3(256), lds, st, feat, aff, warps, lvl_masks, T, C, h, w, H0, W0, \
+                     align_corners, tp, out, argmax, relu)
+    if (ib && ob) PGW_FWD(true, true);
+    else if (ib) PGW_FWD(true, false);
+    else if (ob) PGW_FWD(false, true);
+    else PGW_FWD(false, false);
+#undef PGW_FWD
   }
   PG_LAUNCH_OK("pg_warp_mask_max_fwd");
   return 0;
 }
+extern "C" int pg_warp_mask_max_fwd(const float* feat, const float* aff, const float* warps, const float* lvl_masks,
+                                    int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
+                                    int32_t align_corners, float* out, uint8_t* argmax, void* stream) {
+  return pg_warp_mask_max_fwd_io(feat, aff, warps, lvl_masks, N, T, C, h, w, H0, W0, align_corners, out, argmax, 0, stream);
+}
 
-extern "C" int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, const float* warps,
-                                    const float* lvl_masks, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w,
-                                    int32_t H0, int32_t W0, int32_t align_corners, float* dfeat, void* stream) {
+// io_flags: bit 0 = `gout` is bf16, bit 1 = `dfeat` is bf16
+extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, const float* warps,
+                                       const float* lvl_masks, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w,
+                                       int32_t H0, int32_t W0, int32_t align_corners, void* dfeat, int32_t io_flags, void* stream) {
   PG_REQUIRE(gout && argmax && warps && lvl_masks && dfeat, "pg_warp_mask_max_bwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_bwd: need T<=32, C%%4==0");
   static const bool no_gather = getenv("PG_WARP_BWD_SCATTER") != nullptr;       // ablation: round-1 scatter kernel only
+  const bool gb = io_flags & 1, db = io_flags & 2;
+  hipStream_t st = (hipStream_t)stream;
+#define PGW_BWD(KERNEL, GRID, ...)                                                                   \
+  do {                                                                                               \
+    if (gb && db) hipLaunchKernelGGL((KERNEL<true, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else if (gb) hipLaunchKernelGGL((KERNEL<true, false>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else if (db) hipLaunchKernelGGL((KERNEL<false, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else hipLaunchKernelGGL((KERNEL<false, false>), GRID, dim3(256), 0, st, __VA_ARGS__);            \
+  } while (0)
   if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM) {
     // gather kernel OVERWRITES dfeat (narrow transforms), then the scatter kernel adds the wide ones
-    hipLaunchKernelGGL(warp_bwd_gather_kernel, dim3((h * w + GATHER_PIX - 1) / GATHER_PIX, N), dim3(256), 0, (hipStream_t)stream,
-                       gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
+    PGW_BWD(warp_bwd_gather_kernel, dim3((h * w + GATHER_PIX - 1) / GATHER_PIX, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
+            align_corners, dfeat);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
     // (a sample without wide transforms costs one early-exiting workgroup round: keep that grid small)
-    hipLaunchKernelGGL(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
-                       warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 1);
+    PGW_BWD(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
+            align_corners, dfeat, 1);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (wide transforms)");
     return 0;
   }
-  PG_HIP(hipMemsetAsync(dfeat, 0, sizeof(float) * (size_t)N * h * w * C, (hipStream_t)stream));
-  hipLaunchKernelGGL(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, gout, argmax,
-                     warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
+  PG_HIP(hipMemsetAsync(dfeat, 0, (db ? 2 : 4) * (size_t)N * h * w * C, st));
+  PGW_BWD(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
+#undef PGW_BWD
   PG_LAUNCH_OK("pg_warp_mask_max_bwd");
   return 0;
+}
+extern "C" int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, const float* warps,
+                                    const float* lvl_masks, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w,
+                                    int32_t H0, int32_t W0, int32_t align_corners, float* dfeat, void* stream) {
+  return pg_warp_mask_max_bwd_io(gout, argmax, warps, lvl_masks, N, T, C, h, w, H0, W0, align_corners, dfeat, 0, stream);
 }

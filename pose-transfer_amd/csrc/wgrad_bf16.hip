@@ -291,6 +291,250 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: FOUR taps per workgroup for the thin layers (<= 128 channels on both sides at 128^2 / 256^2 resolution).
+// One tap per workgroup (kernel above) moves (BM + BN) x 64 operand elements per 2 x BM x BN x 64 FLOP; with 128 x 128 /
+// 128 x 64 tiles a K tile is only 8 / 4 MFMAs per wave, so the kernel is bound by the global->LDS latency of its two
+// stages and by L2 bandwidth (round-2 table: 165 - 400 TFLOP/s, dec.5 / enc.1 = 6.7 ms of a 26 ms north-star pass).
+// The four taps (r, s = 0..3) of one filter row read the SAME small-grid tile and, on the large grid, pixels
+// 2 qx + s - 1 of ONE image row: 130 consecutive large pixels cover all four taps of 64 small pixels.  So a workgroup =
+// (M tile, N tile, filter row r, K split): per K tile it DMAs 64 small + 130 large pixel rows (2.6 x fewer bytes), keeps
+// four accumulator sets (one per s), reads the shared operand's fragments once per k-step for all four taps, and has
+// 4 x the MFMA work between two barriers.  Three LDS stages, DMA issued two tiles ahead.
+// LDS image of the large patch: de-interleaved into an EVEN-column and an ODD-column plane (tap s reads plane s & 1 from
+// row p + (s >> 1)), so that the four pixel rows of a transposing read are consecutive LDS rows like the small operand's
+// and the same chunk swizzle makes them conflict-free.  Requires power-of-two Hs, Ws with Ws >= 64 (a K tile = 64
+// consecutive pixels of one small-grid row) and Hl = 2 Hs.
+struct Wg4K {
+  const unsigned short* sm;   // small-grid operand [N][Hs][Ws][Cs]
+  const unsigned short* lg;   // large-grid operand [N][2 Hs][2 Ws][Cl]
+  int Cs, Cl;
+  int N, Hs, Ws, lgWs, lgHs;
+  float* dW;                  // [16][Cout][ldw] fp32, accumulated
+  int Cout, ldw, col_off;
+  int ksplit, atomic, xcd_remap;
+  int ktot;                   // N * Hs * Ws / 64
+};
+
+template <int BM, int BN, int AS>
+__global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
+  constexpr int BS = AS ? BM : BN, BL = AS ? BN : BM;         // widths of the small-grid (shared) / large-grid (per-tap) operand
+  constexpr int TS = (BS == 128 && BL == 128) ? 2 : 1, TL = 1;   // MFMA tiles per wave along the shared / per-tap operand
+  constexpr int WS = BS / (32 * TS), WL = BL / (32 * TL);
+  static_assert(WS * WL == 8, "8 waves");
+  constexpr int S_CPR = BS / 8, L_CPR = BL / 8;               // 16-byte chunks per pixel row
+  constexpr int S_PPI = 64 / S_CPR, L_PPI = 64 / L_CPR;       // pixel rows per wave DMA instruction (1 KB)
+  constexpr int PL = (L_CPR == 16) ? 68 : 72;                 // rows per plane (65 used), a multiple of L_PPI
+  constexpr int S_ST = 64 * BS * 2, L_ST = 2 * PL * BL * 2, STAGE = S_ST + L_ST, NST = 3;
+  constexpr int S_NI = 64 / S_PPI, L_NI = 2 * PL / L_PPI;     // DMA instructions per tile
+  constexpr int S_PASS = (S_NI + 7) / 8, L_PASS = (L_NI + 7) / 8;
+  constexpr int NDMA = S_PASS + L_PASS;                       // DMA instructions per thread and tile
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bx = blockIdx.x, by = blockIdx.y, tr = blockIdx.z / p.ksplit, split = blockIdx.z - tr * p.ksplit;
+  if (p.xcd_remap) {            // the four filter rows of one (M tile, N tile, K split) on ONE XCD (shared L2)
+    const int mt = (int)gridDim.x, nt = (int)gridDim.y;
+    const int L = bx + mt * (by + nt * (int)blockIdx.z);
+    const int xcd = L & 7, j = L >> 3;
+    tr = j & 3;
+    const int u = (j >> 2) * 8 + xcd;
+    bx = u % mt;
+    by = (u / mt) % nt;
+    split = u / (mt * nt);
+  }
+  const int m0 = bx * BM, n0 = by * BN;
+  const int kper = (p.ktot + p.ksplit - 1) / p.ksplit;
+  const int kt0 = split * kper, kt1 = min(p.ktot, kt0 + kper);
+  if (kt0 >= kt1) return;
+
+  const char* const s_base = uniform_ptr(reinterpret_cast<const char*>(p.sm));
+  const char* const l_base = uniform_ptr(reinterpret_cast<const char*>(p.lg));
+  const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
+  const int s_c0 = AS ? m0 : n0, l_c0 = AS ? n0 : m0;        // first channel of this tile in the small / large operand
+
+  f32x16 acc[4][TS][TL];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+      for (int j = 0; j < TL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.f;
+
+  // ---- DMA: lane -> (LDS row of the instruction, 16-byte slot); the global chunk it moves is slot ^ swizzle(LDS row)
+  unsigned s_cofs[S_PASS];            // small operand: byte offset of (tile pixel, chunk) against the tile's first pixel
+  unsigned l_cofs[L_PASS];            // large patch: byte offset of (patch pixel P, chunk) against patch pixel 0
+  int l_P[L_PASS];                    // patch pixel of this lane's LDS row (0 .. 129 valid; >= 130: padding rows)
+#pragma unroll
+  for (int i = 0; i < S_PASS; ++i) {
+    const int ins = min(i * 8 + wave, S_NI - 1);
+    const int row = ins * S_PPI + lane / S_CPR, slot = lane % S_CPR;
+    s_cofs[i] = (unsigned)((row * p.Cs + s_c0 + ((slot ^ wg_swz<S_CPR>(row)) << 3)) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < L_PASS; ++i) {
+    const int ins = min(i * 8 + wave, L_NI - 1);             // surplus instructions repeat the last one (same data, same place)
+    const int row = ins * L_PPI + lane / L_CPR, slot = lane % L_CPR;
+    const int pl = row >= PL ? 1 : 0, pr = row - pl * PL;   // plane (0: even patch pixels, 1: odd), row inside the plane
+    const int P = 2 * pr + pl;
+    l_P[i] = P;
+    l_cofs[i] = (unsigned)((P * p.Cl + l_c0 + ((slot ^ wg_swz<L_CPR>(row)) << 3)) * 2);
+  }
+  const unsigned Cs2 = (unsigned)p.Cs * 2u, Cl2 = (unsigned)p.Cl * 2u;
+  const int Wl = 2 * p.Ws, Hl = 2 * p.Hs;
+  auto issue = [&](int stage, int kt) {
+    // tile coordinates are wave-uniform: small pixels q0 .. q0 + 63 of row (n, qy), columns qx0 ..; large row Y = 2 qy + tr - 1,
+    // patch pixel P <-> large column 2 qx0 - 1 + P
+    const int q0 = kt << 6;
+    const int qx0 = q0 & (p.Ws - 1);
+    const int qy = (q0 >> p.lgWs) & (p.Hs - 1);
+    const int n = q0 >> (p.lgWs + p.lgHs);
+    const int Y = 2 * qy + tr - 1;
+    const bool live = kt < kt1;                               // past the end: zero rows (keeps the vmcnt accounting uniform)
+    const bool row_ok = live & (Y >= 0) & (Y < Hl);
+    const bool left_ok = qx0 > 0, right_ok = qx0 + 64 < p.Ws;
+    const unsigned s_off = (unsigned)q0 * Cs2;
+    const unsigned l_off = ((unsigned)(n * Hl + Y) * (unsigned)Wl + (unsigned)(2 * qx0 - 1)) * Cl2;
+    float* const st = reinterpret_cast<float*>(smem + stage * STAGE);
+    const char* const zp = zero_pg + (lane & 7) * 16;
+#pragma unroll
+    for (int i = 0; i < S_PASS; ++i) {
+      const char* src = live ? s_base + (s_off + s_cofs[i]) : zp;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), st + min(i * 8 + wave, S_NI - 1) * 256, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < L_PASS; ++i) {
+      const bool ok = row_ok & (l_P[i] < 130) & (left_ok | (l_P[i] != 0)) & (right_ok | (l_P[i] != 129));
+      const char* src = ok ? l_base + (l_off + l_cofs[i]) : zp;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), st + S_ST / 4 + min(i * 8 + wave, L_NI - 1) * 256, 16, 0, 0);
+    }
+  };
+
+  // ---- operand fetch (transposing reads), lane roles as in the one-tap kernel
+  const int wsh0 = (wave / WL) * (TS * 32), wlg0 = (wave % WL) * (TL * 32);
+  const int r4 = (lane >> 2) & 3, cq = lane & 3, mb = (lane >> 4) & 1, kh = lane >> 5;
+  unsigned fs[TS], fl[4][TL];
+#pragma unroll
+  for (int t = 0; t < TS; ++t) {
+    const int chunk = ((wsh0 + 32 * t) >> 3) + 2 * mb + (cq >> 1);
+    fs[t] = lds0 + (unsigned)((8 * kh + r4) * (BS * 2)) + (unsigned)(((chunk ^ wg_swz<S_CPR>(r4)) << 4) + ((cq & 1) << 3));
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      const int chunk = ((wlg0 + 32 * t) >> 3) + 2 * mb + (cq >> 1);
+      const int row = (s & 1) * PL + (s >> 1) + 8 * kh + r4;             // tile pixel p = 8 kh + r4 (+ k-step) -> plane row p + (s >> 1)
+      fl[s][t] = lds0 + S_ST + (unsigned)(row * (BL * 2)) + (unsigned)(((chunk ^ wg_swz<L_CPR>(row)) << 4) + ((cq & 1) << 3));
+    }
+  typedef unsigned long long u64;
+  struct Frag { u64 lo, hi; };
+  struct FragSet { Frag sh[TS]; Frag lg[4][TL]; };
+  auto fetch = [&](int stage, auto ksc, FragSet& f) {
+    constexpr int KS = decltype(ksc)::value;
+    const unsigned so = (unsigned)(stage * STAGE);
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      lds_tr64<KS * 16 * BS * 2>(f.sh[t].lo, fs[t] + so);
+      lds_tr64<KS * 16 * BS * 2 + 4 * BS * 2>(f.sh[t].hi, fs[t] + so);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < TL; ++t) {
+        lds_tr64<KS * 16 * BL * 2>(f.lg[s][t].lo, fl[s][t] + so);
+        lds_tr64<KS * 16 * BL * 2 + 4 * BL * 2>(f.lg[s][t].hi, fl[s][t] + so);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfmas = [&](const FragSet& f) {
+    __builtin_amdgcn_s_setprio(1);
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TS; ++i)
+#pragma unroll
+        for (int j = 0; j < TL; ++j) {
+          const u64x2 sh = {f.sh[i].lo, f.sh[i].hi}, lg = {f.lg[s][j].lo, f.lg[s][j].hi};
+          if (AS) acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sh), __builtin_bit_cast(bf16x8, lg), acc[s][i][j], 0, 0, 0);
+          else acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, lg), __builtin_bit_cast(bf16x8, sh), acc[s][i][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr int NRD = 2 * (TS + 4 * TL);
+#define PGW_WAIT(n)                                                 \
+  do {                                                              \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+
+  issue(0, kt0);
+  issue(1, kt0 + 1);
+  issue(2, kt0 + 2);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  FragSet f0, f1;
+  fetch(0, K0{}, f0);
+  int stage = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int nstage = stage == NST - 1 ? 0 : stage + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(stage, K1{}, f1);
+    PGW_WAIT(NRD);
+    mfmas(f0);
+    fetch(stage, K2{}, f0);
+    PGW_WAIT(NRD);
+    mfmas(f1);
+    fetch(stage, K3{}, f1);
+    PGW_WAIT(NRD);
+    mfmas(f0);
+    // every read of this stage has landed (lgkmcnt 0) and tile kt + 1 is in LDS (only the NDMA loads of tile kt + 2 may be
+    // outstanding): after the barrier the stage is free for tile kt + 3
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(stage, kt + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < kt1) fetch(nstage, K0{}, f0);
+    mfmas(f1);
+    stage = nstage;
+  }
+#undef PGW_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy loads past the end must not outlive the workgroup's LDS
+
+  // ---- epilogue: dW[tap = 4 tr + s][m][col_off + n] += acc[s]
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float* const out = p.dW + (long)(tr * 4 + s) * p.Cout * p.ldw + p.col_off;
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+      for (int j = 0; j < TL; ++j) {
+        // AS: rows (Cout) = shared operand, columns = per-tap operand; else the other way round
+        const int mrow0 = m0 + (AS ? wsh0 + 32 * i : wlg0 + 32 * j);
+        const int n = n0 + (AS ? wlg0 + 32 * j : wsh0 + 32 * i) + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          float* o = out + (long)m * p.ldw + n;
+          if (p.atomic) atomicAdd(o, acc[s][i][j][r]);
+          else *o += acc[s][i][j][r];
+        }
+      }
+  }
+}
+
 }  // namespace pg
 
 using namespace pg;
@@ -329,6 +573,49 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
              "pg_wgrad_bf16: operands must be < 4 GiB each (32-bit byte offsets)");
   int bm = (Cout % 256 == 0) ? 256 : (Cout % 128 == 0 ? 128 : 64), bn = (Cx % 256 == 0) ? 256 : (Cx % 128 == 0 ? 128 : 64);
   const int ktot = (int)((k.Q + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+  // ---- four taps per workgroup (wgrad_bf16_tr4_kernel): the thin layers, where the one-tap kernel's tiles are too small to
+  // hide the global->LDS latency — and, measured, every other layer whose small grid has >= 64 columns as well (128-wide
+  // tiles x 4 taps at 1000 - 1080 TFLOP/s against 256 x 256 one-tap tiles at 580 on half the chip; north-star pass 25.5 ->
+  // 24.5 ms thin layers only (PG_WGTR4=1) -> 24.3 ms all eligible layers (default, 2).  PG_WGTR4=0 disables the kernel.
+  {
+    static const int mode = getenv("PG_WGTR4") ? atoi(getenv("PG_WGTR4")) : 2;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const bool geo = pow2(Hs) && pow2(Ws) && Ws >= 64 && Hl == 2 * Hs && Wl == 2 * Ws;
+    const bool thin = bm < 256 || bn < 256;
+    if (mode > 0 && geo && (thin || mode == 2) && ksplit <= 0) {
+      const int tm = Cout % 128 == 0 ? 128 : 64, tn = Cx % 128 == 0 ? 128 : 64;
+      Wg4K q;
+      memset(&q, 0, sizeof(q));
+      q.sm = k.sm; q.lg = k.lg; q.Cs = k.Cs; q.Cl = k.Cl;
+      q.N = N; q.Hs = Hs; q.Ws = Ws;
+      q.lgWs = __builtin_ctz((unsigned)Ws); q.lgHs = __builtin_ctz((unsigned)Hs);
+      q.dW = dW; q.Cout = Cout; q.ldw = ldw; q.col_off = col_off;
+      q.ktot = ktot;
+      const int mt4 = Cout / tm, nt4 = Cx / tn;
+      static const int target4 = getenv("PG_WGTR4_TARGET") ? atoi(getenv("PG_WGTR4_TARGET")) : 256;
+      const long base4 = (long)mt4 * nt4 * 4;
+      int ks4 = (int)((target4 + base4 - 1) / base4);
+      if (ks4 > ktot / 8) ks4 = ktot / 8;                       // >= 8 K tiles per workgroup
+      if (ks4 < 1) ks4 = 1;
+      while (ks4 > 1 && (long)(ks4 - 1) * ((ktot + ks4 - 1) / ks4) >= ktot) --ks4;
+      q.ksplit = ks4; q.atomic = ks4 > 1 ? 1 : 0;
+      q.xcd_remap = (((long)mt4 * nt4 * ks4) % 8 == 0 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
+      dim3 grid4(mt4, nt4, 4 * ks4);
+#define PGW4_LAUNCH(M_, N_)                                                                                    \
+  do {                                                                                                         \
+    if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 1>), grid4, dim3(512), 0, st, q);      \
+    else hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 0>), grid4, dim3(512), 0, st, q);                   \
+  } while (0)
+      if (tm == 128 && tn == 128) PGW4_LAUNCH(128, 128);
+      else if (tm == 128) PGW4_LAUNCH(128, 64);
+      else PGW4_LAUNCH(64, 128);
+#undef PGW4_LAUNCH
+      PG_LAUNCH_OK("pg_wgrad_bf16 (four-tap kernel)");
+      last_info() = 6 | (ks4 << 16) | (1 << 30);
+      return 0;
+    }
+  }
   // few pixels (deep layers at small batch): K cannot be split (>= 16 K tiles per workgroup), so 256-wide tiles leave most
   // of the chip idle (64 workgroups for a 512 x 512 filter) — halve the tile sides until ~128 workgroups exist
   static const bool small_tiles = getenv("PG_WGTR_NO_SMALL_TILES") == nullptr;
@@ -357,7 +644,6 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   k.ksplit = ks; k.atomic = ks > 1 ? 1 : 0;
   k.xcd_remap = (((long)mt * nt * ks) % 8 == 0 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
   dim3 grid(mt, nt, 16 * ks);
-  hipStream_t st = (hipStream_t)stream;
 #define PGW_LAUNCH(M_, N_)                                                                                   \
   do {                                                                                                       \
     if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<M_, N_, 1>), grid, dim3(512), 0, st, k);      \

@@ -115,13 +115,16 @@ class Deformable_Generator(_ArenaModule):
     def engine(self, n, stage=0):
         """Engine (activation buffers + schedules) of one forward at batch n; `stage` separates the chained forwards
         of the stacked generator, which must all stay alive until the backward pass."""
-        if (n, stage) not in self._engines:
-            self._engines[(n, stage)] = E.GeneratorEngine(
+        # engines are built for ONE storage mode (bf16 STORAGE on the bf16 data path, runtime/engine.py); the chained stages of
+        # the stacked generator back-propagate an image gradient through the first layer and keep fp32 storage
+        key = (n, stage, E.bf16_store() and getattr(self, "bf16_store_ok", True))
+        if key not in self._engines:
+            self._engines[key] = E.GeneratorEngine(
                 self.arena, n, self.image_size[0], self.image_size[1], self.pose_dim, self.nfilters_enc,
                 self.nfilters_dec, True, self.align_corners, self.device, n_warps=self.number_of_transforms,
-                masked=self.warp_skip == "mask")
-            self._engines[(n, stage)].drop_stream = "drop/s%d" % stage
-        return self._engines[(n, stage)]
+                masked=self.warp_skip == "mask", bf16_ok=getattr(self, "bf16_store_ok", True))
+            self._engines[key].drop_stream = "drop/s%d" % stage
+        return self._engines[key]
 
     def forward(self, input, warps, masks=None, drop_masks=None, stage=0):
         """Dropout2d follows nn.Module.train()/.eval() like the reference's blocks (networks.py:161); explicit
@@ -143,6 +146,7 @@ class Stacked_Generator(nn.Module):
         self.nfilters_enc, self.nfilters_dec, self.use_input_pose = tuple(nfilters_enc), tuple(nfilters_dec), use_input_pose
         self.generator = Deformable_Generator(input_nc, pose_dim, image_size, nfilters_enc, nfilters_dec, warp_skip,
                                               use_input_pose, align_corners, device)
+        self.generator.bf16_store_ok = False      # the chained backward needs the image gradient of the first layer (fp32 path)
 
     @property
     def arena(self):
@@ -198,11 +202,12 @@ class Generator(_ArenaModule):
         self.drop_seed = 0
 
     def engine(self, n, stage=0):
-        if (n, stage) not in self._engines:
-            self._engines[(n, stage)] = E.GeneratorEngine(self.arena, n, self.image_size[0], self.image_size[1],
-                                                          self.pose_dim, self.nfilters_enc, self.nfilters_dec, False,
-                                                          False, self.device)
-        return self._engines[(n, stage)]
+        key = (n, stage, E.bf16_store())
+        if key not in self._engines:
+            self._engines[key] = E.GeneratorEngine(self.arena, n, self.image_size[0], self.image_size[1],
+                                                   self.pose_dim, self.nfilters_enc, self.nfilters_dec, False,
+                                                   False, self.device)
+        return self._engines[key]
 
     def forward(self, input, drop_masks=None):
         eng = self.engine(input.shape[0])

@@ -58,7 +58,7 @@ def build_lib(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or not os.path.exists(LIB):
+    if force or jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -7,6 +7,7 @@ pre-activation (:150,152) and torch.cat (:241,245,271,284,286) are never materia
 carries a per-sample affine ``aff`` [N,2] and an optional channel mask [N,C] that consumers apply on
 load.  Parameters live in flat arenas (params / grads / Adam m / Adam v) in packed kernel layout.
 """
+import contextlib
 import os
 import math
 import weakref
@@ -288,6 +289,27 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
     return ent[idx]
 
 
+# bf16 STORAGE (round 3): on the bf16 data path the GENERATOR keeps its raw activations and the gradients flowing through
+# them as bf16 tensors (PG_NO_BF16_STORE=1: fp32 storage as in round 2).  Kernels that take raw device pointers learn the
+# dtype from this registry (data_ptr -> tensor) or from per-descriptor flags (lib.make_dst, pg_conv_t.out_bf16).
+BF16_STORE = os.environ.get("PG_NO_BF16_STORE") is None
+_BF16_TENSORS = weakref.WeakValueDictionary()
+
+
+def bf16_store():
+    return PRECISION == 3 and BF16_STORE
+
+
+def _reg_bf16(t):
+    if t.dtype == torch.bfloat16:
+        _BF16_TENSORS[t.data_ptr()] = t
+    return t
+
+
+def _is_bf16_ptr(ptr):
+    return int(ptr or 0) in _BF16_TENSORS
+
+
 _BF_CTX = None              # bf16 operand cache of the pass that is running (set by the engines, see BfCache)
 _BF_CTX_X = None            # during a backward pass: the forward pass's cache (activated inputs = weight-gradient operands)
 
@@ -314,24 +336,49 @@ class BfCache:
     def reserve(self, ptr, C, act, aff, mask, need, dev):
         """the buffer of this key, marked valid: the caller's kernel writes the operand itself"""
         k = self.key(ptr, C, act, aff, mask)
-        b = self.buf.get(k)
-        if b is None or b.numel() < need:
-            b = self.buf[k] = torch.empty(need, dtype=torch.bfloat16, device=dev)
+        b = self._buffer(k, need, dev)
         self.valid.add(k)
         return b
 
-    def get(self, ptr, C, act, aff, mask, N, HW, dev):
-        """the bf16 NHWC tensor bf16(act((a*x+b)*mask)), materialised on the current stream if this pass has not yet"""
+    def adopt(self, ptr, C, act, aff, mask, tensor):
+        """`tensor` (bf16, written by its producer) IS the operand of this key: no materialisation pass"""
         k = self.key(ptr, C, act, aff, mask)
-        need = N * HW * C
+        self.buf[k] = tensor
+        self.valid.add(k)
+        return tensor
+
+    def _buffer(self, k, need, dev):
         b = self.buf.get(k)
-        if b is None or b.numel() < need:
+        if b is None or b.numel() < need or b.data_ptr() in _BF16_TENSORS:     # never write into an adopted storage tensor
             b = self.buf[k] = torch.empty(need, dtype=torch.bfloat16, device=dev)
             self.valid.discard(k)
-        if k not in self.valid:
-            L.call("pg_materialise_bf16", ptr, aff, mask, act, N, HW, C, L.ptr(b), L.stream())
-            self.valid.add(k)
         return b
+
+    def get(self, ptr, C, act, aff, mask, N, HW, dev):
+        """the bf16 NHWC tensor bf16(act((a*x+b)*mask)), materialised on the current stream if this pass has not yet.
+        A raw tensor in bf16 STORAGE that needs no prologue (gradients) is its own operand."""
+        k = self.key(ptr, C, act, aff, mask)
+        if k in self.valid:
+            return self.buf[k]
+        src = _BF16_TENSORS.get(int(ptr or 0))
+        if src is not None and act == L.ACT_NONE and not aff and not mask:
+            return self.adopt(ptr, C, act, aff, mask, src)
+        b = self._buffer(k, N * HW * C, dev)
+        L.call("pg_materialise_bf16_ex", ptr, 1 if src is not None else 0, aff, mask, act, N, HW, C, L.ptr(b), None, 0, L.stream())
+        self.valid.add(k)
+        return b
+
+    def get2(self, ptr, C, act, act2, aff, mask, N, HW, dev):
+        """both activated copies of one normalised tensor in ONE pass over the raw tensor (an encoder skip is read through
+        LeakyReLU by the next level and through ReLU by the decoder)"""
+        k1, k2 = self.key(ptr, C, act, aff, mask), self.key(ptr, C, act2, aff, mask)
+        if k1 in self.valid and k2 in self.valid:
+            return
+        b1, b2 = self._buffer(k1, N * HW * C, dev), self._buffer(k2, N * HW * C, dev)
+        L.call("pg_materialise_bf16_ex", ptr, 1 if _is_bf16_ptr(ptr) else 0, aff, mask, act, N, HW, C, L.ptr(b1), L.ptr(b2), act2,
+               L.stream())
+        self.valid.add(k1)
+        self.valid.add(k2)
 
 
 def _bf16_sources(srcs, N, Hi, Wi, act, dev):
@@ -345,7 +392,8 @@ def _bf16_sources(srcs, N, Hi, Wi, act, dev):
             need = N * Hi * Wi * s.C
             if pool[j] is None or pool[j].numel() < need:
                 pool[j] = torch.empty(need, dtype=torch.bfloat16, device=dev)
-            L.call("pg_materialise_bf16", s.ptr, s.aff, s.mask, act, N, Hi * Wi, s.C, L.ptr(pool[j]), L.stream())
+            L.call("pg_materialise_bf16_ex", s.ptr, 1 if _is_bf16_ptr(s.ptr) else 0, s.aff, s.mask, act, N, Hi * Wi, s.C,
+                   L.ptr(pool[j]), None, 0, L.stream())
             t = pool[j]
         q = L.Src()
         q.ptr, q.C = L.ptr(t), s.C
@@ -368,6 +416,9 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
                 wCout, wCin, transposed = wCin, wCout, False
             act = L.ACT_NONE
         else:
+            if any(_is_bf16_ptr(s.ptr) for s in srcs) or (isinstance(out, torch.Tensor) and out.dtype == torch.bfloat16):
+                raise RuntimeError("bf16 storage: this convolution is not eligible for the bf16 data path (channels %s -> %d)"
+                                   % ([s.C for s in srcs], ncols))
             prec = 0
     d = L.ConvDesc()
     for i, s in enumerate(srcs):
@@ -382,6 +433,7 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
         ncnt = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
         d.epilogue = 0
         d.out = out if isinstance(out, int) else L.ptr(out)
+        d.out_bf16 = 1 if (isinstance(out, torch.Tensor) and out.dtype == torch.bfloat16) else 0
         d.bias = L.ptr(bias)
         d.out_act = out_act
         if out_strides is None:
@@ -430,6 +482,17 @@ STEM_BF16 = os.environ.get("PG_NO_STEM_BF16") is None     # ablation switch: fp3
 def stem_pack_floats(K, cin):
     """Size (in floats) of the weight-repack scratch of a first layer: fp32 [Cin][K*K][64] or the packed bf16 filter."""
     return max(cin * K * K * 64, (int(L.load().pg_stem_pack_elems(K, cin)) + 1) // 2)
+
+
+def _stem_conv_stored(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, raw, outs):
+    """First-layer convolution in bf16 STORAGE: `raw` (bf16 NHWC tensor) receives bf16(conv + bias); `outs` = up to two
+    (activation, bf16 tensor) pairs written in the same pass (the operands of the layers that read this output)."""
+    cin = sum(a.C for a in acts)
+    L.call("pg_stem_pack_bf16", L.ptr(W), K, cin, L.ptr(wt_buf), L.stream())
+    arr = (L.Src * len(acts))(*[a.src() for a in acts])
+    o = list(outs) + [(L.ACT_NONE, None)] * (2 - len(outs))
+    L.call("pg_stem_conv_bf16_v3", arr, len(acts), N, Hi, Wi, K, stride, pad, L.ptr(wt_buf), L.ptr(bias), None,
+           L.ptr(raw), L.ACT_NONE, L.ptr(o[0][1]), o[0][0], L.ptr(o[1][1]), o[1][0], L.stream())
 
 
 def _small_cin_conv(acts, N, Hi, Wi, K, stride, pad, W, bias, wt_buf, out, next_act=None, bf_ptr=None):
@@ -569,11 +632,14 @@ def _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large):
     return bool(x_is_large) and Hs == (Hl - 2) // 2 + 1 and Ws == (Wl - 2) // 2 + 1
 
 
-def _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large=True):
+def _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large=True,
+                 dY=None):
+    # operands in bf16 STORAGE have no fp32 kernel to fall back to: every size goes to the transposing-read kernels
+    stored = _is_bf16_ptr(dY if isinstance(dY, int) else L.ptr(dY)) or any(_is_bf16_ptr(s_.ptr) for s_ in srcs)
     return (PRECISION == 3 and WGRAD_TR and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None
             and cout_store == 0 and _k4s2_geometry(Hs, Ws, Hl, Wl, x_is_large) and isinstance(dW, torch.Tensor)
-            and _tr_channels_ok(Cout, [s_.C for s_ in srcs]) and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS
-            and N * Hs * Ws >= WGRAD_TR_MIN_PIXELS)
+            and _tr_channels_ok(Cout, [s_.C for s_ in srcs])
+            and (stored or (2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS and N * Hs * Ws >= WGRAD_TR_MIN_PIXELS)))
 
 
 def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16=None):
@@ -593,15 +659,18 @@ def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, 
 
     dyb = dy_bf16
     if dyb is None:
-        dyb = buf(L.PG_MAX_SRC, N * Hy * Wy * Cout)
-        L.call("pg_materialise_bf16", dY if isinstance(dY, int) else L.ptr(dY), None, None, L.ACT_NONE, N, Hy * Wy, Cout,
-               L.ptr(dyb), L.stream())
+        dyp = dY if isinstance(dY, int) else L.ptr(dY)
+        dyb = _BF16_TENSORS.get(int(dyp))                 # bf16 STORAGE: the gradient tensor is the operand
+        if dyb is None:
+            dyb = buf(L.PG_MAX_SRC, N * Hy * Wy * Cout)
+            L.call("pg_materialise_bf16", dyp, None, None, L.ACT_NONE, N, Hy * Wy, Cout, L.ptr(dyb), L.stream())
     c0 = 0
     for j, s_ in enumerate(srcs):
         xb = _BF_CTX_X.lookup(s_.ptr, s_.C, act, s_.aff, s_.mask) if _BF_CTX_X is not None else None
         if xb is None:
             xb = buf(j, N * Hx * Wx * s_.C)
-            L.call("pg_materialise_bf16", s_.ptr, s_.aff, s_.mask, act, N, Hx * Wx, s_.C, L.ptr(xb), L.stream())
+            L.call("pg_materialise_bf16_ex", s_.ptr, 1 if _is_bf16_ptr(s_.ptr) else 0, s_.aff, s_.mask, act, N, Hx * Wx, s_.C,
+                   L.ptr(xb), None, 0, L.stream())
         L.call("pg_wgrad_bf16_ex", L.ptr(xb), s_.C, L.ptr(dyb), Cout, 1 if x_is_large else 0, N, Hs, Ws, Hl, Wl, L.ptr(dW), Cin,
                c0, 0, L.stream())
         c0 += s_.C
@@ -611,7 +680,7 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
            y_strides=None, ksplit=0, cout_store=0):
     dyb = None
     if _BF_CTX is not None and _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N,
-                                            x_is_large):
+                                            x_is_large, dY):
         # the bf16 gradient is shared with the data-gradient contraction of the same layer: convert it once, on the MAIN stream
         Hy, Wy = (Hs, Ws) if x_is_large else (Hl, Wl)
         dyb = _BF_CTX.get(dY if isinstance(dY, int) else L.ptr(dY), Cout, L.ACT_NONE, None, None, N, Hy * Wy, dW.device)
@@ -627,12 +696,15 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
 
 def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
                 y_strides=None, ksplit=0, cout_store=0, dy_bf16=None):
-    if _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large):
+    if _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large, dY):
         run = lambda: _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16)
         if PROFILER is not None:
             PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
             return
         return run()
+    if _is_bf16_ptr(dY if isinstance(dY, int) else L.ptr(dY)) and not scalar_x:
+        raise RuntimeError("bf16 storage: this weight gradient is not eligible for the transposing-read kernels "
+                           "(Cout %d, sources %s, k%d s%d)" % (Cout, [s_.C for s_ in srcs], K, stride))
     if (PRECISION == 3 and K == 4 and stride == 2 and pad == 1 and not scalar_x and y_strides is None and cout_store == 0
             and Cin > 32 and Hl == 2 * Hs and Wl == 2 * Ws and isinstance(dW, torch.Tensor)
             and 2.0 * N * Hs * Ws * 16 * Cin * Cout >= WGRAD_BF16_MIN_FLOPS):
@@ -652,7 +724,12 @@ def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stri
         if ws is None:
             ws = _SCW_WS[dW.device] = torch.empty(SMALL_CIN_WGRAD_WS, dtype=torch.float32, device=dW.device)
         fn = "pg_stem_wgrad_bf16" if PRECISION == 3 and STEM_BF16 else "pg_small_cin_wgrad"
-        run = lambda: L.call(fn, arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, L.ptr(dW), L.ptr(ws), ws.numel(), L.stream())
+        if _is_bf16_ptr(dYp):
+            assert fn == "pg_stem_wgrad_bf16", "bf16 storage needs the bf16 first-layer kernels"
+            run = lambda: L.call("pg_stem_wgrad_bf16_ex", arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, 1, L.ptr(dW), L.ptr(ws),
+                                 ws.numel(), L.stream())
+        else:
+            run = lambda: L.call(fn, arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, L.ptr(dW), L.ptr(ws), ws.numel(), L.stream())
         if PROFILER is not None:
             PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
         else:
@@ -740,6 +817,18 @@ class NormState:
         if not self.shared:
             self.bsums.zero_()
         _debug_delay()
+        io = (1 if dz.dtype == torch.bfloat16 else 0) | (2 if y.dtype == torch.bfloat16 else 0)
+        if io:
+            # bf16 STORAGE: dz <- dy in place in bf16; the result is the operand of the layer's gradient contractions
+            L.call("pg_norm_bwd_reduce_ex", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), io, L.stream())
+            bf = None
+            if not (io & 1) and PRECISION == 3 and NORM_BWD_BF16 and _BF_CTX is not None and C > 0 and C % 64 == 0:
+                bf = _BF_CTX.reserve(L.ptr(dz), C, L.ACT_NONE, None, None, N * Lr, dz.device)
+            L.call("pg_norm_bwd_apply_io", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
+                   L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), io, L.stream())
+            if (io & 1) and _BF_CTX is not None and C > 0:
+                _BF_CTX.adopt(L.ptr(dz), C, L.ACT_NONE, None, None, dz)
+            return
         L.call("pg_norm_bwd_reduce", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), L.stream())
         bf = None
         if PRECISION == 3 and NORM_BWD_BF16 and _BF_CTX is not None and C > 0 and C % 64 == 0:
@@ -779,7 +868,7 @@ class GeneratorEngine:
     (src_baseline/models/networks.py:238-253) forward + backward for a fixed (N,H,W)."""
 
     def __init__(self, arena, N, H, W, pose_dim, nfilters_enc, nfilters_dec, deformable=True, align_corners=False,
-                 device="cuda", n_warps=T_WARPS, masked=True):
+                 device="cuda", n_warps=T_WARPS, masked=True, bf16_ok=True):
         # n_warps / masked: warp_skip='mask' -> 10 masked limb transforms; 'full' / 'none' -> ONE unmasked transform
         # (reference networks.py:283: AffineTransformLayer(10 if warp_skip == 'mask' else 1, ...))
         self.A, self.N, self.H, self.W, self.P = arena, N, H, W, pose_dim
@@ -791,18 +880,24 @@ class GeneratorEngine:
         self.encs = ("encoder_app", "encoder_pose") if deformable else ("encoder",)
         assert self.ndec == self.nlev
         f32 = dict(dtype=torch.float32, device=device)
+        # bf16 STORAGE (round 3): raw activations and their gradients as bf16 on the bf16 data path (first layers need the
+        # bf16 stem kernels: <= 80 input channels, 64 outputs)
+        cin_max = (3 + 2 * pose_dim) if not deformable else (3 + pose_dim)
+        self.bfs = bool(bf16_store() and bf16_ok and self.enc[0] == 64 and cin_max <= 80 and STEM_BF16 and torch.cuda.is_available())
+        act = dict(dtype=torch.bfloat16 if self.bfs else torch.float32, device=device)
+        A_ = lambda *shape: _reg_bf16(torch.empty(*shape, **act))
         hw = [(H >> l, W >> l) for l in range(self.nlev)]
         assert all(h << l == H and w << l == W for l, (h, w) in enumerate(hw)), "H,W must be divisible by 2^(levels-1)"
         self.hw = hw
         # encoder activations (raw), grads, norm state
-        self.e_raw = {e: [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nlev)] for e in self.encs}
-        self.e_dz = {e: [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nlev)] for e in self.encs}
+        self.e_raw = {e: [A_(N, hw[l][0], hw[l][1], self.enc[l]) for l in range(self.nlev)] for e in self.encs}
+        self.e_dz = {e: [A_(N, hw[l][0], hw[l][1], self.enc[l]) for l in range(self.nlev)] for e in self.encs}
         self.nscr = NormScratch(len(self.encs) * self.nlev + self.ndec, N, device)
         self.e_norm = {e: [NormState(N, device, self.nscr) if 0 < l < self.nlev - 1 else None for l in range(self.nlev)] for e in self.encs}
         # warped appearance skips (levels 0..3)
         self.nwarp = min(4, self.nlev) if deformable else 0
-        self.w_out = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nwarp)]
-        self.w_g = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], **f32) for l in range(self.nwarp)]
+        self.w_out = [A_(N, hw[l][0], hw[l][1], self.enc[l]) for l in range(self.nwarp)]     # bf16 STORAGE: relu(out)
+        self.w_g = [A_(N, hw[l][0], hw[l][1], self.enc[l]) for l in range(self.nwarp)]
         self.w_arg = [torch.empty(N, hw[l][0], hw[l][1], self.enc[l], dtype=torch.uint8, device=device) for l in range(self.nwarp)]
         self.lvl_masks = [(torch.empty if self.masked else torch.ones)(N, hw[l][0], hw[l][1], self.T, **f32)
                           for l in range(self.nwarp)]
@@ -810,15 +905,19 @@ class GeneratorEngine:
         self.d_raw, self.d_dz, self.d_norm = [], [], []
         for i in range(self.ndec - 1):
             h, w = hw[self.nlev - 2 - i]
-            self.d_raw.append(torch.empty(N, h, w, self.dec[i], **f32))
-            self.d_dz.append(torch.empty(N, h, w, self.dec[i], **f32))
+            self.d_raw.append(A_(N, h, w, self.dec[i]))
+            self.d_dz.append(A_(N, h, w, self.dec[i]))
             self.d_norm.append(NormState(N, device, self.nscr))
         self.drop = [torch.ones(N, self.dec[i], **f32) for i in range(min(3, self.ndec - 1))]
         self.out = torch.empty(N, 3, H, W, **f32)
         cin0 = {"encoder_app": 3 + pose_dim, "encoder_pose": pose_dim, "encoder": 3 + 2 * pose_dim}
         self.wt0 = {e: torch.empty(stem_pack_floats(3, cin0[e]), **f32) for e in self.encs}    # [Cin][9][64] repack of conv 0
-        self.y_taps = torch.empty(N, H, W, 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
+        self.y_taps = torch.empty(N, H, W, 64 if self.bfs else 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
+        cin_fin = (2 if deformable else 1) * self.enc[0] + self.dec[-2]
+        self.wt_fin = torch.zeros(64, cin_fin, **f32) if self.bfs else None    # bf16 STORAGE: weight padded to the 512 x 64 kernel
+        self.fin_ws = torch.empty(1024 * cin_fin * 28, **f32) if (self.bfs and cin_fin <= 256) else None
         self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh): weight- and data-gradient operand
+        self.g_taps64 = _reg_bf16(torch.empty(N, H, W, 64, dtype=torch.bfloat16, device=device)) if self.bfs else None
         self.wt_out = torch.zeros((2 if deformable else 1) * self.enc[0] + self.dec[-2], 32, **f32)   # [cin][(tap, co)]
         self.warps = torch.empty(N, max(self.T, 1), 8, **f32)
         self.input = None
@@ -910,9 +1009,20 @@ class GeneratorEngine:
                     L.call("pg_mask_pyramid", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W,
                            self.hw[l][0], self.hw[l][1], L.ptr(self.lvl_masks[l]), L.stream())
         # ---- encoders (reference networks.py:193-202)
+        bfs = self.bfs
+        assert bfs == (bf16_store() and bfs), "the engine was built for another storage mode (PRECISION changed?)"
+        npx = lambda l: self.hw[l][0] * self.hw[l][1]
         for e in self.encs:
             s0 = self._enc_in_src(e, inp)
-            if self.enc[0] == 64:
+            if bfs:
+                # level 0 has no norm: the stem writes the raw tensor and the operand(s) of its readers in one pass — the next
+                # encoder level (LeakyReLU) and, unless the skip is warped first, the decoder (ReLU)
+                r0 = self.e_raw[e][0]
+                outs = [(L.ACT_LEAKY, _BF_CTX.reserve(L.ptr(r0), 64, L.ACT_LEAKY, None, None, r0.numel(), r0.device))]
+                if not (self.deformable and e == "encoder_app" and self.nwarp > 0):
+                    outs.append((L.ACT_RELU, _BF_CTX.reserve(L.ptr(r0), 64, L.ACT_RELU, None, None, r0.numel(), r0.device)))
+                _stem_conv_stored([s0], N, H, W, 3, 1, 1, A.p(e + ".net.0.weight"), A.p(e + ".net.0.bias"), self.wt0[e], r0, outs)
+            elif self.enc[0] == 64:
                 _small_cin_conv([s0], N, H, W, 3, 1, 1, A.p(e + ".net.0.weight"), A.p(e + ".net.0.bias"), self.wt0[e],
                                 self.e_raw[e][0], next_act=L.ACT_LEAKY)
             else:
@@ -922,7 +1032,11 @@ class GeneratorEngine:
                 hi, wi = self.hw[l - 1]
                 ho, wo = self.hw[l]
                 has_norm = l < self.nlev - 1
-                _conv([self._enc_act(e, l - 1).src()], N, hi, wi, L.ACT_LEAKY, 0, 4, 2, 1, ho, wo,
+                xin = self._enc_act(e, l - 1)
+                if bfs and l - 1 >= 1 and not (self.deformable and e == "encoder_app" and l - 1 < self.nwarp):
+                    # skip l-1 is read twice with different activations: both operands in one pass over the raw tensor
+                    _BF_CTX.get2(L.ptr(xin.t), xin.C, L.ACT_LEAKY, L.ACT_RELU, L.ptr(xin.aff), None, N, npx(l - 1), xin.t.device)
+                _conv([xin.src()], N, hi, wi, L.ACT_LEAKY, 0, 4, 2, 1, ho, wo,
                       A.p("%s.net.%d.net.1.weight" % (e, l)), self.enc[l], self.enc[l - 1], out=self.e_raw[e][l],
                       stats=self.e_norm[e][l].stats_target() if has_norm else None)
                 if has_norm:
@@ -932,6 +1046,12 @@ class GeneratorEngine:
         # ---- deformable skips (reference networks.py:279-288, utils/pose_transform.py:69-92)
         for l in range(self.nwarp):
             a = self._enc_act("encoder_app", l)
+            if bfs:     # bf16 in, relu(out) bf16 out: the stored tensor IS the decoder's operand (and its ReLU-derivative input)
+                L.call("pg_warp_mask_max_fwd_io", L.ptr(a.t), L.ptr(a.aff), L.ptr(self.warps), L.ptr(self.lvl_masks[l]), N,
+                       self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.w_out[l]),
+                       L.ptr(self.w_arg[l]), 7, L.stream())
+                _BF_CTX.adopt(L.ptr(self.w_out[l]), self.enc[l], L.ACT_RELU, None, None, self.w_out[l])
+                continue
             L.call("pg_warp_mask_max_fwd", L.ptr(a.t), L.ptr(a.aff), L.ptr(self.warps), L.ptr(self.lvl_masks[l]), N,
                    self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.w_out[l]),
                    L.ptr(self.w_arg[l]), L.stream())
@@ -951,6 +1071,14 @@ class GeneratorEngine:
         cin = sum(a.C for _, _, a in srcs)
         # 256->3 output conv (networks.py:228) re-associated: 1x1 conv to 27 = 9 taps x 3 channels, then tap gather
         # + bias + tanh (csrc/edge.hip) — a 3-wide GEMM-N would leave 29/32 of every MFMA tile empty
+        if bfs:
+            # bf16 STORAGE: the three sources are bf16 operands already (normalised block output, relu'd warp, the stem's
+            # ReLU copy); the 27 tap columns are padded to the 64-column tile of the bf16 kernels
+            self.wt_fin[:27].copy_(A.p("decoder.net.%d.weight" % (i + 1)).view(27, cin))
+            _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W, self.wt_fin, 64, cin, out=self.y_taps)
+            L.call("pg_tap_gather_pitch", L.ptr(self.y_taps), 64, N, H, W, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
+                   L.OUT_TANH, L.ptr(self.out), 3 * H * W, H * W, W, 1, L.stream())
+            return self.out
         _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W,
               A.p("decoder.net.%d.weight" % (i + 1)), 27, cin, out=self.y_taps)
         L.call("pg_tap_gather", L.ptr(self.y_taps), N, H, W, 3, 3, 1, 3, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
@@ -998,8 +1126,36 @@ class GeneratorEngine:
         _debug_delay()
         L.call("pg_bias_grad", L.ptr(dpre), N, H * W, 3, 3 * H * W, 1, H * W, L.ptr(A.g("decoder.net.%d.bias" % (i + 1))),
                L.stream())
-        L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
-               L.ptr(self.g_taps), L.stream())
+        if not self.bfs:
+            L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
+                   L.ptr(self.g_taps), L.stream())
+        if self.bfs:
+            # bf16 STORAGE: the im2col'd gradient is written as a bf16 [pixel][64] operand.  Weight gradient: one streaming
+            # pass over it and the ACTIVATED bf16 operands of the forward pass (csrc/out_conv_dgrad.hip); data gradient: a
+            # K = 64 bf16 contraction with the zero-padded weight of the forward pass, scattered with relu' like every other
+            # data gradient (the fp32 streaming kernel was VALU-bound: 0.9 ms at batch 32).
+            L.call("pg_im2col_taps_bf16", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 64,
+                   L.ptr(self.g_taps64), L.stream())
+            xs = []
+            for kind, idx, a in srcs:
+                xop = self._bf_fwd.lookup(L.ptr(a.t), a.C, L.ACT_RELU, L.ptr(a.aff), L.ptr(a.mask))
+                assert xop is not None, "forward operand of the output convolution is not in the pass cache"
+                xs.append(L.make_dst(None, a.C, fwd=xop.reshape(-1)[:a.t.numel()].view(a.t.shape), act=L.ACT_RELU))
+            arr = (L.Dst * len(xs))(*xs)
+            side = _side_stream() if SIDE_STREAM else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                L.call("pg_out_conv_wgrad_bf16", L.ptr(self.g_taps64), 64, N, H, W, arr, len(xs), L.ptr(A.g(wkey)),
+                       L.ptr(self.fin_ws), self.fin_ws.numel(), L.stream())
+            self._ready("decoder.net.%d." % (i + 1))
+            _conv_dgrad(Act(self.g_taps64, 64).src(), N, H, W, 0, 1, 1, 0, H, W, self.wt_fin, 64, cin, self._dsts_for(srcs, True))
+        else:
+            self._backward_final_fp32(srcs, cin, wkey, i)
+        self._backward_rest(image_grad)
+
+    def _backward_final_fp32(self, srcs, cin, wkey, i):
+        A, N, H, W = self.A, self.N, self.H, self.W
         _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, self.g_taps, 32, cin, True, H, W, H, W, 1, 1, 0, A.g(wkey),
                cout_store=27)
         self._ready("decoder.net.%d." % (i + 1))
@@ -1012,6 +1168,9 @@ class GeneratorEngine:
             L.call("pg_out_conv_dgrad", L.ptr(self.g_taps), L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.stream())
         else:
             _conv([Act(self.g_taps, 32).src()], N, H, W, L.ACT_NONE, 0, 1, 1, 0, H, W, self.wt_out, cin, 32, dsts=dsts)
+
+    def _backward_rest(self, image_grad=None):
+        A, N, H, W = self.A, self.N, self.H, self.W
         # ---- up blocks
         for i in range(self.ndec - 2, -1, -1):
             srcs = self._dec_sources(i)
@@ -1030,6 +1189,11 @@ class GeneratorEngine:
                         self._dsts_for(srcs, True))
         # ---- deformable skips
         for l in range(self.nwarp):
+            if self.bfs:
+                L.call("pg_warp_mask_max_bwd_io", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
+                       L.ptr(self.lvl_masks[l]), N, self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align,
+                       L.ptr(self.e_dz["encoder_app"][l]), 3, L.stream())
+                continue
             L.call("pg_warp_mask_max_bwd", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
                    L.ptr(self.lvl_masks[l]), N, self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align,
                    L.ptr(self.e_dz["encoder_app"][l]), L.stream())
@@ -1056,8 +1220,12 @@ class GeneratorEngine:
             dz = self.e_dz[e][0]
             s0 = self._enc_in_src(e, self.input)
             _debug_delay()
-            L.call("pg_bias_grad", L.ptr(dz), N * H * W, 1, self.enc[0], self.enc[0], 0, 1,
-                   L.ptr(A.g(e + ".net.0.bias")), L.stream())
+            if self.bfs:
+                assert image_grad is None, "bf16 storage: the chained (stacked) generator keeps fp32 storage"
+                L.call("pg_bias_grad_bf16", L.ptr(dz), N * H * W, self.enc[0], L.ptr(A.g(e + ".net.0.bias")), L.stream())
+            else:
+                L.call("pg_bias_grad", L.ptr(dz), N * H * W, 1, self.enc[0], self.enc[0], 0, 1,
+                       L.ptr(A.g(e + ".net.0.bias")), L.stream())
             _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
                    A.g(e + ".net.0.weight"), scalar_x=True)
             self._ready(e + ".net.0.")

@@ -26,7 +26,7 @@ class Src(C.Structure):
 
 class Dst(C.Structure):
     _fields_ = [("grad", C.c_void_p), ("fwd", C.c_void_p), ("aff", C.c_void_p), ("mask", C.c_void_p),
-                ("C", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+                ("C", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("flags", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
                 ("out", C.c_void_p), ("bias", C.c_void_p),
                 ("oN", C.c_int64), ("oC", C.c_int64), ("oH", C.c_int64), ("oW", C.c_int64),
                 ("dst", Dst * PG_MAX_SRC),
-                ("ndst", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32), ("reserved0", C.c_int32),
+                ("ndst", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32), ("out_bf16", C.c_int32),
                 ("stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
@@ -121,6 +121,18 @@ _PROTOS = {
     "pg_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
     "pg_event_destroy": [_vp],
     "pg_debug_spin": [_i32, _vp],
+    "pg_materialise_bf16_ex": [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp],
+    "pg_norm_bwd_reduce_ex": [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp],
+    "pg_norm_bwd_apply_io": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
+    "pg_warp_mask_max_fwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
+    "pg_warp_mask_max_bwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "pg_stem_conv_bf16_v3": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp],
+    "pg_stem_wgrad_bf16_ex": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
+    "pg_bias_grad_bf16": [_vp, _i64, _i32, _vp, _vp],
+    "pg_tap_gather_pitch": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
+    "pg_im2col_taps_bf16": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pg_out_conv_wgrad_bf16": [_vp, _i32, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp],
+    "pg_out_conv_dgrad_wgrad": [_vp, _vp, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp],
     "pg_version": [],
     "pg_last_launch_info": [],
 }
@@ -200,8 +212,16 @@ def make_src(t, C_, aff=None, mask=None, strides=None):
     return s
 
 
+DST_GRAD_BF16, DST_FWD_BF16 = 1, 2
+
+
 def make_dst(grad, C_, fwd=None, aff=None, mask=None, act=ACT_NONE, accumulate=False):
+    """grad / fwd may be fp32 or bf16 tensors (bf16 STORAGE on the bf16 data path): the dtype travels in Dst.flags."""
     d = Dst()
+    if grad is not None and torch.is_tensor(grad) and grad.dtype == torch.bfloat16:
+        d.flags |= DST_GRAD_BF16
+    if fwd is not None and torch.is_tensor(fwd) and fwd.dtype == torch.bfloat16:
+        d.flags |= DST_FWD_BF16
     d.grad = ptr(grad)
     d.fwd = ptr(fwd)
     d.aff = ptr(aff)

@@ -91,6 +91,61 @@ def test_bf16_data_path_contractions_at_north_star_shapes(case, monkeypatch):
     assert rel(dw, dw_ref) < 2e-3, (case.name, float(rel(dw, dw_ref)))
 
 
+# ------------------------------------------------------------------------------------------ four-tap weight gradient
+def wgrad_tr4_cases():
+    A, M = True, True
+    return [
+        # Conv2d (x on the large grid): encoder level 1 shape (64 -> 128), 128 -> 128, and a 64-channel dY
+        ConvCase("w4_conv_x64_128", "conv", [(64, False, False)], 128, 1, 128, 128, 4, 2, 1, L.ACT_LEAKY, seed=71),
+        ConvCase("w4_conv_128_128_rect", "conv", [(128, A, False)], 128, 2, 128, 256, 4, 2, 1, L.ACT_LEAKY, seed=72),
+        ConvCase("w4_conv_128_y64", "conv", [(128, A, False)], 64, 1, 128, 128, 4, 2, 1, L.ACT_LEAKY, seed=73),
+        ConvCase("w4_conv_128_256", "conv", [(128, A, False)], 256, 1, 128, 128, 4, 2, 1, L.ACT_LEAKY, seed=74),
+        # ConvTranspose2d + crop (dY on the large grid): the last decoder block's shape (three sources, 128 outputs),
+        # a 64-channel source
+        ConvCase("w4_up_3src_128", "convT", [(256, A, M), (128, False, False), (128, A, False)], 128, 1, 64, 64, 4, 2, 1,
+                 L.ACT_RELU, seed=75),
+        ConvCase("w4_up_x64_128", "convT", [(64, A, False)], 128, 2, 64, 128, 4, 2, 1, L.ACT_RELU, seed=76),
+    ]
+
+
+@pytest.mark.parametrize("case", wgrad_tr4_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
+def test_weight_gradient_bf16_four_taps(case, monkeypatch):
+    """wgrad_bf16_tr4_kernel (csrc/wgrad_bf16.hip, round 3): four taps of a filter row per workgroup, the 130-pixel large
+    patch de-interleaved into even / odd column planes, three LDS stages.  Power-of-two maps with >= 64 small-grid columns
+    (the thin full-resolution layers).  Against torch autograd on the bf16-ROUNDED operands, and against the one-tap kernel
+    (PG_WGTR4=0 is read once per process, so the comparison kernel is called through its explicit-split entry)."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setattr(E, "WGRAD_BF16_MIN_FLOPS", 0.0)
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    xs = []
+    for j in range(len(case.srcs)):
+        z = case.raw[j]
+        if case.aff[j] is not None:
+            z = torch.addcmul(case.aff[j][:, 1].view(-1, 1, 1, 1), z, case.aff[j][:, 0].view(-1, 1, 1, 1))
+        if case.mask[j] is not None:
+            z = z * case.mask[j].view(case.N, -1, 1, 1)
+        xs.append(bf(act_fn(z, case.act)))
+    x = torch.cat(xs, 1)
+    w = case.w.clone().requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=2, padding=1) if case.kind == "conv" else F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:-1, 1:-1]
+    ref = torch.autograd.grad((y * bf(case.gout)).sum(), w)[0]
+    got = case.run_wgrad()
+    info = L.load().pg_last_launch_info()
+    assert (info & 15) == 6 and (info & (1 << 30)), hex(info)
+    assert rel(got, ref) < 1e-4, (case.name, float(rel(got, ref)))
+    # accumulation into a non-zero dW through the C entry point, against the one-tap kernel (explicit ksplit -> old kernel)
+    conv = case.kind == "conv"
+    Hs, Ws = (case.Ho, case.Wo) if conv else (case.H, case.W)
+    xb = nhwc(x).to(DEV).to(torch.bfloat16).contiguous()
+    gb = nhwc(bf(case.gout)).to(DEV).to(torch.bfloat16).contiguous()
+    d4 = torch.full((4, 4, case.cout, case.cin), 0.25, device=DEV)
+    d1 = torch.full((4, 4, case.cout, case.cin), 0.25, device=DEV)
+    L.call("pg_wgrad_bf16", L.ptr(xb), case.cin, L.ptr(gb), case.cout, 1 if conv else 0, case.N, Hs, Ws, L.ptr(d4), case.cin, 0, 0, L.stream())
+    L.call("pg_wgrad_bf16", L.ptr(xb), case.cin, L.ptr(gb), case.cout, 1 if conv else 0, case.N, Hs, Ws, L.ptr(d1), case.cin, 0, 2, L.stream())
+    torch.cuda.synchronize()
+    assert rel(d4 - 0.25, d1 - 0.25) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------ configs[3] ops at 256 x 256
 @pytest.mark.parametrize("a", [3, 5])
 def test_nn_loss_at_256(a):
