@@ -102,7 +102,30 @@ def test_generator_224_p32_vs_golden(prec, monkeypatch):
 
 
 # step tolerances vs the REFERENCE capture: (loss rtol, out_gen max-abs, gradient summary / tensor max)
-STEP_TOL = {"f32": (1e-4, 1e-3, 2e-3), "bf16x3": (1e-3, 1e-3, 1e-2), "bf16_data": (3e-2, 0.3, None)}
+STEP_TOL = {"f32": (1e-4, 1e-3, 2e-3), "bf16x3": (1e-3, 1e-3, 1e-2), "bf16_data": (3e-2, 0.3, "study")}
+# Gradient tolerance of the bf16 data path vs the REFERENCE capture, from the tolerance study
+# profiles/round3_bf16_gradient_tolerance.txt (tools: PG_TOL_STUDY=1 pytest -s -k p32_step): per parameter tensor, the largest
+# deviation of (max |g|, 32 strided samples) from the reference, relative to the tensor's largest gradient.  Measured worst
+# case 0.118 (step_l1, bf16 storage) / 0.107 (fp32 storage) / 0.077 (P = 32); stated tolerance BF16_GRAD_TOL = 0.2.  Scalar
+# norm gamma / beta gradients are skipped as in the fp32 tests (their samples are one value; BF16_GRAD_TOL_SCALAR is unused).
+BF16_GRAD_TOL, BF16_GRAD_TOL_SCALAR = 0.2, 0.6
+
+
+def _check_grads(grads, fix, prefix, gt_, tag):
+    study = os.environ.get("PG_TOL_STUDY") == "1"
+    worst = {}
+    for k, g in grads.items():
+        ref = fix[prefix + k]
+        if np.all(ref[3:] == ref[3]):
+            continue
+        ratio = float(np.abs(_summ(g)[2:] - ref[2:]).max() / max(ref[2], 1e-12))
+        scalar = g.numel() == 1
+        tol = gt_ if gt_ != "study" else (BF16_GRAD_TOL_SCALAR if scalar else BF16_GRAD_TOL)
+        worst[k] = (ratio, tol)
+        if study:
+            print("TOLSTUDY %s %s%s numel=%d ratio=%.4f" % (tag, prefix, k, g.numel(), ratio))
+    bad = {k: v for k, v in worst.items() if v[0] > v[1]}
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16_data"])
@@ -125,21 +148,13 @@ def test_p32_step_vs_golden(prec, monkeypatch):
     dC = dev(*[t(m) for m in synth.dropout_masks(63, "p32/step/dC", N)])
     dl = model.dis_update(bA[0], bA[1], {"warps": bA[2], "masks": bA[3], "drop_masks": dA}, bB[0], bB[1], od)
     np.testing.assert_allclose(dl, fix["step_dis_losses"], rtol=rt, atol=max(LOSS_ATOL, rt))
-    if gt_ is not None:
-        for k, g in model.disc.arena.grad_dict().items():
-            ref = fix["step_dgrad_" + k]
-            if not np.all(ref[3:] == ref[3]):
-                assert np.abs(_summ(g)[2:] - ref[2:]).max() <= gt_ * max(ref[2], 1e-12), k
+    _check_grads(model.disc.arena.grad_dict(), fix, "step_dgrad_", gt_, "p32/" + prec)
     og, _, gl = model.gen_update(bC[0], bC[1], {"warps": bC[2], "masks": bC[3], "drop_masks": dC}, od)
     np.testing.assert_allclose(gl, fix["step_gen_losses"], rtol=rt, atol=max(LOSS_ATOL, rt))
     assert maxdiff(og, t(fix["step_out_gen"])) < ot
     if prec == "bf16_data":
         assert float((og.cpu() - t(fix["step_out_gen"])).abs().mean()) < 2.6e-2
-    if gt_ is not None:
-        for k, g in model.gen.arena.grad_dict().items():
-            ref = fix["step_ggrad_" + k]
-            if not np.all(ref[3:] == ref[3]):
-                assert np.abs(_summ(g)[2:] - ref[2:]).max() <= gt_ * max(ref[2], 1e-12), k
+    _check_grads(model.gen.arena.grad_dict(), fix, "step_ggrad_", gt_, "p32/" + prec)
 
 
 def _property_step(H, W, P, N, prec, monkeypatch):

@@ -230,3 +230,40 @@ def test_reducer_stream_order_under_main_stream_delay(tmp_path):
     broken = _dp(tmp_path, dict(base, PG_DP_DEBUG_NO_WAIT="1"))
     worst = max(float((broken[k] - ref[k]).abs().max()) / float(ref[k].abs().max()) for k in ("gen_grads", "disc_grads"))
     assert worst > 1e-2, "negative control: reducing without producer events went unnoticed (%.2e)" % worst
+
+
+# ------------------------------------------------------------------------------------------ bf16 data path vs the reference
+@pytest.mark.parametrize("store", ["bf16_storage", "fp32_storage"])
+def test_bf16_data_step_l1_gradients_vs_golden(store, monkeypatch):
+    """the gradients of the bf16 data path — the path every bf16 throughput figure is quoted on —
+    against the REFERENCE capture (tests/golden/step_l1.npz: dis_update + gen_update, 64 x 64, P = 18), not against the
+    build's own fp32 path.  Both storage modes of the path (round 3: bf16 STORAGE of activations / gradients in the
+    generator; round 2: fp32 storage).  Tolerances from the study in profiles/round3_bf16_gradient_tolerance.txt."""
+    from types import SimpleNamespace
+    from test_gpu_round2 import BF16_GRAD_TOL, BF16_GRAD_TOL_SCALAR, _check_grads, tp, dev
+    from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
+    from conftest import GOLDEN
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setattr(E, "BF16_STORE", store == "bf16_storage")
+    fix = np.load(os.path.join(GOLDEN, "step_l1.npz"))
+    P, H, W, N, name = 18, 64, 64, 2, "step_l1"
+    enc, dec = synth.nfilters((H, W))
+    opt = SimpleNamespace(image_size=(H, W), use_input_pose=True, pose_dim=P, batch_size=N, num_stacks=4, gen_type="baseline",
+                          dataset="fasion", warp_skip="mask", learning_rate=2e-4, content_loss_layer="none",
+                          nn_loss_area_size=1, gan_penalty_weight=1.0, l1_penalty_weight=100.0)
+    model = DeformablePose_GAN(opt, device=DEV)
+    model.gen.load_state_dict(tp(synth.init_params(31, name + "/gen", synth.generator_spec(P, enc, dec), 0.1)))
+    model.disc.load_state_dict(tp(synth.init_params(31, name + "/disc", synth.discriminator_spec(42), 0.1)))
+    assert model.gen.engine(N).bfs == (store == "bf16_storage")
+    od = vars(opt)
+    bA, bB, bC = [dev(*[t(a) for a in synth.batch(31, "%s/it0/%s" % (name, s), N, P, H, W)]) for s in "ABC"]
+    dA = dev(*[t(m) for m in synth.dropout_masks(31, "%s/it0/dA" % name, N)])
+    dC = dev(*[t(m) for m in synth.dropout_masks(31, "%s/it0/dC" % name, N)])
+    dl = model.dis_update(bA[0], bA[1], {"warps": bA[2], "masks": bA[3], "drop_masks": dA}, bB[0], bB[1], od)
+    np.testing.assert_allclose(dl, fix["it0_dis_losses"], rtol=3e-2, atol=3e-2)
+    _check_grads(model.disc.arena.grad_dict(), fix, "it0_dgrad_", "study", "step_l1/" + store)
+    og, _, gl = model.gen_update(bC[0], bC[1], {"warps": bC[2], "masks": bC[3], "drop_masks": dC}, od)
+    np.testing.assert_allclose(gl, fix["it0_gen_losses"], rtol=3e-2, atol=3e-2)
+    d = (og.cpu() - t(fix["it0_out_gen"])).abs()
+    assert float(d.max()) < 0.3 and float(d.mean()) < 2.6e-2, (float(d.max()), float(d.mean()))
+    _check_grads(model.gen.arena.grad_dict(), fix, "it0_ggrad_", "study", "step_l1/" + store)
