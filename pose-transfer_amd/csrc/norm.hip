@@ -60,26 +60,28 @@ __device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {      // 
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
-// 4 consecutive elements of an fp32 (T = float) or bf16 (T = unsigned short: bf16 STORAGE, round 3) tensor
+// One 16-byte chunk of an fp32 (T = float: 4 elements) or bf16 (T = unsigned short: 8 elements; bf16 STORAGE, round 3) tensor
+template <typename T> struct Chunk { static constexpr int N = 16 / (int)sizeof(T); };
 template <typename T>
-__device__ __forceinline__ float4 ld4(const T* base, long i4) {
+__device__ __forceinline__ void ldc(const T* base, long ic, float (&v)[Chunk<T>::N]) {
+  const uint4 u = reinterpret_cast<const uint4*>(base)[ic];
   if constexpr (sizeof(T) == 4) {
-    return reinterpret_cast<const float4*>(base)[i4];
+    v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
   } else {
-    const uint2 u = reinterpret_cast<const uint2*>(base)[i4];
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                       __uint_as_float(u.y & 0xffff0000u));
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
   }
 }
 template <typename T>
-__device__ __forceinline__ void st4(T* base, long i4, float4 v) {
+__device__ __forceinline__ void stc(T* base, long ic, const float (&v)[Chunk<T>::N]) {
+  uint4 u;
   if constexpr (sizeof(T) == 4) {
-    reinterpret_cast<float4*>(base)[i4] = v;
+    u = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
   } else {
-    uint2 u;
-    u.x = pack_bf16_rne(v.x, v.y); u.y = pack_bf16_rne(v.z, v.w);
-    reinterpret_cast<uint2*>(base)[i4] = u;
+    u = make_uint4(pack_bf16_rne(v[0], v[1]), pack_bf16_rne(v[2], v[3]), pack_bf16_rne(v[4], v[5]), pack_bf16_rne(v[6], v[7]));
   }
+  reinterpret_cast<uint4*>(base)[ic] = u;
 }
 template <typename T>
 __device__ __forceinline__ float ld1(const T* base, long i) {
@@ -87,41 +89,37 @@ __device__ __forceinline__ float ld1(const T* base, long i) {
   else return __uint_as_float((unsigned)base[i] << 16);
 }
 
-template <typename TD, typename TY>
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const TD* dz, const TY* y, const float* mr, long L,
+// dz and y share the storage type (fp32 or bf16): every lane moves 16-byte chunks of both
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* dz, const T* y, const float* mr, long L,
                                                               double* bsums) {
+  constexpr int V = Chunk<T>::N;
   __shared__ double red[8];
   const int n = blockIdx.y;
   const float mean = mr[2 * n], rstd = mr[2 * n + 1];
-  const TD* bd = dz + (long)n * L;
-  const TY* by = y + (long)n * L;
+  const T* bd = dz + (long)n * L;
+  const T* by = y + (long)n * L;
   float s = 0.f, q = 0.f;
-  const long L4 = L >> 2;
+  const long LC = L / V;
   const long stride = (long)gridDim.x * 256;
   long i = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < L4; i += 4 * stride) {           // eight independent loads in flight per lane
-    float4 d[4], v[4];
+  for (; i + 3 * stride < LC; i += 4 * stride) {           // eight independent 16-byte loads in flight per lane
+    float d[4][V], v[4][V];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      d[u] = ld4(bd, i + u * stride);
-      v[u] = ld4(by, i + u * stride);
-    }
+    for (int u = 0; u < 4; ++u) { ldc(bd, i + u * stride, d[u]); ldc(by, i + u * stride, v[u]); }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      s += (d[u].x + d[u].y) + (d[u].z + d[u].w);
-      q += (d[u].x * ((v[u].x - mean) * rstd) + d[u].y * ((v[u].y - mean) * rstd)) +
-           (d[u].z * ((v[u].z - mean) * rstd) + d[u].w * ((v[u].w - mean) * rstd));
-    }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < V; ++e) { s += d[u][e]; q += d[u][e] * ((v[u][e] - mean) * rstd); }
   }
-  for (; i < L4; i += stride) {
-    const float4 d = ld4(bd, i);
-    const float4 v = ld4(by, i);
-    s += (d.x + d.y) + (d.z + d.w);
-    q += (d.x * ((v.x - mean) * rstd) + d.y * ((v.y - mean) * rstd)) +
-         (d.z * ((v.z - mean) * rstd) + d.w * ((v.w - mean) * rstd));
+  for (; i < LC; i += stride) {
+    float d[V], v[V];
+    ldc(bd, i, d); ldc(by, i, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s += d[e]; q += d[e] * ((v[e] - mean) * rstd); }
   }
   if (blockIdx.x == 0)
-    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) { s += ld1(bd, i); q += ld1(bd, i) * ((ld1(by, i) - mean) * rstd); }
+    for (long i = LC * V + threadIdx.x; i < L; i += 256) { s += ld1(bd, i); q += ld1(bd, i) * ((ld1(by, i) - mean) * rstd); }
   double ds = wave_sum_d((double)s), dq = wave_sum_d((double)q);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) { red[w] = ds; red[4 + w] = dq; }
@@ -132,39 +130,40 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const TD* dz, cons
   }
 }
 
-template <typename TD, typename TY>
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(TD* dz, const TY* y, const float* mr,
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(T* dz, const T* y, const float* mr,
                                                              const double* bsums, const float* gamma, int N, long L,
                                                              float* dgamma, float* dbeta, unsigned short* dy_bf16) {
+  constexpr int V = Chunk<T>::N;
   const int n = blockIdx.y;
   const float mean = mr[2 * n], rstd = mr[2 * n + 1];
   const float g = gamma[0];
   const float m1 = (float)(bsums[2 * n] / (double)L);
   const float m2 = (float)(bsums[2 * n + 1] / (double)L);
   const float k = g * rstd;
-  TD* bd = dz + (long)n * L;
-  const TY* by = y + (long)n * L;
-  const long L4 = L >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L4; i += (long)gridDim.x * 256) {
-    float4 d = ld4(bd, i);
-    const float4 v = ld4(by, i);
-    d.x = k * (d.x - m1 - ((v.x - mean) * rstd) * m2);
-    d.y = k * (d.y - m1 - ((v.y - mean) * rstd) * m2);
-    d.z = k * (d.z - m1 - ((v.z - mean) * rstd) * m2);
-    d.w = k * (d.w - m1 - ((v.w - mean) * rstd) * m2);
-    st4(bd, i, d);
-    if (dy_bf16) {           // the bf16 operand copy the data- / weight-gradient contractions read (bf16 data path)
-      uint2 pk;
-      pk.x = pack_bf16_rne(d.x, d.y); pk.y = pack_bf16_rne(d.z, d.w);
-      reinterpret_cast<uint2*>(dy_bf16 + (long)n * L)[i] = pk;
+  T* bd = dz + (long)n * L;
+  const T* by = y + (long)n * L;
+  const long LC = L / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < LC; i += (long)gridDim.x * 256) {
+    float d[V], v[V];
+    ldc(bd, i, d); ldc(by, i, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) d[e] = k * (d[e] - m1 - ((v[e] - mean) * rstd) * m2);
+    stc(bd, i, d);
+    if constexpr (sizeof(T) == 4) {
+      if (dy_bf16) {         // the bf16 operand copy the data- / weight-gradient contractions read (fp32 storage on the bf16 data path)
+        uint2 pk;
+        pk.x = pack_bf16_rne(d[0], d[1]); pk.y = pack_bf16_rne(d[2], d[3]);
+        reinterpret_cast<uint2*>(dy_bf16 + (long)n * L)[i] = pk;
+      }
     }
   }
   if (blockIdx.x == 0)
-    for (long i = (L4 << 2) + threadIdx.x; i < L; i += 256) {
+    for (long i = LC * V + threadIdx.x; i < L; i += 256) {
       const float r = k * (ld1(bd, i) - m1 - ((ld1(by, i) - mean) * rstd) * m2);
-      if constexpr (sizeof(TD) == 4) bd[i] = r;
+      if constexpr (sizeof(T) == 4) bd[i] = r;
       else bd[i] = (unsigned short)(pack_bf16_rne(r, 0.f) & 0xffffu);
-      if (dy_bf16) dy_bf16[(long)n * L + i] = (unsigned short)(pack_bf16_rne(r, 0.f) & 0xffffu);
+      if (sizeof(T) == 4 && dy_bf16) dy_bf16[(long)n * L + i] = (unsigned short)(pack_bf16_rne(r, 0.f) & 0xffffu);
     }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     double sg = 0.0, sb = 0.0;
@@ -176,20 +175,20 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(TD* dz, const TY* y
 
 // norm_bwd_reduce ends every workgroup with two double atomics on ONE 64-byte line (bsums [N][2]); same-address
 // atomics serialise (measured on the bias gradient: ~90 ns per workgroup), so that kernel gets few, deep workgroups
-static int norm_blocks_bwd(long L, int N) {
-  long b = (L / 4 + 256 * 16 - 1) / (256 * 16);
+static int norm_blocks_bwd(long L, int N, int vec = 4) {
+  long b = (L / vec + 256 * 16 - 1) / (256 * 16);
   const long cap = N >= 4 ? 64 : N == 3 ? 96 : N == 2 ? 128 : 256;
   if (b < 1) b = 1;
   if (b > cap) b = cap;
   return (int)b;
 }
 
-static int norm_blocks(long L) {
+static int norm_blocks(long L, int vec = 4) {
   // streaming passes on this chip prefer MANY workgroups with one 16-byte chunk per lane over few deep ones (swept at batch
   // 32: 8 chunks per lane / 512 workgroups per sample 2.04 ms, 1 / 8192: 1.87 ms for the norm-backward apply passes of a step)
   static const int per = getenv("PG_NORM_PER") ? atoi(getenv("PG_NORM_PER")) : 1;
   static const int cap = getenv("PG_NORM_CAP") ? atoi(getenv("PG_NORM_CAP")) : 8192;
-  long b = (L / 4 + 256 * per - 1) / (256 * per);
+  long b = (L / vec + 256 * per - 1) / (256 * per);
   if (b < 1) b = 1;
   if (b > cap) b = cap;
   return (int)b;
@@ -216,19 +215,17 @@ extern "C" int pg_norm_finalize(const double* sums, const float* gamma, const fl
   return 0;
 }
 
-// io_flags: bit 0 = dz is bf16, bit 1 = y is bf16 (bf16 STORAGE on the bf16 data path; sums stay double)
+// io_flags: 0 = dz and y fp32, 3 = both bf16 (bf16 STORAGE on the bf16 data path; sums stay double)
 extern "C" int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float* mr, int32_t N, int64_t L, double* bsums,
                                      int32_t io_flags, void* stream) {
-  PG_REQUIRE(dz && y && mr && bsums && N > 0 && L > 0 && L % 4 == 0 && io_flags >= 0 && io_flags <= 3, "pg_norm_bwd_reduce: bad arguments");
-  const dim3 grid(norm_blocks_bwd(L, N), N);
+  PG_REQUIRE(dz && y && mr && bsums && N > 0 && L > 0 && ((io_flags == 0 && L % 4 == 0) || (io_flags == 3 && L % 8 == 0)),
+             "pg_norm_bwd_reduce: bad arguments (dz and y share the storage type; L %% 4 == 0 fp32 / L %% 8 == 0 bf16)");
   typedef unsigned short bf;
   hipStream_t st = (hipStream_t)stream;
-  switch (io_flags) {
-    case 0: hipLaunchKernelGGL((norm_bwd_reduce_kernel<float, float>), grid, dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums); break;
-    case 1: hipLaunchKernelGGL((norm_bwd_reduce_kernel<bf, float>), grid, dim3(256), 0, st, (const bf*)dz, (const float*)y, mr, (long)L, bsums); break;
-    case 2: hipLaunchKernelGGL((norm_bwd_reduce_kernel<float, bf>), grid, dim3(256), 0, st, (const float*)dz, (const bf*)y, mr, (long)L, bsums); break;
-    default: hipLaunchKernelGGL((norm_bwd_reduce_kernel<bf, bf>), grid, dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums); break;
-  }
+  if (io_flags == 0)
+    hipLaunchKernelGGL((norm_bwd_reduce_kernel<float>), dim3(norm_blocks_bwd(L, N, 4), N), dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums);
+  else
+    hipLaunchKernelGGL((norm_bwd_reduce_kernel<bf>), dim3(norm_blocks_bwd(L, N, 8), N), dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums);
   PG_LAUNCH_OK("pg_norm_bwd_reduce");
   return 0;
 }
@@ -237,21 +234,19 @@ extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* 
   return pg_norm_bwd_reduce_ex(dz, y, mr, N, L, bsums, 0, stream);
 }
 
-// io_flags as in pg_norm_bwd_reduce_ex; with a bf16 dz the in-place result IS the bf16 operand of the layer's gradient
-// contractions (dy_bf16 = NULL then)
+// io_flags as in pg_norm_bwd_reduce_ex; with bf16 storage the in-place result IS the bf16 operand of the layer's gradient
+// contractions (dy_bf16 must be NULL then)
 extern "C" int pg_norm_bwd_apply_io(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma,
                                     int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags,
                                     void* stream) {
-  PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0 && io_flags >= 0 && io_flags <= 3, "pg_norm_bwd_apply: bad arguments");
-  const dim3 grid(norm_blocks(L), N);
+  PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0 && (io_flags == 0 || (io_flags == 3 && L % 8 == 0 && !dy_bf16)),
+             "pg_norm_bwd_apply: bad arguments");
   typedef unsigned short bf;
   hipStream_t st = (hipStream_t)stream;
-  switch (io_flags) {
-    case 0: hipLaunchKernelGGL((norm_bwd_apply_kernel<float, float>), grid, dim3(256), 0, st, (float*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
-    case 1: hipLaunchKernelGGL((norm_bwd_apply_kernel<bf, float>), grid, dim3(256), 0, st, (bf*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
-    case 2: hipLaunchKernelGGL((norm_bwd_apply_kernel<float, bf>), grid, dim3(256), 0, st, (float*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
-    default: hipLaunchKernelGGL((norm_bwd_apply_kernel<bf, bf>), grid, dim3(256), 0, st, (bf*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16); break;
-  }
+  if (io_flags == 0)
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(norm_blocks(L, 4), N), dim3(256), 0, st, (float*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
+  else
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf>), dim3(norm_blocks(L, 8), N), dim3(256), 0, st, (bf*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
   PG_LAUNCH_OK("pg_norm_bwd_apply");
   return 0;
 }

@@ -917,7 +917,6 @@ class GeneratorEngine:
         self.wt_fin = torch.zeros(64, cin_fin, **f32) if self.bfs else None    # bf16 STORAGE: weight padded to the 512 x 64 kernel
         self.fin_ws = torch.empty(1024 * cin_fin * 28, **f32) if (self.bfs and cin_fin <= 256) else None
         self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh): weight- and data-gradient operand
-        self.g_taps64 = _reg_bf16(torch.empty(N, H, W, 64, dtype=torch.bfloat16, device=device)) if self.bfs else None
         self.wt_out = torch.zeros((2 if deformable else 1) * self.enc[0] + self.dec[-2], 32, **f32)   # [cin][(tap, co)]
         self.warps = torch.empty(N, max(self.T, 1), 8, **f32)
         self.input = None
@@ -1126,30 +1125,27 @@ class GeneratorEngine:
         _debug_delay()
         L.call("pg_bias_grad", L.ptr(dpre), N, H * W, 3, 3 * H * W, 1, H * W, L.ptr(A.g("decoder.net.%d.bias" % (i + 1))),
                L.stream())
-        if not self.bfs:
-            L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
-                   L.ptr(self.g_taps), L.stream())
+        L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
+               L.ptr(self.g_taps), L.stream())
         if self.bfs:
-            # bf16 STORAGE: the im2col'd gradient is written as a bf16 [pixel][64] operand.  Weight gradient: one streaming
-            # pass over it and the ACTIVATED bf16 operands of the forward pass (csrc/out_conv_dgrad.hip); data gradient: a
-            # K = 64 bf16 contraction with the zero-padded weight of the forward pass, scattered with relu' like every other
-            # data gradient (the fp32 streaming kernel was VALU-bound: 0.9 ms at batch 32).
-            L.call("pg_im2col_taps_bf16", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 64,
-                   L.ptr(self.g_taps64), L.stream())
-            xs = []
-            for kind, idx, a in srcs:
+            # bf16 STORAGE: the im2col'd gradient stays the fp32 [pixel][32] tensor of the streaming kernels; every destination's
+            # forward tensor is the ACTIVATED bf16 operand of the forward pass (its sign gives relu', its value is the
+            # weight-gradient operand).  Two lean streaming passes (csrc/out_conv_dgrad.hip): weight gradient on the side
+            # stream, data gradient on the main stream.  (Tried: the data gradient as a K = 64 bf16 contraction with the padded
+            # weight — 8192 one-K-tile workgroups: 1.05 ms at batch 32 against 0.9 ms streaming.)
+            self.wt_out[:, :27].copy_(A.p(wkey).view(27, cin).t())
+            dsts = []
+            for (kind, idx, a), d0 in zip(srcs, self._dsts_for(srcs, True)):
                 xop = self._bf_fwd.lookup(L.ptr(a.t), a.C, L.ACT_RELU, L.ptr(a.aff), L.ptr(a.mask))
                 assert xop is not None, "forward operand of the output convolution is not in the pass cache"
-                xs.append(L.make_dst(None, a.C, fwd=xop.reshape(-1)[:a.t.numel()].view(a.t.shape), act=L.ACT_RELU))
-            arr = (L.Dst * len(xs))(*xs)
-            side = _side_stream() if SIDE_STREAM else None
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                L.call("pg_out_conv_wgrad_bf16", L.ptr(self.g_taps64), 64, N, H, W, arr, len(xs), L.ptr(A.g(wkey)),
-                       L.ptr(self.fin_ws), self.fin_ws.numel(), L.stream())
+                gt = {"dec": lambda: self.d_dz[idx], "warp": lambda: self.w_g[idx]}.get(
+                    kind, lambda: self.e_dz[{"app": "encoder_app", "pose": "encoder_pose", "enc": "encoder"}[kind]][idx])()
+                dsts.append(L.make_dst(gt, a.C, fwd=xop.reshape(-1)[:gt.numel()].view(gt.shape), act=L.ACT_RELU,
+                                       accumulate=bool(d0.accumulate)))
+            arr = (L.Dst * len(dsts))(*dsts)
+            L.call("pg_out_conv_dgrad_wgrad", L.ptr(self.g_taps), L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.ptr(A.g(wkey)),
+                   L.ptr(self.fin_ws), self.fin_ws.numel(), L.stream())
             self._ready("decoder.net.%d." % (i + 1))
-            _conv_dgrad(Act(self.g_taps64, 64).src(), N, H, W, 0, 1, 1, 0, H, W, self.wt_fin, 64, cin, self._dsts_for(srcs, True))
         else:
             self._backward_final_fp32(srcs, cin, wkey, i)
         self._backward_rest(image_grad)
