@@ -389,10 +389,15 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   }
   for (int k = threadIdx.x; k < w; k += 256) xs_t[k] = warp_norm_coord(k, w, align);
   for (int k = threadIdx.x; k < h; k += 256) ys_t[k] = warp_norm_coord(k, h, align);
+  const long nb = (long)n * h * w;
+  // persistent workgroups (round 3): the per-sample set-up above (ten inverted transforms, w + h table entries) cost more
+  // than the 32 pixels of work behind it when every tile was its own workgroup (65536 workgroups at 256^2, batch 32)
+  const int ntiles = (h * w + GATHER_PIX - 1) / GATHER_PIX;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  __syncthreads();                                           // the previous tile's lists are consumed
   if (threadIdx.x < GATHER_PIX) e_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const long nb = (long)n * h * w;
-  const int P0 = blockIdx.x * GATHER_PIX;
+  const int P0 = tile * GATHER_PIX;
   // ---- phase 1: one lane per (input pixel, transform); the <= 16 mask values of the pre-image box are loaded as ONE batch
   {
     const int p = threadIdx.x & (GATHER_PIX - 1), P = P0 + p;
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
     }
     wst4<DB>(reinterpret_cast<char*>(dfeat), (size_t)((nb + P) * C + c4) * ESD, acc);
   }
+  }   // tile loop
 }
 
 // Scatter form (float atomics), `wide_only`: only the elements whose selected transform is not "narrow" — the complement
@@ -656,8 +662,10 @@ extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, 
   } while (0)
   if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM) {
     // gather kernel OVERWRITES dfeat (narrow transforms), then the scatter kernel adds the wide ones
-    PGW_BWD(warp_bwd_gather_kernel, dim3((h * w + GATHER_PIX - 1) / GATHER_PIX, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
-            align_corners, dfeat);
+    static const int gcap = getenv("PG_WARP_BWD_TILES") ? atoi(getenv("PG_WARP_BWD_TILES")) : 256;     // workgroups per sample
+    int gtiles = (h * w + GATHER_PIX - 1) / GATHER_PIX;
+    if (gtiles > gcap) gtiles = gcap;
+    PGW_BWD(warp_bwd_gather_kernel, dim3(gtiles, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
     // (a sample without wide transforms costs one early-exiting workgroup round: keep that grid small)
     PGW_BWD(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,

@@ -316,7 +316,9 @@ struct Wg4K {
   int ktot;                   // N * Hs * Ws / 64
 };
 
-template <int BM, int BN, int AS>
+// R2: the small grid has 32 columns — a K tile is TWO small-grid rows; the large patch holds the two large rows 2 (qy + i) + r - 1,
+// 66 pixels each, image row i at plane rows 36 i .. (36 = 32 + 4: the four pixel rows of a transposing read stay aligned).
+template <int BM, int BN, int AS, bool R2 = false>
 __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
   constexpr int BS = AS ? BM : BN, BL = AS ? BN : BM;         // widths of the small-grid (shared) / large-grid (per-tap) operand
   constexpr int TS = (BS == 128 && BL == 128) ? 2 : 1, TL = 1;   // MFMA tiles per wave along the shared / per-tap operand
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
   static_assert(WS * WL == 8, "8 waves");
   constexpr int S_CPR = BS / 8, L_CPR = BL / 8;               // 16-byte chunks per pixel row
   constexpr int S_PPI = 64 / S_CPR, L_PPI = 64 / L_CPR;       // pixel rows per wave DMA instruction (1 KB)
-  constexpr int PL = (L_CPR == 16) ? 68 : 72;                 // rows per plane (65 used), a multiple of L_PPI
+  constexpr int PL = 72;                                      // rows per plane (65 / 36 + 33 used), a multiple of L_PPI
+  constexpr int RP = 36, PMAX = R2 ? 65 : 129;                // R2: plane rows per image row; last patch pixel of a row
   constexpr int S_ST = 64 * BS * 2, L_ST = 2 * PL * BL * 2, STAGE = S_ST + L_ST, NST = 3;
   constexpr int S_NI = 64 / S_PPI, L_NI = 2 * PL / L_PPI;     // DMA instructions per tile
   constexpr int S_PASS = (S_NI + 7) / 8, L_PASS = (L_NI + 7) / 8;
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
   // ---- DMA: lane -> (LDS row of the instruction, 16-byte slot); the global chunk it moves is slot ^ swizzle(LDS row)
   unsigned s_cofs[S_PASS];            // small operand: byte offset of (tile pixel, chunk) against the tile's first pixel
   unsigned l_cofs[L_PASS];            // large patch: byte offset of (patch pixel P, chunk) against patch pixel 0
-  int l_P[L_PASS];                    // patch pixel of this lane's LDS row (0 .. 129 valid; >= 130: padding rows)
+  int l_P[L_PASS];                    // patch pixel of this lane's LDS row (0 .. PMAX valid; beyond: padding rows)
+  int l_i[L_PASS];                    // R2: image row (0 / 1) of this lane's LDS row
 #pragma unroll
   for (int i = 0; i < S_PASS; ++i) {
     const int ins = min(i * 8 + wave, S_NI - 1);
@@ -379,8 +383,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
     const int ins = min(i * 8 + wave, L_NI - 1);             // surplus instructions repeat the last one (same data, same place)
     const int row = ins * L_PPI + lane / L_CPR, slot = lane % L_CPR;
     const int pl = row >= PL ? 1 : 0, pr = row - pl * PL;   // plane (0: even patch pixels, 1: odd), row inside the plane
-    const int P = 2 * pr + pl;
-    l_P[i] = P;
+    const int ir = R2 ? pr / RP : 0, jj = pr - ir * RP;     // image row of the tile, column inside the plane row
+    const int P = (R2 && (ir > 1 || jj > 32)) ? 1000 : 2 * jj + pl;
+    l_P[i] = P; l_i[i] = ir;
     l_cofs[i] = (unsigned)((P * p.Cl + l_c0 + ((slot ^ wg_swz<L_CPR>(row)) << 3)) * 2);
   }
   const unsigned Cs2 = (unsigned)p.Cs * 2u, Cl2 = (unsigned)p.Cl * 2u;
@@ -395,9 +400,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
     const int Y = 2 * qy + tr - 1;
     const bool live = kt < kt1;                               // past the end: zero rows (keeps the vmcnt accounting uniform)
     const bool row_ok = live & (Y >= 0) & (Y < Hl);
-    const bool left_ok = qx0 > 0, right_ok = qx0 + 64 < p.Ws;
+    const bool row_ok1 = live & (Y + 2 >= 0) & (Y + 2 < Hl);  // R2: the second small row of the tile
+    const bool left_ok = qx0 > 0, right_ok = qx0 + (R2 ? 32 : 64) < p.Ws;
     const unsigned s_off = (unsigned)q0 * Cs2;
     const unsigned l_off = ((unsigned)(n * Hl + Y) * (unsigned)Wl + (unsigned)(2 * qx0 - 1)) * Cl2;
+    const unsigned l_off1 = l_off + 2u * (unsigned)Wl * Cl2;
     float* const st = reinterpret_cast<float*>(smem + stage * STAGE);
     const char* const zp = zero_pg + (lane & 7) * 16;
 #pragma unroll
@@ -407,8 +414,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
     }
 #pragma unroll
     for (int i = 0; i < L_PASS; ++i) {
-      const bool ok = row_ok & (l_P[i] < 130) & (left_ok | (l_P[i] != 0)) & (right_ok | (l_P[i] != 129));
-      const char* src = ok ? l_base + (l_off + l_cofs[i]) : zp;
+      const bool rok = R2 ? (l_i[i] ? row_ok1 : row_ok) : row_ok;
+      const bool ok = rok & (l_P[i] <= PMAX) & (left_ok | (l_P[i] != 0)) & (right_ok | (l_P[i] != PMAX));
+      const char* src = ok ? l_base + ((R2 && l_i[i] ? l_off1 : l_off) + l_cofs[i]) : zp;
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), st + S_ST / 4 + min(i * 8 + wave, L_NI - 1) * 256, 16, 0, 0);
     }
   };
@@ -445,8 +453,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int t = 0; t < TL; ++t) {
-        lds_tr64<KS * 16 * BL * 2>(f.lg[s][t].lo, fl[s][t] + so);
-        lds_tr64<KS * 16 * BL * 2 + 4 * BL * 2>(f.lg[s][t].hi, fl[s][t] + so);
+        constexpr int XR = R2 ? (KS >> 1) * 4 * BL * 2 : 0;       // R2: k-steps 2, 3 are the second image row (+ 4 plane rows)
+        lds_tr64<KS * 16 * BL * 2 + XR>(f.lg[s][t].lo, fl[s][t] + so);
+        lds_tr64<KS * 16 * BL * 2 + 4 * BL * 2 + XR>(f.lg[s][t].hi, fl[s][t] + so);
       }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -581,7 +590,8 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   {
     static const int mode = getenv("PG_WGTR4") ? atoi(getenv("PG_WGTR4")) : 2;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    const bool geo = pow2(Hs) && pow2(Ws) && Ws >= 64 && Hl == 2 * Hs && Wl == 2 * Ws;
+    const bool geo = pow2(Hs) && pow2(Ws) && (Ws >= 64 || (Ws == 32 && Hs >= 2)) && Hl == 2 * Hs && Wl == 2 * Ws;
+    const bool r2 = Ws == 32;
     const bool thin = bm < 256 || bn < 256;
     if (mode > 0 && geo && (thin || mode == 2) && ksplit <= 0) {
       const int tm = Cout % 128 == 0 ? 128 : 64, tn = Cx % 128 == 0 ? 128 : 64;
@@ -602,10 +612,15 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
       q.ksplit = ks4; q.atomic = ks4 > 1 ? 1 : 0;
       q.xcd_remap = (((long)mt4 * nt4 * ks4) % 8 == 0 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
       dim3 grid4(mt4, nt4, 4 * ks4);
-#define PGW4_LAUNCH(M_, N_)                                                                                    \
-  do {                                                                                                         \
-    if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 1>), grid4, dim3(512), 0, st, q);      \
-    else hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 0>), grid4, dim3(512), 0, st, q);                   \
+#define PGW4_LAUNCH(M_, N_)                                                                                              \
+  do {                                                                                                                   \
+    if (r2) {                                                                                                            \
+      if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 1, true>), grid4, dim3(512), 0, st, q);        \
+      else hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 0, true>), grid4, dim3(512), 0, st, q);                     \
+    } else {                                                                                                             \
+      if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 1, false>), grid4, dim3(512), 0, st, q);       \
+      else hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 0, false>), grid4, dim3(512), 0, st, q);                    \
+    }                                                                                                                    \
   } while (0)
       if (tm == 128 && tn == 128) PGW4_LAUNCH(128, 128);
       else if (tm == 128) PGW4_LAUNCH(128, 64);

@@ -105,6 +105,11 @@ def wgrad_tr4_cases():
         ConvCase("w4_up_3src_128", "convT", [(256, A, M), (128, False, False), (128, A, False)], 128, 1, 64, 64, 4, 2, 1,
                  L.ACT_RELU, seed=75),
         ConvCase("w4_up_x64_128", "convT", [(64, A, False)], 128, 2, 64, 128, 4, 2, 1, L.ACT_RELU, seed=76),
+        # 32-column small grids: a K tile = two small-grid rows (the R2 variant)
+        ConvCase("w4_conv_ws32", "conv", [(128, A, False)], 256, 3, 64, 64, 4, 2, 1, L.ACT_LEAKY, seed=77),
+        ConvCase("w4_up_ws32_3src", "convT", [(256, A, M), (128, False, False), (128, A, False)], 128, 2, 32, 32, 4, 2, 1,
+                 L.ACT_RELU, seed=78),
+        ConvCase("w4_conv_ws32_rect", "conv", [(64, False, False)], 128, 1, 16, 64, 4, 2, 1, L.ACT_LEAKY, seed=79),    # Hs = 8
     ]
 
 
