@@ -438,6 +438,11 @@ int pg_tap_gather_pitch(const float* Y, int32_t pitch, int32_t N, int32_t H, int
  * workspace >= 64 * Ctot * 28 floats. */
 int pg_out_conv_dgrad_wgrad(const float* G, const float* Wt, int32_t N, int32_t H, int32_t W, const pg_dst_t* dst,
                             int32_t ndst, float* dW, float* workspace, int64_t workspace_floats, void* stream);
+/* the same; g_is_dpre = 1: G is the NCHW (N,3,H,W) gradient wrt the pre-tanh output itself (the kernels gather the 27 (tap,
+ * channel) values of a pixel: no pg_im2col_taps pass); wg_stream: stream of the weight-gradient pass (NULL = stream) */
+int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const float* Wt, int32_t N, int32_t H, int32_t W,
+                           const pg_dst_t* dst, int32_t ndst, float* dW, float* workspace, int64_t workspace_floats,
+                           void* wg_stream, void* stream);
 /* bf16 im2col of the output convolution's gradient (pg_im2col_taps with a bf16 G, Cpad = 64) and its weight gradient alone:
  * dW[27][Ctot] += sum_pixels G[pixel][t] * x[pixel][ci], x = the activated bf16 forward operands given as dst[].fwd.  The data
  * gradient of that layer is then a plain bf16 pg_conv (K = 64) with the zero-padded weight. */

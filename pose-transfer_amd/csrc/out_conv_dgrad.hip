@@ -21,6 +21,8 @@ struct OutDgradK {
   int dstart[PG_MAX_SRC + 1];
   float* wpart;            // WG = true: per-workgroup partial weight gradients [blocks][Ctot][28] (round 3)
   int g_bf16_pitch;        // 0: G is fp32 with row pitch 32; else G is bf16 with this row pitch (64)
+  const float* dpre;       // DIRECT = true: the NCHW [N][3][H][W] gradient itself — the 27 (tap, channel) values of a pixel are
+  int H, W;                //   gathered from it, no im2col'd copy exists (round 3)
 };
 
 constexpr int ODG_T = 27;
@@ -51,9 +53,12 @@ __device__ __forceinline__ float4 ld4_dt(const float* base, long idx) {
 // the batched loads stay straight-line code).  Instantiated as <DG, !WG, fp32> (the fp32 paths), <DG, !WG, bf16> and
 // <!DG, WG, bf16>: two lean passes beat one fused pass (256 VGPRs, one wave per SIMD: 3.07 ms at batch 32 against
 // 0.4 + 0.4 ms).
-template <bool DG, bool WG, bool BF>
+template <bool DG, bool WG, bool BF, bool DIRECT = false>
 __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // DIRECT: lane t < 27 = (tap, channel) = (t / 3, t % 3) reads dpre[n][c][y - (r - 1)][x - (s - 1)] (pg_im2col_taps' formula)
+  const int d_c = (lane % 27) % 3, d_tap = (lane % 27) / 3;
+  const int d_dy = 1 - d_tap / 3, d_dx = 1 - d_tap % 3;
   typedef float f32x2w __attribute__((ext_vector_type(2)));
   f32x2w aw01[WG ? ODG_T : 1], aw23[WG ? ODG_T : 1];          // channel pairs (packed fp32 FMAs)
   if constexpr (WG) {
@@ -115,7 +120,14 @@ __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) 
       const int pix = ok[u] ? base + u : base;
       const int n = pix / p.ppix;
       idx[u] = (long)pix * C + c;
-      if (p.g_bf16_pitch)                                      // (wave-uniform) bf16 rows of the bf16 data path
+      if constexpr (DIRECT) {
+        const int rem = pix - n * p.ppix;
+        const int y = rem / p.W, x = rem - y * p.W;            // wave-uniform
+        const int yy = y + d_dy, xx = x + d_dx;
+        const bool in = (yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W);
+        const float v = p.dpre[((long)(n * 3 + d_c) * p.H + (in ? yy : y)) * p.W + (in ? xx : x)];
+        gl[u] = in ? v : 0.f;
+      } else if (p.g_bf16_pitch)                               // (wave-uniform) bf16 rows of the bf16 data path
         gl[u] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p.G)[(long)pix * p.g_bf16_pitch + (lane & 31)] << 16);
       else
         gl[u] = p.G[(long)pix * 32 + (lane & 31)];             // one 128-byte row, lanes 32..63 mirror it
@@ -247,13 +259,26 @@ extern "C" int pg_out_conv_dgrad(const float* G, const float* Wt, int32_t N, int
 // over the same descriptors: every destination's `fwd` must be the ACTIVATED bf16 operand of the forward pass (no aff /
 // mask on it), gradients are bf16, dW is [27][Ctot] fp32 (accumulated), `workspace` holds workspace_floats >= 64 * Ctot * 28
 // floats of per-workgroup partials.
+extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const float* Wt, int32_t N, int32_t H, int32_t W,
+                                      const pg_dst_t* dst, int32_t ndst, float* dW, float* workspace, int64_t workspace_floats,
+                                      void* wg_stream, void* stream);
 extern "C" int pg_out_conv_dgrad_wgrad(const float* G, const float* Wt, int32_t N, int32_t H, int32_t W, const pg_dst_t* dst,
                                        int32_t ndst, float* dW, float* workspace, int64_t workspace_floats, void* stream) {
+  return pg_out_conv_bwd_direct(G, 0, Wt, N, H, W, dst, ndst, dW, workspace, workspace_floats, nullptr, stream);
+}
+
+// g_is_dpre = 1: `G` is the NCHW (N,3,H,W) gradient wrt the pre-tanh output itself; the kernels gather each pixel's 27 (tap,
+// channel) values from it (no pg_im2col_taps pass, no [pixel][32] tensor).  wg_stream: stream of the weight-gradient pass (NULL:
+// `stream`); the caller orders it after the producer of G.
+extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const float* Wt, int32_t N, int32_t H, int32_t W,
+                                      const pg_dst_t* dst, int32_t ndst, float* dW, float* workspace, int64_t workspace_floats,
+                                      void* wg_stream, void* stream) {
   PG_REQUIRE(G && Wt && dst && dW && workspace && ndst >= 1 && ndst <= PG_MAX_SRC && N > 0 && H > 0 && W > 0,
              "pg_out_conv_dgrad_wgrad: bad arguments");
   pg::OutDgradK k;
   memset(&k, 0, sizeof(k));
   k.G = G; k.Wt = Wt;
+  if (g_is_dpre) { k.dpre = G; k.H = H; k.W = W; }
   int c = 0;
   for (int j = 0; j < ndst; ++j) {
     k.dst[j] = dst[j]; k.dstart[j] = c; c += dst[j].C;
@@ -268,7 +293,9 @@ extern "C" int pg_out_conv_dgrad_wgrad(const float* G, const float* Wt, int32_t 
   k.npix = N * H * W; k.ppix = H * W;
   long blocks = (k.npix + 15) / 16;
   if (blocks > 256 * 12) blocks = 256 * 12;
-  hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  hipStream_t st = (hipStream_t)stream, wst = wg_stream ? (hipStream_t)wg_stream : st;
+  if (g_is_dpre) hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<true, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<true, false, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (data gradient)");
   blocks = (k.npix + 15) / 16;
   long cap = workspace_floats / ((long)c * 28);
@@ -276,10 +303,10 @@ extern "C" int pg_out_conv_dgrad_wgrad(const float* G, const float* Wt, int32_t 
   PG_REQUIRE(cap >= 64, "pg_out_conv_dgrad_wgrad: workspace too small");
   if (blocks > cap) blocks = cap;
   k.wpart = workspace;
-  hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  if (g_is_dpre) hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<false, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
+  else hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<false, true, true, false>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (weight gradient)");
-  hipLaunchKernelGGL(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
-                     (int)blocks, c, dW);
+  hipLaunchKernelGGL(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256), dim3(256), 0, wst, workspace, (int)blocks, c, dW);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (reduce)");
   return 0;
 }

@@ -8,6 +8,7 @@ carries a per-sample affine ``aff`` [N,2] and an optional channel mask [N,C] tha
 load.  Parameters live in flat arenas (params / grads / Adam m / Adam v) in packed kernel layout.
 """
 import contextlib
+import ctypes
 import os
 import math
 import weakref
@@ -1011,7 +1012,16 @@ class GeneratorEngine:
         bfs = self.bfs
         assert bfs == (bf16_store() and bfs), "the engine was built for another storage mode (PRECISION changed?)"
         npx = lambda l: self.hw[l][0] * self.hw[l][1]
+        # (round 3, tried and dropped: the pose encoder's chain on the side stream next to the appearance encoder's — 22.28 ms
+        # against 22.02 ms for the north-star pass, and the 224^2 data-parallel identity test failed under it)
         for e in self.encs:
+            self._forward_encoder(e, inp, bfs, npx)
+        self._forward_rest(inp, bfs)
+        return self.out
+
+    def _forward_encoder(self, e, inp, bfs, npx):
+        A, N, H, W = self.A, self.N, self.H, self.W
+        if True:
             s0 = self._enc_in_src(e, inp)
             if bfs:
                 # level 0 has no norm: the stem writes the raw tensor and the operand(s) of its readers in one pass — the next
@@ -1042,6 +1052,8 @@ class GeneratorEngine:
                     self.e_norm[e][l].forward(self.e_raw[e][l], N, ho * wo * self.enc[l],
                                               A.p("%s.net.%d.net.2.weight" % (e, l)), A.p("%s.net.%d.net.2.bias" % (e, l)),
                                               have_stats=True)
+    def _forward_rest(self, inp, bfs):
+        A, N, H, W = self.A, self.N, self.H, self.W
         # ---- deformable skips (reference networks.py:279-288, utils/pose_transform.py:69-92)
         for l in range(self.nwarp):
             a = self._enc_act("encoder_app", l)
@@ -1125,8 +1137,9 @@ class GeneratorEngine:
         _debug_delay()
         L.call("pg_bias_grad", L.ptr(dpre), N, H * W, 3, 3 * H * W, 1, H * W, L.ptr(A.g("decoder.net.%d.bias" % (i + 1))),
                L.stream())
-        L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
-               L.ptr(self.g_taps), L.stream())
+        if not self.bfs:
+            L.call("pg_im2col_taps", L.ptr(dpre), ystr[0], ystr[1], ystr[2], ystr[3], N, H, W, 3, 3, 1, 3, 32,
+                   L.ptr(self.g_taps), L.stream())
         if self.bfs:
             # bf16 STORAGE: the im2col'd gradient stays the fp32 [pixel][32] tensor of the streaming kernels; every destination's
             # forward tensor is the ACTIVATED bf16 operand of the forward pass (its sign gives relu', its value is the
@@ -1143,8 +1156,13 @@ class GeneratorEngine:
                 dsts.append(L.make_dst(gt, a.C, fwd=xop.reshape(-1)[:gt.numel()].view(gt.shape), act=L.ACT_RELU,
                                        accumulate=bool(d0.accumulate)))
             arr = (L.Dst * len(dsts))(*dsts)
-            L.call("pg_out_conv_dgrad_wgrad", L.ptr(self.g_taps), L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.ptr(A.g(wkey)),
-                   L.ptr(self.fin_ws), self.fin_ws.numel(), L.stream())
+            # no im2col'd copy of the gradient: the kernels gather each pixel's 27 values from dpre; the weight-gradient pass
+            # goes to the side stream like every other weight gradient
+            side = _side_stream() if SIDE_STREAM else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            L.call("pg_out_conv_bwd_direct", L.ptr(dpre), 1, L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.ptr(A.g(wkey)),
+                   L.ptr(self.fin_ws), self.fin_ws.numel(), ctypes.c_void_p(side.cuda_stream) if side is not None else None, L.stream())
             self._ready("decoder.net.%d." % (i + 1))
         else:
             self._backward_final_fp32(srcs, cin, wkey, i)

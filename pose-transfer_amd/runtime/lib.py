@@ -132,6 +132,7 @@ _PROTOS = {
     "pg_tap_gather_pitch": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
     "pg_im2col_taps_bf16": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_out_conv_wgrad_bf16": [_vp, _i32, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp],
+    "pg_out_conv_bwd_direct": [_vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp, _vp],
     "pg_out_conv_dgrad_wgrad": [_vp, _vp, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp],
     "pg_version": [],
     "pg_last_launch_info": [],
