@@ -3,8 +3,12 @@ precedes the training step: reference src_deformable/utils/pose_transform.py:94-
 primitives it calls.
 
 PARITY UNPINNED for the two third-party primitives: scikit-image is not installed in this image, so
-``estimate_affine`` and ``grid_points_in_poly`` restate the published algorithms of the release contemporary with
-the reference (scikit-image <= 0.15):
+``estimate_affine`` and ``grid_points_in_poly`` restate the published algorithms of scikit-image 0.14.x
+(``skimage/transform/_geometric.py``: ``AffineTransform`` inherits ``ProjectiveTransform.estimate``, which normalises both
+point sets with ``_center_and_normalize_points``; ``skimage/measure/pnpoly.pyx``).  The reference pins no version (its
+bytecode is CPython 3.6, 2018); a release whose estimate does NOT normalise the points gives different transforms for every
+inconsistent over-determined fit — quantified on the fixture inputs by oracle/tls_normalisation_study.py
+(profiles/round3_tls_normalisation_study.txt):
 
 * ``skimage.transform.estimate_transform('affine', src, dst)`` -> ``AffineTransform.estimate``: both point sets are
   Hartley-normalised (centroid to the origin, RMS distance sqrt(2)), the 2n x 7 system
