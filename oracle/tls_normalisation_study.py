@@ -73,8 +73,9 @@ if __name__ == "__main__":
            "# un-normalised total-least-squares affine fits on the key-point sets of tests/golden/pose_geom.npz (reference",
            "# utils/pose_transform.py:213-289: 10 limb / body fits per sample)."]
     out = "\n".join(hdr + lines + [
-        "# Exactly determined fits (3 points; consistent sets) agree to rounding; over-determined, inconsistent sets (the 4-corner limb",
-        "# polygons of random fixture key-points) differ by whole pixels, and the un-normalised system is occasionally near-singular",
+        "# Consistent point sets (the limb parallelograms estimate_polygon builds from two joints: ~70 %% of the fits) agree to rounding;",
+        "# inconsistent over-determined sets (body: 4 torso joints, head: face joints + shoulders, of random fixture key-points) differ by",
+        "# whole pixels to hundreds of pixels, and the un-normalised system is occasionally near-singular",
         "# (last component of the singular vector ~ 0).  So the choice of variant matters and cannot be settled without the reference's",
         "# scikit-image: f1 stays 'parity unpinned' for this primitive (largest per-case median: %.3f px)." % worst]) + "\n"
     print(out)
