@@ -233,6 +233,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the iteration as ONE captured HIP graph (runtime/graph.py; single GPU only) — an extra, "
                          "non-default measurement of the host-bound small-batch configurations")
+    ap.add_argument("--tape", action="store_true",
+                    help="replay the iteration from the library's launch tape (runtime/tape.py: ONE host call per iteration, the "
+                         "launches stay on their streams; single GPU only) — removes the Python enqueue cost of the small-batch "
+                         "configurations; an extra measurement, the default line is the eager loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--launch-table", default=None, help="write one line per contraction launch of the profiled iteration here")
@@ -265,6 +269,10 @@ def main():
         assert world == 1, "--graph is single-GPU only"
         from pose_transfer_amd.runtime.graph import GraphedIteration
         graphed = GraphedIteration(model, batches, od, warmup=max(2, args.warmup))
+    if args.tape:
+        assert world == 1 and not args.graph, "--tape is single-GPU only (and exclusive with --graph)"
+        from pose_transfer_amd.runtime.tape import TapedIteration
+        graphed = TapedIteration(model, batches, od, warmup=max(2, args.warmup))
     step = graphed.replay if graphed is not None else (lambda: iteration(model, batches, od))
     for _ in range(args.warmup):
         step()
@@ -349,7 +357,8 @@ def main():
                                       if (args.size, P, args.batch, args.precision) == (256, 18, 4, "f32") else ""),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size,
-                       "precision": args.precision, **({"hip_graph": True} if args.graph else {})},
+                       "precision": args.precision, **({"hip_graph": True} if args.graph else {}),
+                       **({"launch_tape": True} if args.tape else {})},
             "step_tflops": round(sf * ips / 1e12, 2),
             "step_frac_of_f32_mfma_peak": round(sf * ips / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,

@@ -451,6 +451,22 @@ int pg_im2col_taps_bf16(const float* dY, int64_t yN, int64_t yC, int64_t yH, int
 int pg_out_conv_wgrad_bf16(const void* G_bf16, int32_t g_pitch, int32_t N, int32_t H, int32_t W, const pg_dst_t* dst,
                            int32_t ndst, float* dW, float* workspace, int64_t workspace_floats, void* stream);
 
+/* ---- launch tape (round 3; no reference counterpart: the reference's loop is eager PyTorch, main.py:77-108).  Between
+ * pg_tape_begin and pg_tape_end the calling thread's enqueues (kernel launches, memsets, pg_stream_wait, pg_zero, pg_copy) are
+ * issued as usual AND recorded with a copy of their arguments; pg_tape_replay re-issues them on the same streams — one call per
+ * training iteration.  Requirements as for a HIP graph: persistent buffers, per-iteration scalars in device memory
+ * (pg_dropout_mask_ctr, pg_adam_ctr, pg_counter_add), inputs copied into static tensors before the replay. */
+int pg_tape_begin(void);
+int pg_tape_end(void** tape, int64_t* n_ops);
+int pg_tape_replay(void* tape);
+int pg_tape_destroy(void* tape);
+/* stream `waiter` waits for the work enqueued on `waited` so far (event record + wait; recorded on a tape) */
+int pg_stream_wait(void* waiter, void* waited);
+int pg_zero(void* ptr, int64_t bytes, void* stream);
+int pg_copy(void* dst, const void* src, int64_t bytes, void* stream);
+/* dst[c][r] = src[r][c], R x C row-major fp32, destination rows `ld` floats apart */
+int pg_transpose_f32(const float* src, int32_t R, int32_t C, float* dst, int32_t ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,7 +113,7 @@ extern "C" int pg_pack_bf16(const float* src, void* dst, int64_t n, void* stream
              "pg_pack_bf16: need an even count and 8 / 4-byte aligned pointers");
   long blocks = (n / 2 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned*)dst, (long)(n / 2));
+  PG_KLAUNCH(pack_bf16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned*)dst, (long)(n / 2));
   PG_LAUNCH_OK("pg_pack_bf16");
   return 0;
 }

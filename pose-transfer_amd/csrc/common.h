@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include "posegan_hip.h"
 
 namespace pg {
@@ -35,6 +38,46 @@ int& last_info();  // thread-local: tile config / loader modes / split-K of the 
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- launch tape (round 3, api.hip: pg_tape_*).  Every kernel launch / memset / stream-ordering call of the library goes through
+// these macros: it is issued as usual and, while the calling thread records, also kept as a closure (kernel, geometry, stream
+// and a COPY of the argument block).  pg_tape_replay re-issues the closures: one C call per training iteration instead of
+// ~250 Python -> ctypes -> descriptor-check -> launch round trips (25 us each; a replayed launch costs the hipLaunchKernel
+// alone).  Unlike a HIP graph the tape keeps the launches on their own streams (weight-gradient side stream, collectives).
+struct Tape;
+Tape* tape_recording();                                  // the tape this thread is recording into, or nullptr
+void tape_push(Tape* t, void (*thunk)(void*), void* closure, void (*del)(void*), const char* where, int line);
+template <typename F>
+inline void tape_record(F&& f, const char* where = "", int line = 0) {
+  Tape* t = tape_recording();
+  if (t == nullptr) return;
+  typedef typename std::decay<F>::type Fn;
+  Fn* c = new Fn(std::forward<F>(f));
+  tape_push(t, [](void* q) { (*static_cast<Fn*>(q))(); }, c, [](void* q) { delete static_cast<Fn*>(q); }, where, line);
+}
+// Every argument expression is evaluated ONCE, here: the closure holds values (a launch written as `dim3(bx, d->N)` must not
+// dereference the caller's descriptor again at replay time — it is gone by then).
+#define PG_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                                              \
+  do {                                                                                                                    \
+    const dim3 pg_g__ = (grid), pg_b__ = (block);                                                                         \
+    const size_t pg_sh__ = (size_t)(shmem);                                                                               \
+    hipStream_t pg_st__ = (stream);                                                                                       \
+    auto pg_args__ = std::make_tuple(__VA_ARGS__);                                                                        \
+    auto pg_fn__ = [=]() {                                                                                                \
+      std::apply([&](const auto&... pg_a__) { hipLaunchKernelGGL(kernel, pg_g__, pg_b__, pg_sh__, pg_st__, pg_a__...); }, \
+                 pg_args__);                                                                                              \
+    };                                                                                                                    \
+    pg_fn__();                                                                                                            \
+    if (pg::tape_recording() != nullptr) pg::tape_record(pg_fn__, __FILE__, __LINE__);                                    \
+  } while (0)
+#define PG_MEMSET_ASYNC(ptr, val, bytes, st)                                                        \
+  do {                                                                                              \
+    void* pg_p__ = (void*)(ptr); const size_t pg_b__ = (bytes); hipStream_t pg_s__ = (st);          \
+    const int pg_v__ = (val);                                                                       \
+    PG_HIP(hipMemsetAsync(pg_p__, pg_v__, pg_b__, pg_s__));                                         \
+    if (pg::tape_recording() != nullptr)                                                            \
+      pg::tape_record([=]() { (void)hipMemsetAsync(pg_p__, pg_v__, pg_b__, pg_s__); }, __FILE__, __LINE__);              \
+  } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -199,7 +199,7 @@ extern "C" int pg_tap_gather_pitch(const float* Y, int32_t pitch, int32_t N, int
                                    int32_t out_act, float* out, int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream) {
   // the k3 p1 Co = 3 gather over a tap tensor whose pixel rows are `pitch` >= 27 floats apart
   PG_REQUIRE(Y && out && N > 0 && N <= 65535 && pitch >= 27, "pg_tap_gather_pitch: bad arguments");
-  hipLaunchKernelGGL(tap_gather_333_kernel, dim3((W + 31) / 32, (H + 7) / 8, N), dim3(256), 0, (hipStream_t)stream, Y, N, H, W,
+  PG_KLAUNCH(tap_gather_333_kernel, dim3((W + 31) / 32, (H + 7) / 8, N), dim3(256), 0, (hipStream_t)stream, Y, N, H, W,
                      bias, out_act, out, (long)oN, (long)oC, (long)oH, (long)oW, pitch);
   PG_LAUNCH_OK("pg_tap_gather_pitch");
   return 0;
@@ -210,14 +210,14 @@ extern "C" int pg_tap_gather(const float* Y, int32_t N, int32_t H, int32_t W, in
                              int64_t oH, int64_t oW, void* stream) {
   PG_REQUIRE(Y && out && N > 0 && Co > 0, "pg_tap_gather: bad arguments");
   if (KH == 3 && KW == 3 && pad == 1 && Co == 3 && N <= 65535) {
-    hipLaunchKernelGGL(tap_gather_333_kernel, dim3((W + 31) / 32, (H + 7) / 8, N), dim3(256), 0, (hipStream_t)stream, Y, N, H, W,
+    PG_KLAUNCH(tap_gather_333_kernel, dim3((W + 31) / 32, (H + 7) / 8, N), dim3(256), 0, (hipStream_t)stream, Y, N, H, W,
                        bias, out_act, out, (long)oN, (long)oC, (long)oH, (long)oW, 27);
     PG_LAUNCH_OK("pg_tap_gather");
     return 0;
   }
   long blocks = ((long)N * H * W + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(tap_gather_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, Y, N, H, W, KH, KW, pad, Co,
+  PG_KLAUNCH(tap_gather_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, Y, N, H, W, KH, KW, pad, Co,
                      bias, out_act, out, (long)oN, (long)oC, (long)oH, (long)oW);
   PG_LAUNCH_OK("pg_tap_gather");
   return 0;
@@ -229,7 +229,7 @@ extern "C" int pg_im2col_taps(const float* dY, int64_t yN, int64_t yC, int64_t y
   PG_REQUIRE(dY && G && N > 0 && Cpad >= KH * KW * C, "pg_im2col_taps: bad arguments");
   long blocks = ((long)N * H * W * Cpad + 1023) / 1024;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(im2col_taps_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
+  PG_KLAUNCH(im2col_taps_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
                      (long)yH, (long)yW, N, H, W, KH, KW, pad, C, Cpad, G);
   PG_LAUNCH_OK("pg_im2col_taps");
   return 0;
@@ -243,7 +243,7 @@ extern "C" int pg_im2col_taps_bf16(const float* dY, int64_t yN, int64_t yC, int6
   PG_REQUIRE(dY && G_bf16 && N > 0 && Cpad >= KH * KW * C, "pg_im2col_taps_bf16: bad arguments");
   long blocks = ((long)N * H * W * Cpad + 1023) / 1024;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(im2col_taps_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
+  PG_KLAUNCH(im2col_taps_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, (long)yN, (long)yC,
                      (long)yH, (long)yW, N, H, W, KH, KW, pad, C, Cpad, reinterpret_cast<float*>(G_bf16));
   PG_LAUNCH_OK("pg_im2col_taps_bf16");
   return 0;
@@ -271,7 +271,7 @@ extern "C" int pg_small_cout_dgrad(const float* dY, int64_t yN, int64_t yC, int6
     PG_HIP(hipFuncSetAttribute((const void*)small_cout_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   long blocks = ((long)N * H * W * (c / 4) + 255) / 256;
   if (blocks > 8192) blocks = 8192;      // each block stages the weights once (27 KB): enough blocks to hide latency
-  hipLaunchKernelGGL(small_cout_dgrad_kernel, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, k);
+  PG_KLAUNCH(small_cout_dgrad_kernel, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_small_cout_dgrad");
   return 0;
 }
@@ -434,7 +434,7 @@ extern "C" int pg_repack_small_cin(const float* W, int32_t KH, int32_t KW, int32
                                    void* stream) {
   PG_REQUIRE(W && Wt && Cout > 0 && Cin > 0, "pg_repack_small_cin: bad arguments");
   const int n = KH * KW * Cout * Cin;
-  hipLaunchKernelGGL(pg::repack_small_cin_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, KH * KW, Cout,
+  PG_KLAUNCH(pg::repack_small_cin_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, KH * KW, Cout,
                      Cin, Wt);
   PG_LAUNCH_OK("pg_repack_small_cin");
   return 0;
@@ -456,8 +456,8 @@ extern "C" int pg_small_cin_conv(const pg_src_t* src, int32_t nsrc, int32_t N, i
   k.Wt = Wt; k.bias = bias; k.out = out;
   k.tiles_x = (k.Wo + 15) / 16; k.tiles_y = (k.Ho + 7) / 8;
   dim3 grid((unsigned)(k.tiles_x * k.tiles_y * N));
-  if (K == 3) hipLaunchKernelGGL((pg::small_cin_conv_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL((pg::small_cin_conv_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, k);
+  if (K == 3) PG_KLAUNCH((pg::small_cin_conv_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, k);
+  else PG_KLAUNCH((pg::small_cin_conv_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_small_cin_conv");
   return 0;
 }
@@ -546,8 +546,8 @@ extern "C" int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, in
   k.N = N; k.Ho = Ho; k.Wo = Wo; k.Hi = Hi; k.Wi = Wi; k.K = K; k.S = stride; k.pad = pad; k.Cin = Cin; k.c_off = c_off; k.nc = nc;
   long blocks = ((long)N * Hi * Wi + 15) / 16;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (K == 3) hipLaunchKernelGGL((pg::small_cin_dgrad_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL((pg::small_cin_dgrad_kernel<4, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  if (K == 3) PG_KLAUNCH((pg::small_cin_dgrad_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  else PG_KLAUNCH((pg::small_cin_dgrad_kernel<4, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_small_cin_dgrad");
   return 0;
 }

@@ -375,9 +375,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
 
 // launch helper used by conv_impl (igemm_conv.hip)
 void launch_conv_bf16_big(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
-  if (bn == 256) hipLaunchKernelGGL((conv_bf16_big_kernel<256>), grid, dim3(512), 0, st, k);
-  else if (bn == 64) hipLaunchKernelGGL((conv_bf16_big_kernel<64>), grid, dim3(512), 0, st, k);
-  else hipLaunchKernelGGL((conv_bf16_big_kernel<128>), grid, dim3(512), 0, st, k);
+  if (bn == 256) PG_KLAUNCH((conv_bf16_big_kernel<256>), grid, dim3(512), 0, st, k);
+  else if (bn == 64) PG_KLAUNCH((conv_bf16_big_kernel<64>), grid, dim3(512), 0, st, k);
+  else PG_KLAUNCH((conv_bf16_big_kernel<128>), grid, dim3(512), 0, st, k);
 }
 
 }  // namespace pg

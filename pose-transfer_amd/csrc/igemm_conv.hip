@@ -1423,16 +1423,16 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
 // ------------------------------------------------------------------------------------------- host side
 template <int BM, int BN, int WGM, int WGN>
 static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma, bool nomask, dim3 grid, hipStream_t st) {
-#define PG_LAUNCH(A, B) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B>), grid, dim3(256), 0, st, k)
+#define PG_CFG_LAUNCH(A, B) PG_KLAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, A, B>), grid, dim3(256), 0, st, k)
 #define PG_LAUNCH_LP(A, B, P) \
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A, B, P>), grid, dim3(256), 0, st, k)
+  PG_KLAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, A, B, P>), grid, dim3(256), 0, st, k)
   if constexpr (WGN == 2) {
     if (prec == PG_PREC_BF16_DATA) {                                        // bf16 tensors, DMA loaders
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NT, 3>), grid, dim3(256), 0, st, k);
+      PG_KLAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NT, 3>), grid, dim3(256), 0, st, k);
       return;
     }
     if (dma && prec == PG_PREC_F32 && amode == A_VEC && bmode == B_NN) {     // LDS-DMA loaders (pure operands)
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NN, 0, 1>), grid, dim3(256), 0, st, k);
+      PG_KLAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NN, 0, 1>), grid, dim3(256), 0, st, k);
       return;
     }
   }
@@ -1446,14 +1446,14 @@ static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma,
     }
   }
   if (nomask && prec == PG_PREC_F32 && amode == A_VEC && bmode == B_NT)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NT, 0, 0, 1>), grid, dim3(256), 0, st, k);
+    PG_KLAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NT, 0, 0, 1>), grid, dim3(256), 0, st, k);
   else if (nomask && prec == PG_PREC_F32 && amode == A_VEC && bmode == B_NN)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NN, 0, 0, 1>), grid, dim3(256), 0, st, k);
-  else if (amode == A_VEC && bmode == B_NT) PG_LAUNCH(A_VEC, B_NT);
-  else if (amode == A_VEC && bmode == B_NN) PG_LAUNCH(A_VEC, B_NN);
-  else if (amode == A_VEC && bmode == B_SCALAR) PG_LAUNCH(A_VEC, B_SCALAR);
-  else PG_LAUNCH(A_SCALAR, B_SCALAR);
-#undef PG_LAUNCH
+    PG_KLAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, A_VEC, B_NN, 0, 0, 1>), grid, dim3(256), 0, st, k);
+  else if (amode == A_VEC && bmode == B_NT) PG_CFG_LAUNCH(A_VEC, B_NT);
+  else if (amode == A_VEC && bmode == B_NN) PG_CFG_LAUNCH(A_VEC, B_NN);
+  else if (amode == A_VEC && bmode == B_SCALAR) PG_CFG_LAUNCH(A_VEC, B_SCALAR);
+  else PG_CFG_LAUNCH(A_SCALAR, B_SCALAR);
+#undef PG_CFG_LAUNCH
 #undef PG_LAUNCH_LP
 }
 
@@ -1692,11 +1692,11 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
       PG_REQUIRE(d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
                  d->oN == (long)d->Ho * d->Wo * k.n_cnt,
                  "pg_conv: split-K needs a dense NHWC output");
-      PG_HIP(hipMemsetAsync(d->out, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * k.n_cnt * (tb ? tb->gtaps : 1), st));
+      PG_MEMSET_ASYNC(d->out, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * k.n_cnt * (tb ? tb->gtaps : 1), st);
     } else {
       for (int j = 0; j < d->ndst; ++j)
         if (!d->dst[j].accumulate)
-          PG_HIP(hipMemsetAsync(d->dst[j].grad, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * d->dst[j].C, st));
+          PG_MEMSET_ASYNC(d->dst[j].grad, 0, sizeof(float) * (size_t)d->N * d->Ho * d->Wo * d->dst[j].C, st);
     }
   }
   // LDS-DMA loaders: the A operand must need no prologue (one source, no deferred affine / mask / activation)
@@ -1750,7 +1750,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     long bx = (items + 511) / 512;
     if (bx < 1) bx = 1;
     if (bx > 128) bx = 128;
-    hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)bx, (unsigned)d->N), dim3(256), 0, st, f);
+    PG_KLAUNCH(splitk_fixup_kernel, dim3((unsigned)bx, (unsigned)d->N), dim3(256), 0, st, f);
     PG_LAUNCH_OK("pg_conv (split-K fixup)");
     return 0;
   }

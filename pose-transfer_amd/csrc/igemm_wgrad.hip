@@ -648,7 +648,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   k.ksplit = ks;
   dim3 grid(nt, mt, k.ntaps * ks);
 #define PG_WG(BM, WGM, WGN, WGK, XS, YS) \
-  hipLaunchKernelGGL((wgrad_igemm_kernel<BM, 64, WGM, WGN, WGK, XS, YS>), grid, dim3(256), 0, st, k)
+  PG_KLAUNCH((wgrad_igemm_kernel<BM, 64, WGM, WGN, WGK, XS, YS>), grid, dim3(256), 0, st, k)
   // compile-time geometry / mask variants of the pipelined kernels (per-sample affines from an LDS table)
   bool any_mask = false;
   for (int j = 0; j < d->nsrc; ++j) any_mask |= d->src[j].mask != nullptr;
@@ -658,16 +658,16 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
 #define PG_WG_SPEC(BM, BN)                                                                                             \
   do {                                                                                                                 \
     if (d->x_is_large) {                                                                                               \
-      if (any_mask) hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 1, 1>), grid, dim3(256), 0, st, k);  \
-      else hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 1, 0>), grid, dim3(256), 0, st, k);           \
+      if (any_mask) PG_KLAUNCH((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 1, 1>), grid, dim3(256), 0, st, k);  \
+      else PG_KLAUNCH((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 1, 0>), grid, dim3(256), 0, st, k);           \
     } else {                                                                                                           \
-      if (any_mask) hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 0, 1>), grid, dim3(256), 0, st, k);  \
-      else hipLaunchKernelGGL((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 0, 0>), grid, dim3(256), 0, st, k);           \
+      if (any_mask) PG_KLAUNCH((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 0, 1>), grid, dim3(256), 0, st, k);  \
+      else PG_KLAUNCH((wgrad_igemm_kernel<BM, BN, 2, 2, 1, 0, 0, 0, 0>), grid, dim3(256), 0, st, k);           \
     }                                                                                                                  \
   } while (0)
   if (cfg == 3) {
     if (spec) PG_WG_SPEC(128, 128);
-    else hipLaunchKernelGGL((wgrad_igemm_kernel<128, 128, 2, 2, 1, 0, 0>), grid, dim3(256), 0, st, k);
+    else PG_KLAUNCH((wgrad_igemm_kernel<128, 128, 2, 2, 1, 0, 0>), grid, dim3(256), 0, st, k);
   } else if (cfg == 0 && spec) {
     PG_WG_SPEC(128, 64);
   } else if (cfg == 0) {
@@ -675,7 +675,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
     PG_WG(128, 2, 2, 1, 0, 0);
   } else if (cfg == 1) {
     PG_REQUIRE(!ys, "pg_conv_wgrad: scalar dY needs Cout<=32");
-    if (narrow) hipLaunchKernelGGL((wgrad_igemm_kernel<64, 32, 2, 1, 2, 1, 0>), grid, dim3(256), 0, st, k);
+    if (narrow) PG_KLAUNCH((wgrad_igemm_kernel<64, 32, 2, 1, 2, 1, 0>), grid, dim3(256), 0, st, k);
     else if (xs) PG_WG(64, 2, 2, 1, 1, 0);
     else PG_WG(64, 2, 2, 1, 0, 0);
   } else {
@@ -765,14 +765,14 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
     // every workgroup ends with C float atomics on the SAME C addresses: measured ~90 ns per workgroup, serialised
     // (2048 workgroups: 106 us for a 67 MB tensor; 96: 21 us = 3.2 TB/s with eight 16-byte loads in flight per lane)
     if (blocks > 96) blocks = 96;
-    hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
+    PG_KLAUNCH(pg::bias_grad_nhwc_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
     PG_LAUNCH_OK("pg_bias_grad");
     return 0;
   }
   int slices = (int)((rows + 256 * 16 - 1) / (256 * 16));
   if (slices > 64) slices = 64;
   if (slices < 1) slices = 1;
-  hipLaunchKernelGGL(pg::bias_grad_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, dY, (long)rows_outer,
+  PG_KLAUNCH(pg::bias_grad_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, dY, (long)rows_outer,
                      (long)rows_inner, C, (long)s_outer, (long)s_inner, (long)sC, db);
   PG_LAUNCH_OK("pg_bias_grad");
   return 0;
@@ -785,7 +785,7 @@ extern "C" int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, f
   const int ppb = 256 / (C / 4);
   long blocks = (npix + (long)ppb * 16 - 1) / ((long)ppb * 16);
   if (blocks > 96) blocks = 96;
-  hipLaunchKernelGGL(pg::bias_grad_nhwc_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+  PG_KLAUNCH(pg::bias_grad_nhwc_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float*>(dY_bf16), (long)npix, C, db);
   PG_LAUNCH_OK("pg_bias_grad_bf16");
   return 0;

@@ -361,7 +361,7 @@ template <int AREA>
 static int launch_nn_tile64(const float* P, const float* G, int N, int H, int W, float scale, int relu_mask, float* loss, float* dP,
                             hipStream_t st) {
   const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
-  hipLaunchKernelGGL(nn_loss_tile64_kernel<AREA>, dim3((unsigned)(tiles_x * tiles_y * N)), dim3(256), 0, st, P, G, N, H, W, scale,
+  PG_KLAUNCH(nn_loss_tile64_kernel<AREA>, dim3((unsigned)(tiles_x * tiles_y * N)), dim3(256), 0, st, P, G, N, H, W, scale,
                      relu_mask, tiles_x, tiles_y, loss, dP);
   return 0;
 }
@@ -373,7 +373,7 @@ using namespace pg;
 extern "C" int pg_gan_logloss(const float* logits, int64_t count, int32_t mode, float scale, float* loss,
                               float* dlogits, float* sig, void* stream) {
   PG_REQUIRE(logits && count > 0 && (mode == 0 || mode == 1), "pg_gan_logloss: bad arguments");
-  hipLaunchKernelGGL(gan_logloss_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, logits, (long)count,
+  PG_KLAUNCH(gan_logloss_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, logits, (long)count,
                      mode, scale, loss, dlogits, sig);
   PG_LAUNCH_OK("pg_gan_logloss");
   return 0;
@@ -382,7 +382,7 @@ extern "C" int pg_gan_logloss(const float* logits, int64_t count, int32_t mode, 
 extern "C" int pg_l1_loss(const float* pred, const float* target, int64_t count, float scale, float* loss, float* gout,
                           int32_t accumulate, void* stream) {
   PG_REQUIRE(pred && target && count > 0, "pg_l1_loss: bad arguments");
-  hipLaunchKernelGGL(l1_loss_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, pred, target,
+  PG_KLAUNCH(l1_loss_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, pred, target,
                      (long)count, scale, loss, gout, accumulate);
   PG_LAUNCH_OK("pg_l1_loss");
   return 0;
@@ -390,7 +390,7 @@ extern "C" int pg_l1_loss(const float* pred, const float* target, int64_t count,
 
 extern "C" int pg_tanh_bwd(float* g, const float* out, int64_t count, void* stream) {
   PG_REQUIRE(g && out && count > 0, "pg_tanh_bwd: bad arguments");
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, g, out, (long)count);
+  PG_KLAUNCH(tanh_bwd_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, g, out, (long)count);
   PG_LAUNCH_OK("pg_tanh_bwd");
   return 0;
 }
@@ -403,12 +403,12 @@ extern "C" int pg_vgg_conv1_relu_fwd(const float* x, const float* w, const float
     const long npix = (long)N * H * W;
     long blocks = (npix + 15) / 16;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(vgg_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, N, H, W, feat);
+    PG_KLAUNCH(vgg_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, N, H, W, feat);
   } else {
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     long blocks = (long)tiles_x * tiles_y * N;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(vgg_fwd_tile_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, N, H, W, tiles_x,
+    PG_KLAUNCH(vgg_fwd_tile_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, N, H, W, tiles_x,
                        tiles_y, feat);
   }
   PG_LAUNCH_OK("pg_vgg_conv1_relu_fwd");
@@ -421,7 +421,7 @@ extern "C" int pg_vgg_conv1_dgrad(const float* dfeat, const float* w, int32_t N,
   const long npix = (long)N * H * W;
   long blocks = (npix + 15) / 16;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(vgg_dgrad_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dfeat, w, N, H, W, gout);
+  PG_KLAUNCH(vgg_dgrad_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dfeat, w, N, H, W, gout);
   PG_LAUNCH_OK("pg_vgg_conv1_dgrad");
   return 0;
 }
@@ -435,7 +435,7 @@ extern "C" int pg_nn_loss(const float* P, const float* G, int32_t N, int32_t H, 
   {                                                                                                    \
     long blocks = (npix + (256 / LPP) - 1) / (256 / LPP);                                              \
     if (blocks > 8192) blocks = 8192;                                                                  \
-    hipLaunchKernelGGL(nn_loss_kernel<LPP>, dim3((int)blocks), dim3(256), 0, st, P, G, N, H, W, area,  \
+    PG_KLAUNCH(nn_loss_kernel<LPP>, dim3((int)blocks), dim3(256), 0, st, P, G, N, H, W, area,  \
                        scale, relu_mask, loss, dP);                                                    \
   }
   if (C == 64 && (area == 3 || area == 5 || area == 7) && getenv("PG_NN_LOSS_V1") == nullptr) {

@@ -201,7 +201,7 @@ using namespace pg;
 extern "C" int pg_norm_stats(const float* y, int32_t N, int64_t L, double* sums, void* stream) {
   PG_REQUIRE(y && sums && N > 0 && L > 0, "pg_norm_stats: bad arguments");
   PG_REQUIRE(L % 4 == 0, "pg_norm_stats: per-sample length must be a multiple of 4 (float4 path)");
-  hipLaunchKernelGGL(norm_stats_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, y, (long)L, sums);
+  PG_KLAUNCH(norm_stats_kernel, dim3(norm_blocks(L), N), dim3(256), 0, (hipStream_t)stream, y, (long)L, sums);
   PG_LAUNCH_OK("pg_norm_stats");
   return 0;
 }
@@ -209,7 +209,7 @@ extern "C" int pg_norm_stats(const float* y, int32_t N, int64_t L, double* sums,
 extern "C" int pg_norm_finalize(const double* sums, const float* gamma, const float* beta, int32_t N, int64_t L,
                                 float eps, float* mr, float* aff, void* stream) {
   PG_REQUIRE(sums && gamma && beta && mr && aff && N > 0, "pg_norm_finalize: bad arguments");
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, N,
+  PG_KLAUNCH(norm_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, N,
                      (long)L, eps, mr, aff);
   PG_LAUNCH_OK("pg_norm_finalize");
   return 0;
@@ -223,9 +223,9 @@ extern "C" int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float*
   typedef unsigned short bf;
   hipStream_t st = (hipStream_t)stream;
   if (io_flags == 0)
-    hipLaunchKernelGGL((norm_bwd_reduce_kernel<float>), dim3(norm_blocks_bwd(L, N, 4), N), dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums);
+    PG_KLAUNCH((norm_bwd_reduce_kernel<float>), dim3(norm_blocks_bwd(L, N, 4), N), dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums);
   else
-    hipLaunchKernelGGL((norm_bwd_reduce_kernel<bf>), dim3(norm_blocks_bwd(L, N, 8), N), dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums);
+    PG_KLAUNCH((norm_bwd_reduce_kernel<bf>), dim3(norm_blocks_bwd(L, N, 8), N), dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums);
   PG_LAUNCH_OK("pg_norm_bwd_reduce");
   return 0;
 }
@@ -244,9 +244,9 @@ extern "C" int pg_norm_bwd_apply_io(void* dz, const void* y, const float* mr, co
   typedef unsigned short bf;
   hipStream_t st = (hipStream_t)stream;
   if (io_flags == 0)
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(norm_blocks(L, 4), N), dim3(256), 0, st, (float*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
+    PG_KLAUNCH((norm_bwd_apply_kernel<float>), dim3(norm_blocks(L, 4), N), dim3(256), 0, st, (float*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
   else
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf>), dim3(norm_blocks(L, 8), N), dim3(256), 0, st, (bf*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
+    PG_KLAUNCH((norm_bwd_apply_kernel<bf>), dim3(norm_blocks(L, 8), N), dim3(256), 0, st, (bf*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
   PG_LAUNCH_OK("pg_norm_bwd_apply");
   return 0;
 }

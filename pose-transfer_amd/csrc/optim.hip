@@ -144,7 +144,7 @@ extern "C" int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
   long blocks = (n / 4 + 255) / 256;
   { static const long cap = getenv("PG_ADAM_CAP") ? atol(getenv("PG_ADAM_CAP")) : 131072; if (blocks > cap) blocks = cap; }
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, b1, b2,
+  PG_KLAUNCH(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, b1, b2,
                      eps, step_size, bc2_sqrt, grad_scale);
   PG_LAUNCH_OK("pg_adam");
   return 0;
@@ -158,7 +158,7 @@ extern "C" int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m
   const unsigned short* gb = reinterpret_cast<const unsigned short*>(g_bf16);
   unsigned short* pb = reinterpret_cast<unsigned short*>(p_bf16);
 #define PG_ADAM_EX(G, W)                                                                                               \
-  hipLaunchKernelGGL((adam_ex_kernel<G, W>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, gb, m, v, (long)n, \
+  PG_KLAUNCH((adam_ex_kernel<G, W>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, gb, m, v, (long)n, \
                      b1, b2, eps, step_size, bc2_sqrt, grad_scale, pb)
   if (gb && pb) PG_ADAM_EX(true, true);
   else if (gb) PG_ADAM_EX(true, false);
@@ -171,7 +171,7 @@ extern "C" int pg_adam_ex(float* p, const float* g, const void* g_bf16, float* m
 
 extern "C" int pg_dropout_mask(float* out, int64_t n, uint64_t key, float p, void* stream) {
   PG_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f, "pg_dropout_mask: bad arguments");
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
+  PG_KLAUNCH(dropout_mask_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
                      (unsigned long long)key, p);
   PG_LAUNCH_OK("pg_dropout_mask");
   return 0;
@@ -180,7 +180,7 @@ extern "C" int pg_dropout_mask(float* out, int64_t n, uint64_t key, float p, voi
 extern "C" int pg_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
   PG_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "pg_nchw_to_nhwc: bad arguments");
   const int rows = C, cols = H * W;
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, (hipStream_t)stream,
+  PG_KLAUNCH(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, (hipStream_t)stream,
                      src, dst, rows, cols);
   PG_LAUNCH_OK("pg_nchw_to_nhwc");
   return 0;
@@ -189,7 +189,7 @@ extern "C" int pg_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t 
 extern "C" int pg_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
   PG_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "pg_nhwc_to_nchw: bad arguments");
   const int rows = H * W, cols = C;
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, (hipStream_t)stream,
+  PG_KLAUNCH(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, N), dim3(256), 0, (hipStream_t)stream,
                      src, dst, rows, cols);
   PG_LAUNCH_OK("pg_nhwc_to_nchw");
   return 0;
@@ -200,7 +200,7 @@ extern "C" int pg_apply_affine_act(const float* x, const float* aff, const float
   PG_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "pg_apply_affine_act: bad arguments");
   long blocks = (HW * C + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(affine_act_kernel, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
+  PG_KLAUNCH(affine_act_kernel, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
                      (long)HW, C, y);
   PG_LAUNCH_OK("pg_apply_affine_act");
   return 0;
@@ -286,10 +286,10 @@ extern "C" int pg_materialise_bf16_ex(const void* x, int32_t x_is_bf16, const fl
   long blocks = (HW * C / 8 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (x_is_bf16)
-    hipLaunchKernelGGL(pg::materialise_bf16_kernel<true>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
+    PG_KLAUNCH(pg::materialise_bf16_kernel<true>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
                        (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2);
   else
-    hipLaunchKernelGGL(pg::materialise_bf16_kernel<false>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
+    PG_KLAUNCH(pg::materialise_bf16_kernel<false>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
                        (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2);
   PG_LAUNCH_OK("pg_materialise_bf16");
   return 0;
@@ -303,7 +303,7 @@ extern "C" int pg_materialise_bf16(const float* x, const float* aff, const float
 extern "C" int pg_weights_to_bf16(const float* W, int32_t taps, int32_t Cout, int32_t Cin, void* nt_bf16, void* t_bf16,
                                   void* stream) {
   PG_REQUIRE(W && (nt_bf16 || t_bf16) && taps > 0 && Cout > 0 && Cin > 0, "pg_weights_to_bf16: bad arguments");
-  hipLaunchKernelGGL(pg::weights_to_bf16_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, taps), dim3(256), 0,
+  PG_KLAUNCH(pg::weights_to_bf16_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, taps), dim3(256), 0,
                      (hipStream_t)stream, W, Cout, Cin, reinterpret_cast<unsigned short*>(nt_bf16),
                      reinterpret_cast<unsigned short*>(t_bf16));
   PG_LAUNCH_OK("pg_weights_to_bf16");
@@ -375,7 +375,7 @@ extern "C" int pg_channel_major_bf16(const float* x, const float* aff, const flo
   PG_REQUIRE(x && out_bf16 && N > 0 && C > 0 && C % 4 == 0 && (sub == 1 || sub == 2) && Wp >= Wq + 2 && Wp % 8 == 0 && K % 64 == 0 &&
              K >= (int64_t)N * (Hq + 2) * Wp && K < (1LL << 31) && ((size_t)out_bf16 & 15) == 0,
              "pg_channel_major_bf16: bad geometry (Wp %% 8 == 0, K %% 64 == 0, K >= N*(Hq+2)*Wp)");
-  hipLaunchKernelGGL(pg::channel_major_bf16_kernel, dim3((unsigned)(K / 64), (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+  PG_KLAUNCH(pg::channel_major_bf16_kernel, dim3((unsigned)(K / 64), (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      x, aff, mask, act, N, H, W, C, sub, py, px, Hq, Wq, Wp, (long)K, reinterpret_cast<unsigned short*>(out_bf16));
   PG_LAUNCH_OK("pg_channel_major_bf16");
   return 0;
@@ -387,7 +387,7 @@ __global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long i
 
 extern "C" int pg_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {
   PG_REQUIRE(ctr, "pg_counter_add: null counter");
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(ctr),
+  PG_KLAUNCH(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(ctr),
                      (unsigned long long)inc);
   PG_LAUNCH_OK("pg_counter_add");
   return 0;
@@ -395,7 +395,7 @@ extern "C" int pg_counter_add(uint64_t* ctr, uint64_t inc, void* stream) {
 
 extern "C" int pg_dropout_mask_ctr(float* out, int64_t n, uint64_t key, float p, const uint64_t* ctr, void* stream) {
   PG_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f && ctr, "pg_dropout_mask_ctr: bad arguments");
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
+  PG_KLAUNCH(dropout_mask_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n,
                      (unsigned long long)key, p, reinterpret_cast<const unsigned long long*>(ctr));
   PG_LAUNCH_OK("pg_dropout_mask_ctr");
   return 0;
@@ -410,7 +410,7 @@ extern "C" int pg_adam_ctr(float* p, const float* g, const void* g_bf16, float* 
   unsigned short* pb = reinterpret_cast<unsigned short*>(p_bf16);
   const unsigned long long* c = reinterpret_cast<const unsigned long long*>(ctr);
 #define PG_ADAM_CTR(G, W)                                                                                              \
-  hipLaunchKernelGGL((adam_ex_kernel<G, W>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, gb, m, v, (long)n, \
+  PG_KLAUNCH((adam_ex_kernel<G, W>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, gb, m, v, (long)n, \
                      (float)b1, (float)b2, eps, lr, 1.0f, grad_scale, pb, c, (long)step0, b1, b2)
   if (gb && pb) PG_ADAM_CTR(true, true);
   else if (gb) PG_ADAM_CTR(true, false);
@@ -431,7 +431,7 @@ extern "C" int pg_add2(float* out, const float* a, const float* b, int64_t n, vo
   PG_REQUIRE(out && a && b && n > 0, "pg_add2: bad arguments");
   long blocks = (n + 255) / 256;
   { static const long cap = getenv("PG_ADAM_CAP") ? atol(getenv("PG_ADAM_CAP")) : 131072; if (blocks > cap) blocks = cap; }
-  hipLaunchKernelGGL(add2_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, a, b, (long)n);
+  PG_KLAUNCH(add2_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, a, b, (long)n);
   PG_LAUNCH_OK("pg_add2");
   return 0;
 }

@@ -249,8 +249,8 @@ extern "C" int pg_out_conv_dgrad(const float* G, const float* Wt, int32_t N, int
     if (dst[j].flags != 0) { PG_REQUIRE((dst[j].flags & want) == want, "pg_out_conv_dgrad: a destination mixes fp32 and bf16 tensors"); ++nbf; }
   }
   PG_REQUIRE(nbf == 0 || nbf == ndst, "pg_out_conv_dgrad: destinations must be all fp32 or all bf16");
-  if (nbf) hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<true, false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  if (nbf) PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  else PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad");
   return 0;
 }
@@ -294,8 +294,8 @@ extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const f
   long blocks = (k.npix + 15) / 16;
   if (blocks > 256 * 12) blocks = 256 * 12;
   hipStream_t st = (hipStream_t)stream, wst = wg_stream ? (hipStream_t)wg_stream : st;
-  if (g_is_dpre) hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<true, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, k);
-  else hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<true, false, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, k);
+  if (g_is_dpre) PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, k);
+  else PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (data gradient)");
   blocks = (k.npix + 15) / 16;
   long cap = workspace_floats / ((long)c * 28);
@@ -303,10 +303,10 @@ extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const f
   PG_REQUIRE(cap >= 64, "pg_out_conv_dgrad_wgrad: workspace too small");
   if (blocks > cap) blocks = cap;
   k.wpart = workspace;
-  if (g_is_dpre) hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<false, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
-  else hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<false, true, true, false>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
+  if (g_is_dpre) PG_KLAUNCH((pg::out_conv_dgrad_kernel<false, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
+  else PG_KLAUNCH((pg::out_conv_dgrad_kernel<false, true, true, false>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (weight gradient)");
-  hipLaunchKernelGGL(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256), dim3(256), 0, wst, workspace, (int)blocks, c, dW);
+  PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256), dim3(256), 0, wst, workspace, (int)blocks, c, dW);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (reduce)");
   return 0;
 }
@@ -342,9 +342,9 @@ extern "C" int pg_out_conv_wgrad_bf16(const void* G_bf16, int32_t g_pitch, int32
   PG_REQUIRE(cap >= 64, "pg_out_conv_wgrad_bf16: workspace too small");
   if (blocks > cap) blocks = cap;
   k.wpart = workspace;
-  hipLaunchKernelGGL((pg::out_conv_dgrad_kernel<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  PG_KLAUNCH((pg::out_conv_dgrad_kernel<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_out_conv_wgrad_bf16");
-  hipLaunchKernelGGL(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
+  PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
                      (int)blocks, c, dW);
   PG_LAUNCH_OK("pg_out_conv_wgrad_bf16 (reduce)");
   return 0;

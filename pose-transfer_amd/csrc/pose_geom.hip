@@ -329,7 +329,7 @@ using namespace pg;
 
 extern "C" int pg_affine_transforms(const float* kp_from, const float* kp_to, int32_t N, int32_t P, float* out, void* stream) {
   PG_REQUIRE(kp_from && kp_to && out && N > 0 && (P == 16 || P == 18), "pg_affine_transforms: need pose_dim 16 or 18 (got %d)", P);
-  hipLaunchKernelGGL(affine_transforms_kernel, dim3((N * 10 + 63) / 64), dim3(64), 0, (hipStream_t)stream, kp_from, kp_to, N, P,
+  PG_KLAUNCH(affine_transforms_kernel, dim3((N * 10 + 63) / 64), dim3(64), 0, (hipStream_t)stream, kp_from, kp_to, N, P,
                      joint_table(P), out);
   PG_LAUNCH_OK("pg_affine_transforms");
   return 0;
@@ -337,7 +337,7 @@ extern "C" int pg_affine_transforms(const float* kp_from, const float* kp_to, in
 
 extern "C" int pg_uniform_transform(const float* kp_from, const float* kp_to, int32_t N, int32_t P, float* out, void* stream) {
   PG_REQUIRE(kp_from && kp_to && out && N > 0 && (P == 16 || P == 18), "pg_uniform_transform: need pose_dim 16 or 18 (got %d)", P);
-  hipLaunchKernelGGL(uniform_transform_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, kp_from, kp_to, N, P,
+  PG_KLAUNCH(uniform_transform_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, kp_from, kp_to, N, P,
                      joint_table(P), out);
   PG_LAUNCH_OK("pg_uniform_transform");
   return 0;
@@ -347,7 +347,7 @@ extern "C" int pg_pose_masks(const float* kp_to, int32_t N, int32_t P, int32_t H
   PG_REQUIRE(kp_to && out && N > 0 && H > 0 && W > 0 && (P == 16 || P == 18), "pg_pose_masks: need pose_dim 16 or 18 (got %d)", P);
   int bx = (H * W + 255) / 256;
   if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(pose_masks_kernel, dim3(bx, 10, N), dim3(256), 0, (hipStream_t)stream, kp_to, P, H, W, joint_table(P), out);
+  PG_KLAUNCH(pose_masks_kernel, dim3(bx, 10, N), dim3(256), 0, (hipStream_t)stream, kp_to, P, H, W, joint_table(P), out);
   PG_LAUNCH_OK("pg_pose_masks");
   return 0;
 }
@@ -357,7 +357,7 @@ extern "C" int pg_preprocess_image(const uint8_t* img, int32_t N, int32_t H, int
   PG_REQUIRE(img && out && N > 0 && H > 0 && W > 0, "pg_preprocess_image: bad arguments");
   int bx = (H * W + 255) / 256;
   if (bx > 256) bx = 256;
-  hipLaunchKernelGGL(preprocess_image_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, img, H, W, out, (long)oN,
+  PG_KLAUNCH(preprocess_image_kernel, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, img, H, W, out, (long)oN,
                      (long)oC, (long)oH, (long)oW);
   PG_LAUNCH_OK("pg_preprocess_image");
   return 0;

@@ -209,10 +209,10 @@ static int launch_small_cin_wgrad(SmallCinWgK& k, float* ws, long ws_floats, hip
   } else {
     k.part = ws;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)groups), dim3(256), lds, st, k);
+  PG_KLAUNCH(kern, dim3((unsigned)blocks, (unsigned)groups), dim3(256), lds, st, k);
   if (k.part) {
     const int ry = blocks >= 32 ? 16 : 1;
-    hipLaunchKernelGGL(small_cin_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256),
+    PG_KLAUNCH(small_cin_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256),
                        0, st, k.part, blocks, k.npad, K * K * k.Ctot, k.Ctot, k.dW);
   }
   return 0;

@@ -429,7 +429,7 @@ static int launch_stem_conv(StemK& k, hipStream_t st) {
   if (per_cu > 4) per_cu = 4;
   int blocks = stem_cu_count() * per_cu;
   if (blocks > k.ntiles) blocks = k.ntiles;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, st, k);
+  PG_KLAUNCH(kern, dim3((unsigned)blocks), dim3(256), LDS, st, k);
   return 0;
 }
 
@@ -460,9 +460,9 @@ static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hip
     if (ws == nullptr || blocks < 1) return -2;
   }
   k.part = ws;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), LDS, st, k);
+  PG_KLAUNCH(kern, dim3((unsigned)blocks), dim3(NW * 64), LDS, st, k);
   const int ry = blocks >= 32 ? 16 : 1;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256), 0, st, k.part,
+  PG_KLAUNCH(stem_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256), 0, st, k.part,
                      blocks, k.npad, K * K, CP, k.Ctot, dW);
   return 0;
 }
@@ -481,7 +481,7 @@ extern "C" int pg_stem_pack_bf16(const float* W, int32_t K, int32_t Cin, uint16_
   PG_REQUIRE(W && Wp && (K == 3 || K == 4) && Cin > 0 && Cin <= 80, "pg_stem_pack_bf16: bad arguments (K=%d Cin=%d)", K, Cin);
   const int CG = pg_stem_group_channels(Cin), ng = (Cin + CG - 1) / CG;
   const long total = pg_stem_pack_elems(K, Cin);
-  hipLaunchKernelGGL(pg::stem_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin, CG,
+  PG_KLAUNCH(pg::stem_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin, CG,
                      ng, Wp);
   PG_LAUNCH_OK("pg_stem_pack_bf16");
   return 0;

@@ -567,7 +567,7 @@ extern "C" int pg_cords_to_map(const float* cords, int32_t N, int32_t P, int32_t
   PG_REQUIRE(cords && out && N > 0 && P > 0 && H > 0 && W > 0 && sigma > 0.f, "pg_cords_to_map: bad arguments");
   int bx = (H * W + 255) / 256;
   if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(cords_to_map_kernel, dim3(bx, P, N), dim3(256), 0, (hipStream_t)stream, cords, P, H, W,
+  PG_KLAUNCH(cords_to_map_kernel, dim3(bx, P, N), dim3(256), 0, (hipStream_t)stream, cords, P, H, W,
                      1.0 / (2.0 * (double)sigma * (double)sigma), out, (long)oN, (long)oC, (long)oH, (long)oW);
   PG_LAUNCH_OK("pg_cords_to_map");
   return 0;
@@ -581,10 +581,10 @@ extern "C" int pg_mask_pyramid(const void* masks, int32_t is_f64, int32_t N, int
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (is_f64)
-    hipLaunchKernelGGL(mask_pyramid_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    PG_KLAUNCH(mask_pyramid_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const double*)masks, N, T, H0, W0, h, w, out);
   else
-    hipLaunchKernelGGL(mask_pyramid_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    PG_KLAUNCH(mask_pyramid_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float*)masks, N, T, H0, W0, h, w, out);
   PG_LAUNCH_OK("pg_mask_pyramid");
   return 0;
@@ -616,7 +616,7 @@ extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const
   const int relu = (io_flags & 4) ? 1 : 0;
   if (v1 || cpp > 256 || 256 % cpp != 0 || lds > 64 * 1024 || (double)h * w * C * 4.0 >= 2147483648.0) {
     PG_REQUIRE(io_flags == 0, "pg_warp_mask_max_fwd: bf16 storage needs the tiled kernel (C / 4 must divide 256)");
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, (const float*)feat, aff, warps,
+    PG_KLAUNCH(warp_fwd_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, (const float*)feat, aff, warps,
                        lvl_masks, T, C, h, w, H0, W0, align_corners, (float*)out, argmax);
   } else {
     int tp = 64;
@@ -627,7 +627,7 @@ extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const
     const dim3 grid((unsigned)tiles, N);
     hipStream_t st = (hipStream_t)stream;
 #define PGW_FWD(IB_, OB_)                                                                                                     \
-  hipLaunchKernelGGL((warp_fwd3_kernel<IB_, OB_>), grid, dim3(256), lds, st, feat, aff, warps, lvl_masks, T, C, h, w, H0, W0, \
+  PG_KLAUNCH((warp_fwd3_kernel<IB_, OB_>), grid, dim3(256), lds, st, feat, aff, warps, lvl_masks, T, C, h, w, H0, W0, \
                      align_corners, tp, out, argmax, relu)
     if (ib && ob) PGW_FWD(true, true);
     else if (ib) PGW_FWD(true, false);
@@ -655,10 +655,10 @@ extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, 
   hipStream_t st = (hipStream_t)stream;
 #define PGW_BWD(KERNEL, GRID, ...)                                                                   \
   do {                                                                                               \
-    if (gb && db) hipLaunchKernelGGL((KERNEL<true, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
-    else if (gb) hipLaunchKernelGGL((KERNEL<true, false>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
-    else if (db) hipLaunchKernelGGL((KERNEL<false, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
-    else hipLaunchKernelGGL((KERNEL<false, false>), GRID, dim3(256), 0, st, __VA_ARGS__);            \
+    if (gb && db) PG_KLAUNCH((KERNEL<true, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else if (gb) PG_KLAUNCH((KERNEL<true, false>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else if (db) PG_KLAUNCH((KERNEL<false, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
+    else PG_KLAUNCH((KERNEL<false, false>), GRID, dim3(256), 0, st, __VA_ARGS__);            \
   } while (0)
   if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM) {
     // gather kernel OVERWRITES dfeat (narrow transforms), then the scatter kernel adds the wide ones
@@ -673,7 +673,7 @@ extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, 
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (wide transforms)");
     return 0;
   }
-  PG_HIP(hipMemsetAsync(dfeat, 0, (db ? 2 : 4) * (size_t)N * h * w * C, st));
+  PG_MEMSET_ASYNC(dfeat, 0, (db ? 2 : 4) * (size_t)N * h * w * C, st);
   PGW_BWD(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
 #undef PGW_BWD
   PG_LAUNCH_OK("pg_warp_mask_max_bwd");

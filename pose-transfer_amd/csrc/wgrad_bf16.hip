@@ -615,11 +615,11 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
 #define PGW4_LAUNCH(M_, N_)                                                                                              \
   do {                                                                                                                   \
     if (r2) {                                                                                                            \
-      if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 1, true>), grid4, dim3(512), 0, st, q);        \
-      else hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 0, true>), grid4, dim3(512), 0, st, q);                     \
+      if (k.a_is_small) PG_KLAUNCH((wgrad_bf16_tr4_kernel<M_, N_, 1, true>), grid4, dim3(512), 0, st, q);        \
+      else PG_KLAUNCH((wgrad_bf16_tr4_kernel<M_, N_, 0, true>), grid4, dim3(512), 0, st, q);                     \
     } else {                                                                                                             \
-      if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 1, false>), grid4, dim3(512), 0, st, q);       \
-      else hipLaunchKernelGGL((wgrad_bf16_tr4_kernel<M_, N_, 0, false>), grid4, dim3(512), 0, st, q);                    \
+      if (k.a_is_small) PG_KLAUNCH((wgrad_bf16_tr4_kernel<M_, N_, 1, false>), grid4, dim3(512), 0, st, q);       \
+      else PG_KLAUNCH((wgrad_bf16_tr4_kernel<M_, N_, 0, false>), grid4, dim3(512), 0, st, q);                    \
     }                                                                                                                    \
   } while (0)
       if (tm == 128 && tn == 128) PGW4_LAUNCH(128, 128);
@@ -661,8 +661,8 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   dim3 grid(mt, nt, 16 * ks);
 #define PGW_LAUNCH(M_, N_)                                                                                   \
   do {                                                                                                       \
-    if (k.a_is_small) hipLaunchKernelGGL((wgrad_bf16_tr_kernel<M_, N_, 1>), grid, dim3(512), 0, st, k);      \
-    else hipLaunchKernelGGL((wgrad_bf16_tr_kernel<M_, N_, 0>), grid, dim3(512), 0, st, k);                   \
+    if (k.a_is_small) PG_KLAUNCH((wgrad_bf16_tr_kernel<M_, N_, 1>), grid, dim3(512), 0, st, k);      \
+    else PG_KLAUNCH((wgrad_bf16_tr_kernel<M_, N_, 0>), grid, dim3(512), 0, st, k);                   \
   } while (0)
   if (bm == 256 && bn == 256) PGW_LAUNCH(256, 256);
   else if (bm == 128 && bn == 256) PGW_LAUNCH(128, 256);

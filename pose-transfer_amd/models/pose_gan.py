@@ -167,7 +167,7 @@ class DeformablePose_GAN(nn.Module):
         n, (H, W) = input.shape[0], self.image_size
         input, target = input.contiguous(), target.contiguous()
         self.gen.zero_grad()
-        self._loss[0:3].zero_()
+        E.dev_zero(self._loss[0:3])
         engs, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
         # discriminator on [img, src_pose, out_gen, tgt_pose] — forward + data-gradient only
         deng = self.disc.engine(n)
@@ -224,7 +224,7 @@ class DeformablePose_GAN(nn.Module):
         n = input.shape[0]
         input, real_inp, real_target = input.contiguous(), real_inp.contiguous(), real_target.contiguous()
         self.disc.zero_grad()
-        self._loss[4:7].zero_()
+        E.dev_zero(self._loss[4:7])
         engs, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"), call="d")
         deng = self.disc.engine(2 * n)
         logits = deng.forward([(real_inp, real_target), (input, out_gen)])     # cat((real, fake), 0) — pose_gan.py:136

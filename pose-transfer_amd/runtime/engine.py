@@ -191,7 +191,7 @@ class ParamArena:
                 {k: _unpack(k, mv(self.v, k)) for k, _ in self.spec})
 
     def zero_grad(self):
-        self.grads.zero_()
+        dev_zero(self.grads)
 
     def adam_step(self, lr, b1=0.5, b2=0.999, eps=1e-8, grad_scale=1.0, grads_bf16=None):
         """torch.optim.Adam semantics (reference models/pose_gan.py:50-51); bias corrections in double.
@@ -270,26 +270,34 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
         off = (W.data_ptr() - arena.params.data_ptr()) // 4
         return arena.bf16_params()[off:off + W.numel()]
     if arena is None:
-        # a weight outside any arena (kernel tests, module-level API): convert on every call — a cache keyed by address
-        # would serve stale copies when the allocator reuses the address for a different tensor of the same size
-        buf = torch.empty(W.numel(), dtype=torch.bfloat16, device=W.device)
+        # a weight outside any arena (kernel tests, module-level API, the padded output-conv weight): converted on every call
+        # into a buffer that lives as long as the weight tensor does (stable pointers: launch tape / HIP graph; a cache of
+        # CONTENTS keyed by address would serve stale copies when the allocator reuses the address)
+        keep = _BF_W_EXT.get((W.data_ptr(), W.numel(), bool(transposed)))
+        if keep is None or keep[0]() is not W:
+            keep = (weakref.ref(W), torch.empty(W.numel(), dtype=torch.bfloat16, device=W.device))
+            _BF_W_EXT[(W.data_ptr(), W.numel(), bool(transposed))] = keep
+        buf = keep[1]
         L.call("pg_weights_to_bf16", L.ptr(W), taps, Cout, Cin, None if transposed else L.ptr(buf),
                L.ptr(buf) if transposed else None, L.stream())
         return buf
     key = (W.data_ptr(), W.numel())
     ver = arena.version()
     ent = _BF_W.get(key)
-    if ent is None or ent[0] != ver:
-        ent = _BF_W[key] = [ver, None, None]
-    idx = 2 if transposed else 1
-    if ent[idx] is None:
-        buf = torch.empty(W.numel(), dtype=torch.bfloat16, device=W.device)
+    if ent is None:
+        ent = _BF_W[key] = [-1, -1, None, None]          # versions of the [nt, t] copies, their (persistent) buffers
+    idx = 1 if transposed else 0
+    if ent[2 + idx] is None:
+        ent[2 + idx] = torch.empty(W.numel(), dtype=torch.bfloat16, device=W.device)
+    if ent[idx] != ver:
+        buf = ent[2 + idx]
         L.call("pg_weights_to_bf16", L.ptr(W), taps, Cout, Cin, None if transposed else L.ptr(buf),
                L.ptr(buf) if transposed else None, L.stream())
-        ent[idx] = buf
-    return ent[idx]
+        ent[idx] = ver
+    return ent[2 + idx]
 
 
+_BF_W_EXT = {}              # (data_ptr, numel, transposed) -> (weakref to the weight tensor, its bf16 buffer)
 # bf16 STORAGE (round 3): on the bf16 data path the GENERATOR keeps its raw activations and the gradients flowing through
 # them as bf16 tensors (PG_NO_BF16_STORE=1: fp32 storage as in round 2).  Kernels that take raw device pointers learn the
 # dtype from this registry (data_ptr -> tensor) or from per-descriptor flags (lib.make_dst, pg_conv_t.out_bf16).
@@ -535,6 +543,27 @@ SIDE_STREAM = os.environ.get("PG_NO_SIDE_STREAM") is None
 _SIDE = {}
 
 
+def _raw(stream):
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+def dev_zero(t):
+    """t.zero_() as a library call (stream-ordered on torch's current stream; recorded on a launch tape)"""
+    if not t.is_cuda:
+        t.zero_()
+        return
+    L.call("pg_zero", L.ptr(t), t.numel() * t.element_size(), L.stream())
+
+
+def dev_copy(dst, src):
+    """dst.copy_(src) for equal dtype / contiguous tensors as a library call; anything else goes through torch"""
+    if (dst.is_cuda and dst.dtype == src.dtype and dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+            and dst.device == src.device):
+        L.call("pg_copy", L.ptr(dst), L.ptr(src), dst.numel() * dst.element_size(), L.stream())
+    else:
+        dst.copy_(src.reshape(dst.shape) if src.numel() == dst.numel() else src)
+
+
 def _side_stream():
     dev = torch.cuda.current_device()
     st = _SIDE.get(dev)
@@ -546,7 +575,7 @@ def _side_stream():
 def _join_side():
     """main stream waits for everything enqueued on the side stream so far."""
     if SIDE_STREAM and _SIDE.get(torch.cuda.current_device()) is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
+        L.call("pg_stream_wait", L.stream(), _raw(_SIDE[torch.cuda.current_device()]))
 
 
 OUT_CONV_STREAM = os.environ.get("PG_NO_OUT_CONV_STREAM") is None   # ablation switch: K=32 pg_conv launch instead
@@ -689,7 +718,7 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
         return _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x,
                            y_strides, ksplit, cout_store, dyb)
     side = _side_stream()
-    side.wait_stream(torch.cuda.current_stream())
+    L.call("pg_stream_wait", _raw(side), L.stream())
     with torch.cuda.stream(side):
         _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x, y_strides,
                     ksplit, cout_store, dyb)
@@ -800,13 +829,13 @@ class NormState:
     def stats_target(self):
         """The (zeroed) statistics buffer a producing pg_conv accumulates into (pg_conv_t.stats)."""
         if not self.shared:
-            self.sums.zero_()
+            dev_zero(self.sums)
         return self.sums
 
     def forward(self, y, N, Lr, gamma, beta, have_stats=False):
         if not have_stats:
             if not self.shared:
-                self.sums.zero_()
+                dev_zero(self.sums)
             L.call("pg_norm_stats", L.ptr(y), N, Lr, L.ptr(self.sums), L.stream())
         L.call("pg_norm_finalize", L.ptr(self.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(self.mr),
                L.ptr(self.aff), L.stream())
@@ -816,7 +845,7 @@ class NormState:
         writes dy as the bf16 operand the data- / weight-gradient contractions of this layer will ask the pass's operand
         cache for, so their materialisation pass (4 B read + 2 B write per element) does not run."""
         if not self.shared:
-            self.bsums.zero_()
+            dev_zero(self.bsums)
         _debug_delay()
         io = (1 if dz.dtype == torch.bfloat16 else 0) | (2 if y.dtype == torch.bfloat16 else 0)
         if io:
@@ -971,7 +1000,7 @@ class GeneratorEngine:
         self.use_drop = bool(train) or masks is not None
         if masks is not None:
             for d, m in zip(self.drop, masks):
-                d.copy_(m)
+                dev_copy(d, m)
         elif train:
             for i, d in enumerate(self.drop):
                 self._drop_counter += 1
@@ -995,14 +1024,15 @@ class GeneratorEngine:
         A, N, H, W = self.A, self.N, self.H, self.W
         assert tuple(inp.shape) == (N, 3 + 2 * self.P, H, W) and inp.is_contiguous() and inp.dtype == torch.float32
         self.input = inp
-        self.nscr.sums.zero_()
+        dev_zero(self.nscr.sums)
         if not hasattr(self, "use_drop"):
             self.set_dropout(None, train=True)
         if self.deformable:
             T = self.T
             # (N,T,8) as the reference Dataset emits it; estimate_uniform_transform may hand over 9 values per row
             # (pose_transform.py:322) — only the first six are ever read (pose_transform.py:28)
-            self.warps.copy_(warps.reshape(N, T, -1)[:, :, :8])
+            w8 = warps.reshape(N, T, -1)
+            dev_copy(self.warps, w8 if w8.shape[-1] == 8 else w8[:, :, :8])
             if self.masked:
                 assert masks.is_contiguous() and tuple(masks.shape) == (N, T, H, W)
                 for l in range(self.nwarp):
@@ -1085,7 +1115,7 @@ class GeneratorEngine:
         if bfs:
             # bf16 STORAGE: the three sources are bf16 operands already (normalised block output, relu'd warp, the stem's
             # ReLU copy); the 27 tap columns are padded to the 64-column tile of the bf16 kernels
-            self.wt_fin[:27].copy_(A.p("decoder.net.%d.weight" % (i + 1)).view(27, cin))
+            dev_copy(self.wt_fin[:27], A.p("decoder.net.%d.weight" % (i + 1)).view(27, cin))
             _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W, self.wt_fin, 64, cin, out=self.y_taps)
             L.call("pg_tap_gather_pitch", L.ptr(self.y_taps), 64, N, H, W, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
                    L.OUT_TANH, L.ptr(self.out), 3 * H * W, H * W, W, 1, L.stream())
@@ -1128,7 +1158,7 @@ class GeneratorEngine:
         A, N, H, W = self.A, self.N, self.H, self.W
         assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
         ystr = (3 * H * W, H * W, W, 1)
-        self.nscr.bsums.zero_()
+        dev_zero(self.nscr.bsums)
         # ---- final conv k3s1p1 (+bias, tanh handled by the caller)
         i = self.ndec - 1
         srcs = self._dec_sources(i)
@@ -1146,7 +1176,7 @@ class GeneratorEngine:
             # weight-gradient operand).  Two lean streaming passes (csrc/out_conv_dgrad.hip): weight gradient on the side
             # stream, data gradient on the main stream.  (Tried: the data gradient as a K = 64 bf16 contraction with the padded
             # weight — 8192 one-K-tile workgroups: 1.05 ms at batch 32 against 0.9 ms streaming.)
-            self.wt_out[:, :27].copy_(A.p(wkey).view(27, cin).t())
+            L.call("pg_transpose_f32", L.ptr(A.p(wkey)), 27, cin, L.ptr(self.wt_out), 32, L.stream())
             dsts = []
             for (kind, idx, a), d0 in zip(srcs, self._dsts_for(srcs, True)):
                 xop = self._bf_fwd.lookup(L.ptr(a.t), a.C, L.ACT_RELU, L.ptr(a.aff), L.ptr(a.mask))
@@ -1160,7 +1190,7 @@ class GeneratorEngine:
             # goes to the side stream like every other weight gradient
             side = _side_stream() if SIDE_STREAM else None
             if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
+                L.call("pg_stream_wait", _raw(side), L.stream())
             L.call("pg_out_conv_bwd_direct", L.ptr(dpre), 1, L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.ptr(A.g(wkey)),
                    L.ptr(self.fin_ws), self.fin_ws.numel(), ctypes.c_void_p(side.cuda_stream) if side is not None else None, L.stream())
             self._ready("decoder.net.%d." % (i + 1))
@@ -1175,7 +1205,7 @@ class GeneratorEngine:
         self._ready("decoder.net.%d." % (i + 1))
         # data-gradient of the 3-channel output conv = one K=32 contraction of the same im2col'd gradient with the
         # weight viewed as [27 (tap, co)][cin] (transposed, zero-padded to 32), scattered with relu' / dropout mask
-        self.wt_out[:, :27].copy_(A.p(wkey).view(27, cin).t())
+        L.call("pg_transpose_f32", L.ptr(A.p(wkey)), 27, cin, L.ptr(self.wt_out), 32, L.stream())
         dsts = self._dsts_for(srcs, True)
         if cin <= 256 and all(t.C % 4 == 0 for t in dsts) and OUT_CONV_STREAM:
             arr = (L.Dst * len(dsts))(*dsts)          # K = 27: no GEMM — the streaming kernel (one wave per pixel)
@@ -1333,7 +1363,7 @@ class DiscriminatorEngine:
         """pairs: list of (input NCHW (n,3+2P,H,W), judged NCHW (n,3,H,W)); sum n == M.  Returns logits (M,K)."""
         A, H, W = self.A, self.H, self.W
         self.inputs = pairs
-        self.nscr.sums.zero_()
+        dev_zero(self.nscr.sums)
         off = 0
         bf0 = None
         if PRECISION == 3 and STEM_BF16 and STEM_EMIT_BF16 and _BF_CTX is not None and 3 + 2 * self.P + 3 <= 80:
@@ -1372,7 +1402,7 @@ class DiscriminatorEngine:
         """dlogits (M,K).  need_wgrad: accumulate weight grads (dis_update).  image_grad: list of NCHW (n,3,H,W)
         buffers (one per forward pair, or None) receiving d/d(judged image) (gen_update)."""
         A, M, H, W = self.A, self.M, self.H, self.W
-        self.nscr.bsums.zero_()
+        dev_zero(self.nscr.bsums)
         j = self.nblk - 1
         ystr = (self.K, 1, self.ws[j], 1)
         wkey = "net.%d.net.1.weight" % j

@@ -121,6 +121,14 @@ _PROTOS = {
     "pg_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
     "pg_event_destroy": [_vp],
     "pg_debug_spin": [_i32, _vp],
+    "pg_tape_begin": [],
+    "pg_tape_end": [C.POINTER(_vp), C.POINTER(_i64)],
+    "pg_tape_replay": [_vp],
+    "pg_tape_destroy": [_vp],
+    "pg_stream_wait": [_vp, _vp],
+    "pg_zero": [_vp, _i64, _vp],
+    "pg_copy": [_vp, _vp, _i64, _vp],
+    "pg_transpose_f32": [_vp, _i32, _i32, _vp, _i32, _vp],
     "pg_materialise_bf16_ex": [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp],
     "pg_norm_bwd_reduce_ex": [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp],
     "pg_norm_bwd_apply_io": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp],

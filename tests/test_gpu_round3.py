@@ -272,3 +272,63 @@ def test_bf16_data_step_l1_gradients_vs_golden(store, monkeypatch):
     d = (og.cpu() - t(fix["it0_out_gen"])).abs()
     assert float(d.max()) < 0.3 and float(d.mean()) < 2.6e-2, (float(d.max()), float(d.mean()))
     _check_grads(model.gen.arena.grad_dict(), fix, "it0_ggrad_", "study", "step_l1/" + store)
+
+
+# ------------------------------------------------------------------------------------------ launch tape
+@pytest.mark.parametrize("prec", ["f32", "bf16_data"])
+def test_launch_tape_replay_matches_eager(prec, monkeypatch):
+    """runtime/tape.py: dis_update + gen_update recorded on the library's launch tape (csrc/api.hip: pg_tape_*) and replayed
+    from ONE host call per iteration, weight gradients still on their side stream.  With explicit dropout masks a tape
+    session (1 eager warm-up + 1 recorded + 2 replayed iterations) lands on the same parameters as 4 eager iterations up to
+    run-to-run summation noise (Adam's first steps amplify it: bound as in the HIP-graph test); with device dropout two
+    replays draw different masks (the device counter feeds the key); the eager path works again after close()."""
+    from types import SimpleNamespace
+    from test_gpu_round2 import tp, dev
+    from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
+    from pose_transfer_amd.runtime.tape import TapedIteration
+    monkeypatch.setattr(E, "PRECISION", {"f32": 0, "bf16_data": 3}[prec])
+    P, H, W, N = 18, 64, 64, 2
+    enc, dec = synth.nfilters((H, W))
+    opt = SimpleNamespace(image_size=(H, W), use_input_pose=True, pose_dim=P, batch_size=N, num_stacks=4, gen_type="baseline",
+                          dataset="fasion", warp_skip="mask", learning_rate=2e-4, content_loss_layer="none",
+                          nn_loss_area_size=1, gan_penalty_weight=1.0, l1_penalty_weight=100.0)
+    od = dict(vars(opt), lazy_losses=True)
+
+    def fresh():
+        m = DeformablePose_GAN(opt, device=DEV)
+        m.gen.load_state_dict(tp(synth.init_params(91, "graph/gen", synth.generator_spec(P, enc, dec), 0.1)))
+        m.disc.load_state_dict(tp(synth.init_params(91, "graph/disc", synth.discriminator_spec(3 + 2 * P + 3), 0.1)))
+        return m
+
+    batches = [dev(*[t(a) for a in synth.batch(91, "graph/%s" % s, N, P, H, W)]) for s in "ABC"]
+    dA = dev(*[t(m) for m in synth.dropout_masks(91, "graph/dA", N)])
+    dC = dev(*[t(m) for m in synth.dropout_masks(91, "graph/dC", N)])
+    eager = fresh()
+    for _ in range(4):
+        a, b, c = batches
+        eager.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3], "drop_masks": dA}, b[0], b[1], od)
+        eager.gen_update(c[0], c[1], {"warps": c[2], "masks": c[3], "drop_masks": dC}, od)
+    t_model = fresh()
+    tape = TapedIteration(t_model, batches, od, warmup=1, drop_masks=(dA, dC))
+    assert tape.n_ops > 50
+    for _ in range(2):
+        out, dl, gl = tape.replay()
+    torch.cuda.synchronize()
+    tape.close()
+    assert t_model.gen.arena.step == eager.gen.arena.step == 4 and t_model.disc.arena.step == 4
+    lr, steps = float(opt.learning_rate), 4
+    for me, mg in ((eager.gen, t_model.gen), (eager.disc, t_model.disc)):
+        d = (me.arena.params - mg.arena.params).abs()
+        assert float(d.max()) <= 2.5 * steps * lr, float(d.max())
+        assert float(d.median()) <= (2e-5 if prec == "f32" else 2e-4), float(d.median())
+    assert torch.isfinite(out).all() and torch.isfinite(dl).all() and torch.isfinite(gl).all()
+    m2 = fresh()
+    t2 = TapedIteration(m2, batches, od, warmup=1)
+    eng = m2.gen.engine(N)
+    t2.replay(); torch.cuda.synchronize(); d1 = [d.clone() for d in eng.drop]
+    t2.replay(); torch.cuda.synchronize(); d2 = [d.clone() for d in eng.drop]
+    t2.close()
+    assert any(not torch.equal(x, y) for x, y in zip(d1, d2))
+    a, b, c = batches
+    m2.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3]}, b[0], b[1], od)
+    assert m2.disc.arena.step == 5

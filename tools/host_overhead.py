@@ -38,3 +38,18 @@ print("%s batch 4: %d C-ABI calls per iteration; top: %s" % (prec, sum(counts.va
       ", ".join("%s x%d" % kv for kv in sorted(counts.items(), key=lambda kv: -kv[1])[:12])))
 print("per iteration: host CPU time %.2f ms, enqueue wall %.2f ms, end-to-end wall %.2f ms" %
       ((c1 - c0) / 20 * 1e3, (w1 - w0) / 20 * 1e3, (w2 - w0) / 20 * 1e3))
+# the same iteration replayed from the library's launch tape (runtime/tape.py): ONE host call per iteration
+from pose_transfer_amd.runtime.tape import TapedIteration
+tape = TapedIteration(model, batches, od, warmup=2)
+for _ in range(3):
+    tape.replay()
+torch.cuda.synchronize()
+w0, c0 = time.perf_counter(), time.process_time()
+for _ in range(20):
+    tape.replay()
+w1, c1 = time.perf_counter(), time.process_time()
+torch.cuda.synchronize()
+w2 = time.perf_counter()
+print("launch tape (%d recorded enqueues): host CPU time %.2f ms, enqueue wall %.2f ms, end-to-end wall %.2f ms per iteration" %
+      (tape.n_ops, (c1 - c0) / 20 * 1e3, (w1 - w0) / 20 * 1e3, (w2 - w0) / 20 * 1e3))
+tape.close()
