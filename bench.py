@@ -157,6 +157,25 @@ HBM_MODELS = {
     "pg_out_conv_dgrad": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (128 + 8 * sum(a[5][i].C for i in range(_ival(a[6])))),
     "pg_materialise_bf16": lambda a: 6 * _ival(a[4]) * _ival(a[5]) * _ival(a[6]),                 # fp32 in, bf16 out
     "pg_channel_major_bf16": lambda a: 6 * _ival(a[4]) * _ival(a[5]) * _ival(a[6]) * _ival(a[7]) // max(1, _ival(a[8]) ** 2),
+    # ---- round 3: the `_io` / bf16-STORAGE forms (io_flags: element sizes follow the flags)
+    "pg_warp_mask_max_fwd_io": lambda a: _ival(a[4]) * _ival(a[7]) * _ival(a[8]) * (
+        _ival(a[6]) * ((2 if _ival(a[14]) & 1 else 4) + (2 if _ival(a[14]) & 2 else 4)) + 4 * _ival(a[5])),
+    "pg_warp_mask_max_bwd_io": lambda a: int(_ival(a[4]) * _ival(a[7]) * _ival(a[8]) * _ival(a[6]) * (8.25 if _ival(a[13]) == 3 else 16.5)),
+    "pg_norm_bwd_reduce_ex": lambda a: (4 if _ival(a[6]) == 3 else 8) * _ival(a[3]) * _ival(a[4]),
+    "pg_norm_bwd_apply_io": lambda a: (6 if _ival(a[10]) == 3 else (14 if a[9] else 12)) * _ival(a[5]) * _ival(a[6]),
+    "pg_materialise_bf16_ex": lambda a: ((2 if _ival(a[1]) else 4) + (4 if a[9] else 2)) * _ival(a[5]) * _ival(a[6]) * _ival(a[7]),
+    "pg_stem_conv_bf16_v3": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * 4 * sum(a[0][i].C for i in range(_ival(a[1])))
+                            + (256 * (1 if a[10] else 0) + 128 * sum(1 for j in (11, 13, 15) if a[j])) * _ival(a[2])
+                            * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
+                            * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
+    "pg_stem_wgrad_bf16_ex": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * 4 * sum(a[0][i].C for i in range(_ival(a[1])))
+                             + (128 if _ival(a[9]) else 256) * _ival(a[2])
+                             * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
+                             * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
+    "pg_bias_grad_bf16": lambda a: 2 * _ival(a[1]) * _ival(a[2]),
+    "pg_tap_gather_pitch": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (27 * 4 + 12),
+    # output-conv backward, bf16 storage: data gradient (dpre + activated operand + gradient write) + weight gradient (dpre + operand)
+    "pg_out_conv_bwd_direct": lambda a: _ival(a[3]) * _ival(a[4]) * _ival(a[5]) * (24 + 6 * sum(a[6][i].C for i in range(_ival(a[7])))),
     "pg_l1_loss": lambda a: 12 * _ival(a[2]),
     "pg_tanh_bwd": lambda a: 12 * _ival(a[2]),
 }
