@@ -32,6 +32,23 @@ __device__ __forceinline__ unsigned wpack_bf16(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+// V consecutive channels (V = 4: 16 B fp32 / 8 B bf16; V = 8: bf16 only, 16 B)
+template <bool BF, int V>
+__device__ __forceinline__ void wldv(const char* base, size_t byte_off, float (&v)[V]) {
+  if constexpr (V == 8) {
+    static_assert(BF, "8 channels per lane: bf16 tensors only");
+    const uint4 u = *reinterpret_cast<const uint4*>(base + byte_off);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+  } else {
+    const float4 f = wld4<BF>(base, byte_off);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  }
+}
+template <bool BF, int V>
+__device__ __forceinline__ void wstv(char* base, size_t byte_off, const float (&v)[V]);
+
 template <bool BF>
 __device__ __forceinline__ void wst4(char* base, size_t byte_off, float4 v) {
   if constexpr (BF) {
@@ -213,6 +230,16 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* feat, const 
   }
 }
 
+template <bool BF, int V>
+__device__ __forceinline__ void wstv(char* base, size_t byte_off, const float (&v)[V]) {
+  if constexpr (V == 8) {
+    uint4 u = make_uint4(wpack_bf16(v[0], v[1]), wpack_bf16(v[2], v[3]), wpack_bf16(v[4], v[5]), wpack_bf16(v[6], v[7]));
+    *reinterpret_cast<uint4*>(base + byte_off) = u;
+  } else {
+    wst4<BF>(base, byte_off, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
 // ---- backward.  Gather form: an input pixel (X, Y) collects from the output pixels whose bilinear footprint under some
 // transform covers it.  The affine map is inverted per (sample, transform): the pre-image of the 2 x 2 neighbourhood of
 // (X, Y) is a parallelogram, its bounding box holds <= GATHER_CAP integer points for every "narrow" transform (identity
@@ -257,7 +284,7 @@ __device__ __forceinline__ WarpInv invert_warp(const Theta& th, int h, int w, in
 // Arithmetic per output element is unchanged (same operations in the same order, adding a +-0 for a zero-weight tap).
 struct WarpTap { int o[4]; float w[4]; };          // byte offsets into the sample's feature map (x C x 4 applied), weights
 
-template <bool IB, bool OB>
+template <bool IB, bool OB, int V = 4>
 __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const float* aff, const float* warps,
                                                         const float* masks, int T, int C, int h, int w, int H0, int W0,
                                                         int align, int TP, void* out, uint8_t* amax, int relu_out) {
@@ -281,12 +308,13 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
     for (int i = tid; i < h; i += 256)
       ys_t[i] = align ? (h > 1 ? (((float)i * 2.0f) / (fh - 1.0f)) - 1.0f : 0.0f) : ((((float)i * 2.0f) + 1.0f) / fh) - 1.0f;
   }
-  const int cpp = C >> 2;
+  // V channels per lane (round 3: 8 on bf16 tensors — 16-byte accesses, half the lanes / instructions per pixel)
+  const int cpp = C / V;
   const int ppp = 256 / cpp;                                   // pixels per pass (host: cpp divides 256)
   const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
   const char* fb = reinterpret_cast<const char*>(feat) + (size_t)n * h * w * C * ESI;
   const int npix = h * w;
-  const int cc = (tid % cpp) * 4, lp = tid / cpp;
+  const int cc = (tid % cpp) * V, lp = tid / cpp;
   for (int p0 = blockIdx.x * TP; p0 < npix; p0 += gridDim.x * TP) {
     __syncthreads();
     // ---- pre-pass: (pixel, transform) pairs, mask values read as one contiguous run
@@ -325,51 +353,58 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
       }
     }
     __syncthreads();
-    // ---- sampling pass: lane = (pixel of the pass, 4 channels)
+    // ---- sampling pass: lane = (pixel of the pass, V channels)
     for (int pl = lp; pl < TP; pl += ppp) {
       const int pix = p0 + pl;
       if (pix >= npix) break;
-      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      int bi[4] = {255, 255, 255, 255};
+      float best[V];
+      int bi[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 255; }
       for (int t = 0; t < T; ++t) {
         const float m = mval[pl * T + t];
-        float cand[4] = {0.f, 0.f, 0.f, 0.f};
+        float cand[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) cand[e] = 0.f;
         int id = 255;
         if (m != 0.f) {
 #pragma clang fp contract(off)
           const WarpTap tp = taps[pl * T + t];
-          float4 v[4];
+          float v[4][V];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = wld4<IB>(fb, (size_t)(unsigned)tp.o[k] + cc * ESI);
-          float s[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int k = 0; k < 4; ++k) wldv<IB, V>(fb, (size_t)(unsigned)tp.o[k] + cc * ESI, v[k]);
+          float s[V];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            s[0] = s[0] + ((v[k].x * a) + b) * tp.w[k];
-            s[1] = s[1] + ((v[k].y * a) + b) * tp.w[k];
-            s[2] = s[2] + ((v[k].z * a) + b) * tp.w[k];
-            s[3] = s[3] + ((v[k].w * a) + b) * tp.w[k];
-          }
+          for (int e = 0; e < V; ++e) s[e] = 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) cand[e] = s[e] * m;
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] = s[e] + ((v[k][e] * a) + b) * tp.w[k];
+#pragma unroll
+          for (int e = 0; e < V; ++e) cand[e] = s[e] * m;
           id = t;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < V; ++e)
           if (cand[e] > best[e]) { best[e] = cand[e]; bi[e] = id; }
       }
       const long o = ((long)n * npix + pix) * C + cc;
       if (relu_out) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], 0.f);
+        for (int e = 0; e < V; ++e) best[e] = fmaxf(best[e], 0.f);
       }
-      wst4<OB>(reinterpret_cast<char*>(out), (size_t)o * ESO, make_float4(best[0], best[1], best[2], best[3]));
-      if (amax) *reinterpret_cast<uchar4*>(amax + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1],
-                                                                    (unsigned char)bi[2], (unsigned char)bi[3]);
+      wstv<OB, V>(reinterpret_cast<char*>(out), (size_t)o * ESO, best);
+      if (amax) {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q)
+          *reinterpret_cast<uchar4*>(amax + o + 4 * q) = make_uchar4((unsigned char)bi[4 * q], (unsigned char)bi[4 * q + 1],
+                                                                      (unsigned char)bi[4 * q + 2], (unsigned char)bi[4 * q + 3]);
+      }
     }
   }
 }
 
-template <bool GB, bool DB>
+template <bool GB, bool DB, int V = 4>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, const uint8_t* amax, const float* warps,
                                                               const float* masks, int T, int C, int h, int w, int H0, int W0,
                                                               int align, void* dfeat) {
@@ -449,16 +484,18 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
     }
   }
   __syncthreads();
-  // ---- phase 2: lanes = 4 channels of an input pixel; entries in batches of four (independent loads in flight)
-  const int cq = C >> 2;
+  // ---- phase 2: lanes = V channels of an input pixel; entries in batches of four (independent loads in flight)
+  const int cq = C / V;
   for (int q = threadIdx.x; q < GATHER_PIX * cq; q += 256) {
-    const int p = q / cq, c4 = (q - p * cq) * 4;
+    const int p = q / cq, c4 = (q - p * cq) * V;
     const int P = P0 + p;
     if (P >= h * w) continue;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
     const int cnt = e_cnt[p];
     for (int e0 = 0; e0 < cnt; e0 += 4) {
-      long o[4]; float wt[4]; int tt[4]; uchar4 am[4]; float4 g[4];
+      long o[4]; float wt[4]; int tt[4]; unsigned am[4][V / 4]; float g[4][V];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool val = e0 + u < cnt;
@@ -467,18 +504,19 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
         tt[u] = val ? (pk >> 24) : 256;          // padding entries match no arg-max byte (255 = "no transform won" is a byte value)
         wt[u] = val ? e_w[p][ee] : 0.f;
         o[u] = (nb + (pk & 0xffffff)) * C + c4;
-        am[u] = *reinterpret_cast<const uchar4*>(amax + o[u]);
-        g[u] = wld4<GB>(reinterpret_cast<const char*>(gout), (size_t)o[u] * ESG);
+#pragma unroll
+        for (int qd = 0; qd < V / 4; ++qd) am[u][qd] = *reinterpret_cast<const unsigned*>(amax + o[u] + 4 * qd);
+        wldv<GB, V>(reinterpret_cast<const char*>(gout), (size_t)o[u] * ESG, g[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc.x += am[u].x == tt[u] ? g[u].x * wt[u] : 0.f;
-        acc.y += am[u].y == tt[u] ? g[u].y * wt[u] : 0.f;
-        acc.z += am[u].z == tt[u] ? g[u].z * wt[u] : 0.f;
-        acc.w += am[u].w == tt[u] ? g[u].w * wt[u] : 0.f;
-      }
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int ab = (int)((am[u][e >> 2] >> (8 * (e & 3))) & 0xffu);
+          acc[e] += ab == tt[u] ? g[u][e] * wt[u] : 0.f;
+        }
     }
-    wst4<DB>(reinterpret_cast<char*>(dfeat), (size_t)((nb + P) * C + c4) * ESD, acc);
+    wstv<DB, V>(reinterpret_cast<char*>(dfeat), (size_t)((nb + P) * C + c4) * ESD, acc);
   }
   }   // tile loop
 }
@@ -610,9 +648,11 @@ extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const
   PG_REQUIRE(feat && warps && lvl_masks && out, "pg_warp_mask_max_fwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_fwd: need T<=32, C%%4==0 (T=%d C=%d)", T, C);
   static const bool v1 = getenv("PG_WARP_FWD_V1") != nullptr;      // ablation switch: the round-1 per-lane walk
-  const int cpp = C / 4;
-  const size_t lds = ((MAXT * sizeof(Theta) + (size_t)(w + h + 64 * T) * 4 + 15) / 16) * 16 + (size_t)64 * T * sizeof(WarpTap);
   const bool ib = io_flags & 1, ob = io_flags & 2;
+  static const bool no_v8 = getenv("PG_WARP_NO_V8") != nullptr;      // ablation switch: 4 channels per lane on bf16 tensors too
+  const bool v8 = ib && ob && C % 8 == 0 && 256 % (C / 8) == 0 && !no_v8;
+  const int cpp = v8 ? C / 8 : C / 4;
+  const size_t lds = ((MAXT * sizeof(Theta) + (size_t)(w + h + 64 * T) * 4 + 15) / 16) * 16 + (size_t)64 * T * sizeof(WarpTap);
   const int relu = (io_flags & 4) ? 1 : 0;
   if (v1 || cpp > 256 || 256 % cpp != 0 || lds > 64 * 1024 || (double)h * w * C * 4.0 >= 2147483648.0) {
     PG_REQUIRE(io_flags == 0, "pg_warp_mask_max_fwd: bf16 storage needs the tiled kernel (C / 4 must divide 256)");
@@ -629,7 +669,10 @@ extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const
 #define PGW_FWD(IB_, OB_)                                                                                                     \
   PG_KLAUNCH((warp_fwd3_kernel<IB_, OB_>), grid, dim3(256), lds, st, feat, aff, warps, lvl_masks, T, C, h, w, H0, W0, \
                      align_corners, tp, out, argmax, relu)
-    if (ib && ob) PGW_FWD(true, true);
+    if (v8)
+      PG_KLAUNCH((warp_fwd3_kernel<true, true, 8>), grid, dim3(256), lds, st, feat, aff, warps, lvl_masks, T, C, h, w, H0, W0,
+                 align_corners, tp, out, argmax, relu);
+    else if (ib && ob) PGW_FWD(true, true);
     else if (ib) PGW_FWD(true, false);
     else if (ob) PGW_FWD(false, true);
     else PGW_FWD(false, false);
@@ -665,7 +708,12 @@ extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, 
     static const int gcap = getenv("PG_WARP_BWD_TILES") ? atoi(getenv("PG_WARP_BWD_TILES")) : 256;     // workgroups per sample
     int gtiles = (h * w + GATHER_PIX - 1) / GATHER_PIX;
     if (gtiles > gcap) gtiles = gcap;
-    PGW_BWD(warp_bwd_gather_kernel, dim3(gtiles, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
+    static const bool no_v8b = getenv("PG_WARP_NO_V8") != nullptr;
+    if (gb && db && C % 8 == 0 && !no_v8b)
+      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8>), dim3(gtiles, N), dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w,
+                 H0, W0, align_corners, dfeat);
+    else
+      PGW_BWD(warp_bwd_gather_kernel, dim3(gtiles, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
     // (a sample without wide transforms costs one early-exiting workgroup round: keep that grid small)
     PGW_BWD(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
