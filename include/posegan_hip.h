@@ -451,6 +451,11 @@ int pg_im2col_taps_bf16(const float* dY, int64_t yN, int64_t yC, int64_t yH, int
 int pg_out_conv_wgrad_bf16(const void* G_bf16, int32_t g_pitch, int32_t N, int32_t H, int32_t W, const pg_dst_t* dst,
                            int32_t ndst, float* dW, float* workspace, int64_t workspace_floats, void* stream);
 
+/* every per-tap TRANSPOSED bf16 weight copy of a parameter arena (the data-gradient operands of the bf16 data path) in one
+ * launch: table = device array of {int64 arena offset (floats); int32 taps, Cout, Cin, first tile} records, 32 x 32 tiles */
+int pg_weights_to_bf16_batch(const float* arena, const void* table, int32_t ntab, int32_t total_tiles, void* out_t_bf16,
+                             void* stream);
+
 /* ---- launch tape (round 3; no reference counterpart: the reference's loop is eager PyTorch, main.py:77-108).  Between
  * pg_tape_begin and pg_tape_end the calling thread's enqueues (kernel launches, memsets, pg_stream_wait, pg_zero, pg_copy) are
  * issued as usual AND recorded with a copy of their arguments; pg_tape_replay re-issues them on the same streams — one call per

@@ -1719,7 +1719,8 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     if (bn != 0) {
       const int mtb = cdiv(k.M, bn == 64 ? 512 : 256), ntb = k.n_cnt / bn;
       const long wgs = (long)mtb * ntb * k.nphase;
-      if (wgs >= 448 || getenv("PG_FORCE_BF16_BIG") != nullptr) {
+      static const long big_min = getenv("PG_BF16_BIG_MIN") ? atol(getenv("PG_BF16_BIG_MIN")) : 192;   // swept (tools/sweep_bf16_big_min.sh): 448 -> 523 / 814, 192 -> 529 / 832 img/s (256^2 batch 4 / 224^2 batch 8)
+      if (wgs >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr) {
         k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
         launch_conv_bf16_big(k, bn, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");

@@ -278,7 +278,45 @@ __global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float* W, in
     }
   }
 }
+// All transposed bf16 weight copies of an arena in ONE launch (round 3: 23 launches per iteration before — launch-count bound at
+// small batch).  table[k] = {float offset of tensor k in the arena, taps, Cout, Cin, first tile}; a workgroup = one 32 x 32 tile
+// of one tap of one tensor; out_t[off + tap*Cout*Cin + ci*Cout + co] = bf16(W[off + tap*Cout*Cin + co*Cin + ci]).
+struct WtTab { long off; int taps, Cout, Cin, tile0; };
+__global__ __launch_bounds__(256) void weights_to_bf16_batch_kernel(const float* arena, const WtTab* tab, int ntab, unsigned short* out_t) {
+  __shared__ float tile[32][33];
+  int k = 0;
+  const int b = blockIdx.x;
+  while (k + 1 < ntab && tab[k + 1].tile0 <= b) ++k;
+  const WtTab e = tab[k];
+  const int tci = (e.Cin + 31) / 32, tco = (e.Cout + 31) / 32;
+  int r = b - e.tile0;
+  const int tap = r / (tci * tco); r -= tap * tci * tco;
+  const int co0 = (r / tci) * 32, ci0 = (r % tci) * 32;
+  const long base = e.off + (long)tap * e.Cout * e.Cin;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int q = ty; q < 32; q += 8) {
+    const int co = co0 + q, ci = ci0 + tx;
+    tile[q][tx] = (co < e.Cout && ci < e.Cin) ? arena[base + (long)co * e.Cin + ci] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = ty; q < 32; q += 8) {
+    const int ci = ci0 + q, co = co0 + tx;
+    if (ci < e.Cin && co < e.Cout) out_t[base + (long)ci * e.Cout + co] = (unsigned short)(pack2_bf16(tile[tx][q], 0.f) & 0xffffu);
+  }
+}
 }  // namespace pg
+
+// table: device array of ntab records {int64 off; int32 taps, Cout, Cin, tile0} (24 bytes each, tile0 ascending from 0)
+extern "C" int pg_weights_to_bf16_batch(const float* arena, const void* table, int32_t ntab, int32_t total_tiles, void* out_t_bf16,
+                                        void* stream) {
+  PG_REQUIRE(arena && table && out_t_bf16 && ntab > 0 && total_tiles > 0, "pg_weights_to_bf16_batch: bad arguments");
+  PG_KLAUNCH(pg::weights_to_bf16_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, arena,
+             reinterpret_cast<const pg::WtTab*>(table), ntab, reinterpret_cast<unsigned short*>(out_t_bf16));
+  PG_LAUNCH_OK("pg_weights_to_bf16_batch");
+  return 0;
+}
 
 extern "C" int pg_materialise_bf16_ex(const void* x, int32_t x_is_bf16, const float* aff, const float* mask, int32_t act, int32_t N,
                                       int64_t HW, int32_t C, void* out_bf16, void* out2_bf16, int32_t act2, void* stream) {

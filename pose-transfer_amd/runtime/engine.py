@@ -144,6 +144,7 @@ class ParamArena:
         self.step = 0
         self.params_bf16 = None       # bf16 data path: bf16 copy of the whole arena, kept current by Adam / load_state_dict
         self.bf16_version = -1
+        self.params_bf16_t, self.bf16_t_version = None, -1      # ... and the per-tap transposed copy (bf16_params_t)
         ARENAS[self.params.untyped_storage().data_ptr()] = self
 
     def p(self, key):
@@ -168,6 +169,30 @@ class ParamArena:
             L.call("pg_pack_bf16", L.ptr(self.params), L.ptr(self.params_bf16), self.total, L.stream())
             self.bf16_version = self.version()
         return self.params_bf16
+
+    def bf16_params_t(self):
+        """per-tap TRANSPOSED bf16 copy of every convolution weight ([tap][Cin][Cout]: the K-contiguous operand of the data
+        gradients), same offsets as the arena, rebuilt by ONE launch per optimiser step (pg_weights_to_bf16_batch)"""
+        if self.params_bf16_t is None:
+            self.params_bf16_t = torch.empty(self.total, dtype=torch.bfloat16, device=self.params.device)
+            rec, tile0 = [], 0
+            for k in self.keys:
+                ps = self.pshape[k]
+                if len(ps) != 4:
+                    continue
+                taps, co, ci = ps[0] * ps[1], ps[2], ps[3]
+                rec.append((self.off[k], taps, co, ci, tile0))
+                tile0 += taps * ((co + 31) // 32) * ((ci + 31) // 32)
+            tab = np.zeros(len(rec), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("co", "<i4"), ("ci", "<i4"), ("t0", "<i4")]))
+            for i, r in enumerate(rec):
+                tab[i] = r
+            self._wt_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.params.device)
+            self._wt_n, self._wt_tiles = len(rec), tile0
+        if self.bf16_t_version != self.version():
+            L.call("pg_weights_to_bf16_batch", L.ptr(self.params), L.ptr(self._wt_tab), self._wt_n, self._wt_tiles,
+                   L.ptr(self.params_bf16_t), L.stream())
+            self.bf16_t_version = self.version()
+        return self.params_bf16_t
 
     def load_state_dict(self, sd):
         self._bump_version()
@@ -281,6 +306,9 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
         L.call("pg_weights_to_bf16", L.ptr(W), taps, Cout, Cin, None if transposed else L.ptr(buf),
                L.ptr(buf) if transposed else None, L.stream())
         return buf
+    if BATCH_WT and W.dim() == 4:
+        off = (W.data_ptr() - arena.params.data_ptr()) // 4
+        return arena.bf16_params_t()[off:off + W.numel()]
     key = (W.data_ptr(), W.numel())
     ver = arena.version()
     ent = _BF_W.get(key)
@@ -297,6 +325,7 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
     return ent[2 + idx]
 
 
+BATCH_WT = os.environ.get("PG_NO_BATCH_WT") is None      # ablation switch: one pg_weights_to_bf16 launch per layer and step
 _BF_W_EXT = {}              # (data_ptr, numel, transposed) -> (weakref to the weight tensor, its bf16 buffer)
 # bf16 STORAGE (round 3): on the bf16 data path the GENERATOR keeps its raw activations and the gradients flowing through
 # them as bf16 tensors (PG_NO_BF16_STORE=1: fp32 storage as in round 2).  Kernels that take raw device pointers learn the

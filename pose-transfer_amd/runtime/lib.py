@@ -121,6 +121,7 @@ _PROTOS = {
     "pg_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
     "pg_event_destroy": [_vp],
     "pg_debug_spin": [_i32, _vp],
+    "pg_weights_to_bf16_batch": [_vp, _vp, _i32, _i32, _vp, _vp],
     "pg_tape_begin": [],
     "pg_tape_end": [C.POINTER(_vp), C.POINTER(_i64)],
     "pg_tape_replay": [_vp],
