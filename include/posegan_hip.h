@@ -393,6 +393,10 @@ int pg_event_destroy(void* ev);
 /* Test aid (no reference counterpart): one lane busy-waits ~`microseconds` (0..50000) on `stream`, delaying whatever is
  * enqueued behind it — used by the stream-ordering stress test of the data-parallel reducer (runtime/dp.py). */
 int pg_debug_spin(int32_t microseconds, void* stream);
+/* Measurement aid (no reference counterpart): with PG_DEBUG_CONV_TIMELINE set, every workgroup of the 256-row bf16 convolution
+ * kernel stamps its phases (0 start, 1 row table built, 2 first K tile landed, 3 K loop done, 4 epilogue done: shader clock;
+ * 5 / 6 the 100 MHz wall clock at start / end; 7 the XCD); this copies the stamps of the LAST launch: n_wgs x 8 uint64. */
+int pg_debug_conv_timeline(unsigned long long* host_out, int32_t n_wgs);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Round 3 — bf16 STORAGE on the bf16 data path (PG_PREC_BF16_DATA).  Raw convolution outputs (the tensors the reference's
@@ -421,6 +425,13 @@ int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const float* war
 int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, const float* warps, const float* lvl_masks, int32_t N,
                             int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0, int32_t align_corners,
                             void* dfeat, int32_t io_flags, void* stream);
+/* bounding boxes (ymin, ymax, xmin, xmax; empty: ymax < ymin) of the non-zero pixels of the (N, T, H0, W0) limb masks, and the
+ * warp backward that uses them to skip (pixel, transform) pairs whose candidates all carry a zero mask
+ * (utils/pose_transform.py:84-89: the masks are zero outside the limb polygons) */
+int pg_mask_bbox(const void* masks, int32_t is_f64, int32_t N, int32_t T, int32_t H0, int32_t W0, int32_t* bbox, void* stream);
+int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax, const float* warps, const float* lvl_masks,
+                              const int32_t* bbox, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0, int32_t W0,
+                              int32_t align_corners, void* dfeat, int32_t io_flags, void* stream);
 /* first layers: `out` (fp32) may be NULL; up to three bf16 outputs bf16(act_k(conv + bias)), PG_ACT_NONE = the raw tensor */
 int pg_stem_conv_bf16_v3(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                          int32_t pad, const uint16_t* Wp, const float* bias, float* out, uint16_t* out_bf16, int32_t act,

@@ -37,6 +37,190 @@ __device__ __forceinline__ int lds_rd32_now(unsigned addr) {      // opaque LDS 
     __builtin_amdgcn_sched_barrier(0);                              \
   } while (0)
 
+
+// Row table entry of this kernel: RowInfo plus the output pixel index (n*Ho + oy)*Wo + ox, so that an epilogue row pass needs one
+// ds_read_b64 (n, opix) and one multiply-add for its address.  The epilogues below are VALU-bound with one workgroup per CU (every
+// wave64 VALU instruction is 4 cycles, two waves per SIMD): ~38 instructions per row pass were 1.4 us per 32-row half.
+struct RowB {
+  int n;           // sample index, -1 = row outside the problem
+  int opix;        // output pixel index
+  short iy, ix;    // input base coordinate (q*si)
+  short oy, ox;    // output coordinate (shared epilogues of igemm_common.h)
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// wave-wide fp32 sum without LDS traffic: four DPP steps inside the rows of 16 lanes, then the four row sums by v_readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);       // row_half_mirror
+  v += dpp_f<0x140>(v);       // row_mirror
+  const int iv = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
+}
+
+// Forward-output store of a wave's 64 x 64 sub-tile through its private LDS tile (layout as vec_store_64x64), bf16 or fp32 rows.
+// n_lo = sample of the block's first row, one_sample = all 64 rows belong to it (wave-uniform, from the tile geometry).
+// Without a bias the rows outside the problem are exact zeros (their A rows were the zero page): they add nothing to the sums.
+template <int TN_, bool OB>
+__device__ __forceinline__ void big_store_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowB* rows, int wm0, int lane, void* obase,
+                                                int n_cnt, int ngc, bool has_bias, float4 bv, bool do_stats, int n_lo, bool one_sample,
+                                                float (&st_s)[2], float (&st_q)[2], double* stats) {
+  constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
+  char* const ob = reinterpret_cast<char*>(obase) + (size_t)ngc * (OB ? 2 : 4);
+  const unsigned rowb = (unsigned)n_cnt * (OB ? 2u : 4u);
+  float tot_s = 0.f, tot_q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int2 ro[NP];
+    float4 v[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int row = it * RPP + rsel;
+      ro[it] = *reinterpret_cast<const int2*>(&rows[wm0 + i * 32 + row]);            // (n, opix)
+      v[it] = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const bool ok = ro[it].x >= 0;
+      if (has_bias) { v[it].x += bv.x; v[it].y += bv.y; v[it].z += bv.z; v[it].w += bv.w; }
+      if (ok) {
+        char* const dst = ob + (size_t)(unsigned)ro[it].y * rowb;
+        if constexpr (OB) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(v[it].x, v[it].y), pack_bf16(v[it].z, v[it].w));
+        else *reinterpret_cast<float4*>(dst) = v[it];
+      }
+      if (do_stats) {
+        float s4 = (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        float q4 = fmaf(v[it].x, v[it].x, fmaf(v[it].y, v[it].y, fmaf(v[it].z, v[it].z, v[it].w * v[it].w)));
+        if (has_bias) { s4 = ok ? s4 : 0.f; q4 = ok ? q4 : 0.f; }
+        if (one_sample) { tot_s += s4; tot_q += q4; }
+        else {
+          const int dn = ro[it].x - n_lo;
+          st_s[0] += (ok && dn == 0) ? s4 : 0.f; st_q[0] += (ok && dn == 0) ? q4 : 0.f;
+          st_s[1] += (ok && dn == 1) ? s4 : 0.f; st_q[1] += (ok && dn == 1) ? q4 : 0.f;
+          if (ok && dn > 1) {
+            stat_spill(stats, ro[it].x, v[it].x); stat_spill(stats, ro[it].x, v[it].y);
+            stat_spill(stats, ro[it].x, v[it].z); stat_spill(stats, ro[it].x, v[it].w);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (one_sample) { st_s[0] += tot_s; st_q[0] += tot_q; }
+}
+
+// Data-gradient scatter of a wave's whole (TM*32) x 64 tile, gradient AND forward tensors in bf16 STORAGE, every sample >= 32
+// pixels (host: dst_io == 1).  gfx950 counts loads and stores in ONE vmcnt, so waiting for a load that was issued behind a store
+// also waits for that store's acknowledgement (~2 us under load): the round-2 scheme (per batch of four row passes: loads, wait,
+// compute, stores) paid that once per batch — 30 us of a 97 us workgroup on the dec.5 data gradient (tools/conv_timeline.py).
+// Here the global loads of 32-row half h+1 (forward values, previous gradients, the two candidate samples' affine / mask) are
+// issued BEFORE the stores of half h (whose results wait in 16 registers), and nothing else reads global memory: one counted
+// wait per half, never behind a store.
+template <int TM_, int TN_>
+__device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], float* T, const RowB* rows, int wm0, int lane,
+                                                 const LaneDst& d, bool cval, int m_first, int gg, int M, int N) {
+  constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
+  struct Half {
+    uint2 fb[NP], ob[NP];
+    float2 ab[2];
+    float4 mk[2];
+    int nlo;
+    unsigned ok;
+  };
+  const unsigned short* const fwd16 = reinterpret_cast<const unsigned short*>(d.fwdp);
+  unsigned short* const grad16 = reinterpret_cast<unsigned short*>(d.gradp);
+  auto issue = [&](int hh, Half& L) {
+    const int mf = min(m_first + 32 * hh, M - 1);
+    L.nlo = __builtin_amdgcn_readfirstlane(mf / gg);
+    const int nhi = min(L.nlo + 1, N - 1);
+    L.ok = 0;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int2 ro = *reinterpret_cast<const int2*>(&rows[wm0 + hh * 32 + it * RPP + rsel]);
+      const bool ok = (ro.x >= 0) & cval;
+      const unsigned idx = ok ? (unsigned)ro.y * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
+      L.ok |= (ok ? 1u : 0u) << it;
+      L.fb[it] = *reinterpret_cast<const uint2*>(fwd16 + (d.has_fwd ? idx : (unsigned)d.c));
+      L.ob[it] = *reinterpret_cast<const uint2*>(grad16 + (d.accum ? idx : (unsigned)d.c));
+    }
+    L.ab[0] = *reinterpret_cast<const float2*>(d.affp + d.affmul * L.nlo);
+    L.ab[1] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nhi);
+    L.mk[0] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? L.nlo * d.C + d.c : (d.c & 511)));
+    L.mk[1] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nhi * d.C + d.c : (d.c & 511)));
+  };
+  Half cur;
+  issue(0, cur);
+#pragma unroll
+  for (int hh = 0; hh < TM_; ++hh) {
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[hh][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint2 res[NP];
+    unsigned oidx[NP];
+#pragma unroll
+    for (int b = 0; b < NP / 4; ++b) {
+      float4 v[4];
+      int2 ro[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = (b * 4 + u) * RPP + rsel;
+        v[u] = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
+        ro[u] = *reinterpret_cast<const int2*>(&rows[wm0 + hh * 32 + row]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = b * 4 + u;
+        const bool hi = ro[u].x > cur.nlo;
+        const float a = hi ? cur.ab[1].x : cur.ab[0].x, bb = hi ? cur.ab[1].y : cur.ab[0].y;
+        const float m4[4] = {hi ? cur.mk[1].x : cur.mk[0].x, hi ? cur.mk[1].y : cur.mk[0].y, hi ? cur.mk[1].z : cur.mk[0].z,
+                             hi ? cur.mk[1].w : cur.mk[0].w};
+        const float g4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const float f4[4] = {bf16_lo_f32(cur.fb[it].x), bf16_hi_f32(cur.fb[it].x), bf16_lo_f32(cur.fb[it].y), bf16_hi_f32(cur.fb[it].y)};
+        const float o4[4] = {bf16_lo_f32(cur.ob[it].x), bf16_hi_f32(cur.ob[it].x), bf16_lo_f32(cur.ob[it].y), bf16_hi_f32(cur.ob[it].y)};
+        float r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaf(f4[e], a, bb) * m4[e];
+          r4[e] = fmaf(g4[e] * m4[e], act_grad_s(z, d.dslope), d.accum ? o4[e] : 0.f);
+        }
+        res[it] = make_uint2(pack_bf16(r4[0], r4[1]), pack_bf16(r4[2], r4[3]));
+        oidx[it] = (unsigned)ro[u].y * (unsigned)d.C + (unsigned)d.c;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned okh = cur.ok;
+    if (hh + 1 < TM_) issue(hh + 1, cur);        // the next half's loads go out BEFORE this half's stores
+#pragma unroll
+    for (int it = 0; it < NP; ++it)
+      if ((okh >> it) & 1u) *reinterpret_cast<uint2*>(grad16 + oidx[it]) = res[it];
+  }
+}
+
+// PG_DEBUG_CONV_TIMELINE: per-workgroup time stamps (s_memtime) of the LAST launch: 0 start, 1 rows/taps set up, 2 first tile landed,
+// 3 K loop done, 4 epilogue done, 5 wall clock (100 MHz) at start, 6 wall clock at the end, 7 XCC id
+constexpr int TL_WGS = 16384, TL_SLOTS = 16;      // 8..10: inside the epilogue (see the stamps)
+static __device__ unsigned long long kTimeline[TL_WGS * TL_SLOTS];
+
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   constexpr int BM = (BN == 64) ? 512 : 256;                // BN = 64 (N = 64 layers at full resolution): 512 x 64, a wave owns 64 x 64
@@ -45,20 +229,36 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   constexpr int A_PASS = BM / 64, B_PASS = BN / 64;      // global_load_lds per thread and tile (64 rows per pass)
   constexpr int A_ST = BM * 128, B_ST = BN * 128;        // bytes per stage
   constexpr int STAGE = A_ST + B_ST;
-  constexpr int ROWS_OFF = 2 * STAGE, TAPS_OFF = ROWS_OFF + BM * (int)sizeof(RowInfo);
-  __shared__ __attribute__((aligned(1024))) char smem[TAPS_OFF + MAXTAP * 4];     // ONE LDS object (see header)
-  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + ROWS_OFF);
+  constexpr int ROWS_OFF = 2 * STAGE, TAPS_OFF = ROWS_OFF + BM * (int)sizeof(RowB);
+  constexpr int STAT_OFF = (TAPS_OFF + MAXTAP * 4 + 7) & ~7, STAT_N = 8;         // per-workgroup statistics: STAT_N samples x (sum, sum of squares)
+  __shared__ __attribute__((aligned(1024))) char smem[STAT_OFF + STAT_N * 2 * 8];     // ONE LDS object (see header)
+  RowB* rows = reinterpret_cast<RowB*>(smem + ROWS_OFF);
   int* taps_l = reinterpret_cast<int*>(smem + TAPS_OFF);
   const unsigned lds0 = (unsigned)(size_t)smem;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const bool tl_on = (p.xcd_swizzle & 16) != 0;
+  const int tl_id = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+  auto stamp = [&](int slot) {
+    if (tl_on && tid == 0 && tl_id < TL_WGS) {
+      kTimeline[tl_id * TL_SLOTS + slot] = __builtin_amdgcn_s_memtime();
+      if (slot == 0) {
+        kTimeline[tl_id * TL_SLOTS + 5] = wall_clock64();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        kTimeline[tl_id * TL_SLOTS + 7] = xcc & 0xf;
+      }
+      if (slot == 4) kTimeline[tl_id * TL_SLOTS + 6] = wall_clock64();
+    }
+  };
+  stamp(0);
   // Workgroups are dealt round-robin to the 8 XCDs (one 4 MB L2 each) in dispatch order.  Remapped, the j-th workgroup an
   // XCD receives walks (sub-pixel phase fastest, then N tile, then M tile): the four phases of a transposed convolution /
   // conv data-gradient read the same input pixels through different taps, the N tiles of an M tile the same activation
   // rows — both are then served from that XCD's L2 instead of the fabric (MI355X_MICROARCH.md: per-XCD L2s).
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (p.xcd_swizzle) {          // host: gridDim.x % 8 == 0, ksplit == 1, no tap batch
+  if (p.xcd_swizzle & 1) {          // host: gridDim.x % 8 == 0, ksplit == 1, no tap batch
     const int mt = (int)gridDim.x, nt = (int)gridDim.y, P = (int)gridDim.z;
     const int L = bx + mt * (by + nt * bz);
     const int xcd = L & 7, j = L >> 3;
@@ -75,12 +275,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   const int m0 = bx * BM, nb0 = by * BN;
   const int ntap = p.ntap[phase];
 
+  if (tid >= 64 && tid < 64 + STAT_N * 2) reinterpret_cast<double*>(smem + STAT_OFF)[tid - 64] = 0.0;
   if (tid < MAXTAP)
     taps_l[tid] = (p.dy[phase][tid] & 0xff) | ((p.dx[phase][tid] & 0xff) << 8) | ((int)p.wtap[phase][tid] << 16);
   if (tid < BM) {
-    RowInfo ri;
+    RowB ri;
     const int m = m0 + tid;
-    ri.n = -1; ri.iy = 0; ri.ix = 0; ri.oy = 0; ri.ox = 0;
+    ri.n = -1; ri.opix = 0; ri.iy = 0; ri.ix = 0; ri.oy = 0; ri.ox = 0;
     if (m < p.M) {
       const int gg = p.Gy * p.Gx;
       const int n = m / gg;
@@ -91,17 +292,19 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       const int ox = qx * p.so + p.phx[phase];
       if (oy < p.Ho && ox < p.Wo) {
         ri.n = n; ri.iy = (short)(qy * p.si); ri.ix = (short)(qx * p.si); ri.oy = (short)oy; ri.ox = (short)ox;
+        ri.opix = (n * p.Ho + oy) * p.Wo + ox;
       }
     }
     rows[tid] = ri;
   }
   __syncthreads();
 
+  stamp(1);
   const int cpt = p.Ctot / 64;                      // K tiles per tap
   const int ktot = ntap * cpt;
   const int kper = (ktot + p.ksplit - 1) / p.ksplit;
   const int kt0 = split * kper;
-  const int kt1 = min(ktot, kt0 + kper);
+  const int kt1 = (p.xcd_swizzle & 8) ? min(ktot, kt0 + 1) : min(ktot, kt0 + kper);      // bit 3: PG_DEBUG_ONE_KTILE (fixed-cost experiment)
   if (kt0 >= kt1) return;
 
   f32x16 acc[TM][TN];
@@ -138,8 +341,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     int rn[A_PASS], ryx[A_PASS];
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      const unsigned ra = lds0 + ROWS_OFF + (unsigned)(((tid >> 3) + 64 * i) * (int)sizeof(RowInfo));
-      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4" : "=&v"(rn[i]), "=&v"(ryx[i]) : "v"(ra));
+      const unsigned ra = lds0 + ROWS_OFF + (unsigned)(((tid >> 3) + 64 * i) * (int)sizeof(RowB));
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:8" : "=&v"(rn[i]), "=&v"(ryx[i]) : "v"(ra));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -149,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       const bool ok = (rn[i] >= 0) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
       const long off = ((long)((rn[i] * p.Hi + iy) * p.Wi + ix) * sC + cl) * 2;
       pa[i] = ok ? sp + off : zero_pg + (tid & 7) * 16;
+      if (p.xcd_swizzle & 2) pa[i] = sp + (long)cl * 2;        // PG_DEBUG_OPERAND_A: every row reads pixel 0 (delivery experiment)
     }
     const int base = (tp >> 16) * p.wCout;
 #pragma unroll
@@ -156,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       const int n = nb0 + (tid >> 3) + 64 * i;
       const long off = ((long)(base + p.n_off + n) * p.wCin + cc + chunk * 8) * 2;
       pb[i] = (n < p.n_cnt) ? wp + off : zero_pg + (tid & 7) * 16;
+      if (p.xcd_swizzle & 4) pb[i] = wp + ((long)(base + p.n_off) * p.wCin + cc + chunk * 8) * 2;      // PG_DEBUG_OPERAND_B
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): no scalar (kernel-argument) load stays in flight past here
   };
@@ -225,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  stamp(2);
   f32x4 va0[TM], vb0[TN], va1[TM], vb1[TN];
   fetch(0, 0, va0, vb0);
   int stage = 0;
@@ -259,6 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
 
   // ------------------------------------------------------------------ epilogue (operand stages are free after a barrier)
   __syncthreads();
+  stamp(3);
   float* const T = reinterpret_cast<float*>(smem) + wave * (32 * (32 * TN + 4));
   const int ngc = nb0 + wn0 + (lane % (8 * TN)) * 4;            // first of this lane's 4 columns
   if (p.part != nullptr) {                                      // split-K through the workspace: plain partial tiles
@@ -276,70 +483,62 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     if (p.bias && ngc < p.n_cnt) bv = *reinterpret_cast<const float4*>(p.bias + ngc);
     // fused per-sample statistics of the following norm layer: a 64-row half of the wave tile spans at most two
     // consecutive samples on the layers this kernel serves (>= 64 pixels per sample); the rare rest goes to stat_spill
-    double* red = reinterpret_cast<double*>(smem + 8 * (32 * (32 * TN + 4)) * 4);       // behind the 8 wave tiles
-    int* redn = reinterpret_cast<int*>(red + 8 * 2 * 2 * 2);
+    // Merge inside the workgroup through LDS double atomics on a table indexed by (sample - first sample of the tile), then
+    // ONE pair of global double atomics per sample and workgroup, spread over PG_STAT_SLOTS addresses per sample.  (Round 2
+    // merged with a serial scan over the (wave, half) entries: 3.8 - 6.3 us per workgroup, tools/conv_timeline.py.)
+    double* const stab = reinterpret_cast<double*>(smem + STAT_OFF);
+    const int nbase = m0 / (p.Gy * p.Gx);
+    const int gslot = (bx + by * 5 + bz * 3) % PG_STAT_SLOTS;
+    const int gg = p.Gy * p.Gx;
+    const int wrow0 = __builtin_amdgcn_readfirstlane(m0 + wm0);
+    const bool has_bias = p.bias != nullptr;
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
-      int stat_n0 = 0;
-      if (do_stats) {
-        const int nn = rows[wm0 + 64 * h + lane].n;
-        int nf = nn >= 0 ? nn : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nf = min(nf, __shfl_xor(nf, o));
-        stat_n0 = nf;
-      }
+      // sample of the block's first row / of its last row inside the problem: wave-uniform, from the tile geometry
+      const int mf = wrow0 + 64 * h;
+      const bool any = mf < p.M;
+      const int n_lo = min(mf, p.M - 1) / gg;
+      const bool one_sample = min(mf + 63, p.M - 1) / gg == n_lo;
       float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
+      if (h == 0) stamp(14);
       if (p.out_bf16)
-        vec_store_64x64<TN, true>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
-                                  p.Ho, p.Wo, ngc, bv, do_stats, stat_n0, st_s, st_q, p.stats);
+        big_store_64x64<TN, true>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
+                                  ngc, has_bias, bv, do_stats, n_lo, one_sample, st_s, st_q, p.stats);
       else
-        vec_store_64x64<TN, false>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
-                                   p.Ho, p.Wo, ngc, bv, do_stats, stat_n0, st_s, st_q, p.stats);
-      if (do_stats) {
+        big_store_64x64<TN, false>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
+                                   ngc, has_bias, bv, do_stats, n_lo, one_sample, st_s, st_q, p.stats);
+      if (do_stats && any) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const double ds = wave_sum_d((double)st_s[k]), dq = wave_sum_d((double)st_q[k]);
-          if (lane == 0) { red[((wave * 2 + h) * 2 + k) * 2] = ds; red[((wave * 2 + h) * 2 + k) * 2 + 1] = dq; }
-        }
-        if (lane == 0) redn[wave * 2 + h] = stat_n0;
-      }
-    }
-    if (do_stats) {
-      // block-level merge: (wave, half, k) entries of equal sample are summed by the first of them, then ONE pair of
-      // double atomics per sample and workgroup, spread over PG_STAT_SLOTS addresses per sample
-      __syncthreads();
-      constexpr int NE = 8 * (TM / 2) * 2;
-      if (tid < NE) {
-        const int w = tid / ((TM / 2) * 2), hk = tid - w * ((TM / 2) * 2), h = hk >> 1, k = hk & 1;
-        auto sample = [&](int e) {
-          const int ww = e / ((TM / 2) * 2), hh = (e - ww * ((TM / 2) * 2)) >> 1, kk = e & 1;
-          const int b = redn[ww * 2 + hh];
-          return b == 0x7fffffff ? -1 : b + kk;
-        };
-        auto slot_of = [&](int e) {
-          const int ww = e / ((TM / 2) * 2), hh = (e - ww * ((TM / 2) * 2)) >> 1, kk = e & 1;
-          return ((ww * 2 + hh) * 2 + kk) * 2;
-        };
-        (void)h; (void)k;
-        const int n = sample(tid);
-        double ds = red[slot_of(tid)], dq = red[slot_of(tid) + 1];
-        bool first = true;
-        for (int o = 0; o < tid; ++o) if (sample(o) == n) first = false;
-        if (first && n >= 0) {
-          for (int o = tid + 1; o < NE; ++o) if (sample(o) == n) { ds += red[slot_of(o)]; dq += red[slot_of(o) + 1]; }
-          if (ds != 0.0 || dq != 0.0) {
-            const int slot = (bx + by * 5 + bz * 3) % PG_STAT_SLOTS;
-            atomicAdd(&p.stats[((long)n * PG_STAT_SLOTS + slot) * 2], ds);
-            atomicAdd(&p.stats[((long)n * PG_STAT_SLOTS + slot) * 2 + 1], dq);
+          if (k == 1 && one_sample) break;
+          const double ds = (double)wave_sum_dpp(st_s[k]), dq = (double)wave_sum_dpp(st_q[k]);
+          if (lane == 0 && (ds != 0.0 || dq != 0.0)) {
+            const int n = n_lo + k, sl = n - nbase;
+            if (sl >= 0 && sl < STAT_N) { atomicAdd(&stab[sl * 2], ds); atomicAdd(&stab[sl * 2 + 1], dq); }
+            else {
+              atomicAdd(&p.stats[((long)n * PG_STAT_SLOTS + gslot) * 2], ds);
+              atomicAdd(&p.stats[((long)n * PG_STAT_SLOTS + gslot) * 2 + 1], dq);
+            }
           }
         }
       }
+      if (h == 0) stamp(15);
     }
+    stamp(8);                   // stores issued, wave sums done
+    if (do_stats) {
+      __syncthreads();
+      stamp(9);                 // every wave's stores drained (the barrier waits for vmcnt(0))
+      if (tid < STAT_N * 2) {
+        const double v = stab[tid];
+        if (v != 0.0) atomicAdd(&p.stats[((long)(nbase + (tid >> 1)) * PG_STAT_SLOTS + gslot) * 2 + (tid & 1)], v);
+      }
+    }
+    if (tl_on) { __syncthreads(); stamp(4); }
     return;
   }
   // ---- data-gradient scatter (host guarantees vec_dst: every destination C % 32 == 0, aligned)
   {
-    const bool cval = ngc < p.n_cnt;
+    bool cval = ngc < p.n_cnt;
     const int ngs = cval ? ngc : 0;
     float* gradp = p.dst[0].grad;
     const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
@@ -361,18 +560,34 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     ld.C = C; ld.c = ngs - cst;
     ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
     ld.accum = dacc != 0;
+    if (p.xcd_swizzle & 32) { ld.has_fwd = false; ld.fwdp = gradp; }      // PG_DEBUG_EPI_NOFWD / _NOSTORE / _NOACC: epilogue experiments
+    if (p.xcd_swizzle & 64) cval = false;
+    if (p.xcd_swizzle & 128) ld.accum = false;
+    stamp(8);
+    if (p.dst_io == 1) {          // host: every destination and forward tensor in bf16 STORAGE, >= 32 pixels per sample
+      big_scatter_tile<TM, TN>(acc, T, rows, wm0, lane, ld, cval, __builtin_amdgcn_readfirstlane(m0 + wm0), p.Gy * p.Gx, p.M, p.N);
+    } else {
 #pragma unroll
-    for (int h = 0; h < TM / 2; ++h) {
-      if (p.dst_io == 0)
-        vec_scatter_64x64<TN, 0>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
-      else if (p.dst_io == 1)
-        vec_scatter_64x64<TN, 1>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
-      else
-        vec_scatter_64x64<TN, 2>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+      for (int h = 0; h < TM / 2; ++h) {
+        if (p.dst_io == 0)
+          vec_scatter_64x64<TN, 0>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+        else
+          vec_scatter_64x64<TN, 2>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+      }
     }
   }
+  if (tl_on) { __syncthreads(); stamp(4); }
 }
 
+}  // namespace pg
+// debugging aid: copies the time stamps of the last PG_DEBUG_CONV_TIMELINE launch (n_wgs x 8 uint64) to host memory
+extern "C" int pg_debug_conv_timeline(unsigned long long* host_out, int32_t n_wgs) {
+  if (host_out == nullptr || n_wgs <= 0 || n_wgs > pg::TL_WGS) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pg::kTimeline), sizeof(unsigned long long) * pg::TL_SLOTS * (size_t)n_wgs, 0,
+                             hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+namespace pg {
 // launch helper used by conv_impl (igemm_conv.hip)
 void launch_conv_bf16_big(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
   if (bn == 256) PG_KLAUNCH((conv_bf16_big_kernel<256>), grid, dim3(512), 0, st, k);

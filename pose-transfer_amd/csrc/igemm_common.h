@@ -117,8 +117,8 @@ static __device__ __noinline__ void stat_spill(double* stats, int n, float g) {
 // tile (32 rows x 64 columns, pitch 68) a lane gets 4 consecutive columns of a row: 16 float4 stores per wave, a full
 // 256-byte row segment per 16 lanes.  Used for dense [pixel][n_cnt] destinations (forward output incl. bias and the
 // fused statistics, split-K partial tiles).
-template <int TN_, bool OB = false>
-__device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowInfo* rows, int wm0, int lane,
+template <int TN_, bool OB = false, typename RowT = RowInfo>
+__device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowT* rows, int wm0, int lane,
                                                 float* obase, int n_cnt, int Ho, int Wo, int ngc, float4 bv,
                                                 bool do_stats, int stat_n0, float (&st_s)[2], float (&st_q)[2],
                                                 double* stats) {
@@ -134,21 +134,33 @@ __device__ __forceinline__ void vec_store_64x64(const f32x16 (&acc)[2][TN_], flo
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[i][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // every row pass's LDS reads (row table + transposed values) are issued as ONE batch, then the stores go out back to
+    // back: a pass that reads its row, branches on it, reads its values and stores is three dependent LDS round trips, and
+    // the 8 passes of a half cost ~2.5 us per wave with one workgroup per CU (round 3, tools/conv_timeline.py)
+    constexpr int NP = 32 / RPP;
+    int rn[NP], roy[NP], rox[NP];
+    float4 v[NP];
 #pragma unroll
-    for (int it = 0; it < 32 / RPP; ++it) {
+    for (int it = 0; it < NP; ++it) {
       const int row = it * RPP + rsel;
-      const RowInfo ri = rows[wm0 + i * 32 + row];
-      float4 v = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
-      if (ri.n >= 0 && cval) {
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        st4_any(obase, (unsigned long)((long)((ri.n * Ho + ri.oy) * Wo + ri.ox) * n_cnt + ngc), OB, v);
-        if (do_stats) {
-          const float s4 = (v.x + v.y) + (v.z + v.w);
-          const float q4 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
-          const int dn = ri.n - stat_n0;
-          if (dn == 0) { st_s[0] += s4; st_q[0] += q4; }
-          else if (dn == 1) { st_s[1] += s4; st_q[1] += q4; }
-          else { stat_spill(stats, ri.n, v.x); stat_spill(stats, ri.n, v.y); stat_spill(stats, ri.n, v.z); stat_spill(stats, ri.n, v.w); }
+      const RowT ri = rows[wm0 + i * 32 + row];
+      rn[it] = ri.n; roy[it] = ri.oy; rox[it] = ri.ox;
+      v[it] = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const bool ok = rn[it] >= 0 && cval;
+      v[it].x += bv.x; v[it].y += bv.y; v[it].z += bv.z; v[it].w += bv.w;
+      if (ok) st4_any(obase, (unsigned long)((long)((rn[it] * Ho + roy[it]) * Wo + rox[it]) * n_cnt + ngc), OB, v[it]);
+      if (do_stats) {
+        const float s4 = (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        const float q4 = fmaf(v[it].x, v[it].x, fmaf(v[it].y, v[it].y, fmaf(v[it].z, v[it].z, v[it].w * v[it].w)));
+        const int dn = rn[it] - stat_n0;
+        st_s[0] += (ok && dn == 0) ? s4 : 0.f; st_q[0] += (ok && dn == 0) ? q4 : 0.f;
+        st_s[1] += (ok && dn == 1) ? s4 : 0.f; st_q[1] += (ok && dn == 1) ? q4 : 0.f;
+        if (ok && dn > 1) {
+          stat_spill(stats, rn[it], v[it].x); stat_spill(stats, rn[it], v[it].y);
+          stat_spill(stats, rn[it], v[it].z); stat_spill(stats, rn[it], v[it].w);
         }
       }
     }
@@ -169,8 +181,8 @@ struct LaneDst {
 };
 // IO: 0 = fp32 tensors, 1 = gradient AND forward tensor in bf16 STORAGE (compile-time: the batched loads stay straight-line
 // code), 2 = per-destination run-time flags (mixed launches; the loads sit under wave-uniform branches)
-template <int TN_, int IO = 0>
-__device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowInfo* rows, int wm0, int lane,
+template <int TN_, int IO = 0, typename RowT = RowInfo>
+__device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowT* rows, int wm0, int lane,
                                                   const LaneDst& d, bool cval, int Ho, int Wo) {
   const bool gbf = IO == 1 ? true : (IO == 0 ? false : d.grad_bf16);
   const bool fbf = IO == 1 ? true : (IO == 0 ? false : d.fwd_bf16);
@@ -194,7 +206,7 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int row = (h * 4 + u) * RPP + rsel;
-        const RowInfo ri = rows[wm0 + i * 32 + row];
+        const RowT ri = rows[wm0 + i * 32 + row];
         ok[u] = (ri.n >= 0) & cval;
         const int nn = ok[u] ? ri.n : 0;
         idx[u] = ok[u] ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;

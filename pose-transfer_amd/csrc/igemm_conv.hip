@@ -1722,6 +1722,14 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
       static const long big_min = getenv("PG_BF16_BIG_MIN") ? atol(getenv("PG_BF16_BIG_MIN")) : 192;   // swept (tools/sweep_bf16_big_min.sh): 448 -> 523 / 814, 192 -> 529 / 832 img/s (256^2 batch 4 / 224^2 batch 8)
       if (wgs >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr) {
         k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
+        if (getenv("PG_DEBUG_OPERAND_A")) k.xcd_swizzle |= 2;
+        if (getenv("PG_DEBUG_OPERAND_B")) k.xcd_swizzle |= 4;
+        if (getenv("PG_DEBUG_ONE_KTILE")) k.xcd_swizzle |= 8;
+        if (getenv("PG_DEBUG_CONV_TIMELINE")) k.xcd_swizzle |= 16;
+        if (getenv("PG_DEBUG_EPI_NOFWD")) k.xcd_swizzle |= 32;
+        if (getenv("PG_DEBUG_EPI_NOSTORE")) k.xcd_swizzle |= 64;
+        if (getenv("PG_DEBUG_EPI_NOACC")) k.xcd_swizzle |= 128;
+        if (k.dst_io == 1 && k.Gy * k.Gx < 32) k.dst_io = 2;      // the pipelined bf16 scatter assumes <= 2 samples per 32 rows
         launch_conv_bf16_big(k, bn, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
         last_info() = (bn == 256 ? 4 : (bn == 128 ? 5 : 6)) | (amode << 4) | (bmode << 8) | (1 << 16);

@@ -87,6 +87,33 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(const TIn* m, int N, 
   }
 }
 
+// Bounding box of the non-zero pixels of every (sample, transform) mask plane (N, T, H0, W0): out[(n*T+t)*4 ..] = ymin, ymax, xmin,
+// xmax; an empty plane gives ymax < ymin.  One workgroup per plane, coalesced scan (84 MB at batch 32: ~20 us).
+template <typename TIn>
+__global__ __launch_bounds__(256) void mask_bbox_kernel(const TIn* m, int H0, int W0, int* out) {
+  __shared__ int red[4][256];
+  const TIn* b = m + (long)blockIdx.x * H0 * W0;
+  int y0 = H0, y1 = -1, x0 = W0, x1 = -1;
+  for (int i = threadIdx.x; i < H0 * W0; i += 256) {
+    if (b[i] != (TIn)0) {
+      const int y = i / W0, x = i - y * W0;
+      y0 = min(y0, y); y1 = max(y1, y); x0 = min(x0, x); x1 = max(x1, x);
+    }
+  }
+  red[0][threadIdx.x] = y0; red[1][threadIdx.x] = y1; red[2][threadIdx.x] = x0; red[3][threadIdx.x] = x1;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if ((int)threadIdx.x < s_) {
+      red[0][threadIdx.x] = min(red[0][threadIdx.x], red[0][threadIdx.x + s_]);
+      red[1][threadIdx.x] = max(red[1][threadIdx.x], red[1][threadIdx.x + s_]);
+      red[2][threadIdx.x] = min(red[2][threadIdx.x], red[2][threadIdx.x + s_]);
+      red[3][threadIdx.x] = max(red[3][threadIdx.x], red[3][threadIdx.x + s_]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[(long)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
 struct Theta { float t00, t01, t02, t10, t11, t12; };
 
 // normalize_transforms + per-level translation rescale, in the reference's evaluation order
@@ -407,7 +434,7 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
 template <bool GB, bool DB, int V = 4>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, const uint8_t* amax, const float* warps,
                                                               const float* masks, int T, int C, int h, int w, int H0, int W0,
-                                                              int align, void* dfeat) {
+                                                              int align, void* dfeat, const int* bbox) {
   // GB / DB: the incoming gradient / the written input gradient are bf16 tensors (bf16 STORAGE)
   constexpr int ESG = GB ? 2 : 4, ESD = DB ? 2 : 4;
   constexpr int FLAT = GATHER_T * GATHER_CAP;             // worst case per input pixel: no overflow possible
@@ -418,9 +445,23 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   __shared__ int e_cnt[GATHER_PIX];
   __shared__ float xs_t[GATHER_MAXDIM], ys_t[GATHER_MAXDIM];      // normalised grid coordinate per column / row (host: h, w <= 1024)
   const int n = blockIdx.y;
+  // bbox (optional, pg_mask_bbox): per (sample, transform) the bounding box of the non-zero FULL-resolution mask.  At this level a
+  // mask pixel can be non-zero only inside the box scaled to the level and grown by the bilinear down-sampling's reach; a
+  // (pixel, transform) pair whose candidate box misses it is skipped before any mask load — the limb masks cover a few per cent
+  // of the image, so phase 1 (16 strided mask loads + tap evaluation per pair) runs for ~2 of the 10 transforms.
+  __shared__ int mb[MAXT][4];
   if (threadIdx.x < T) {
     th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
     inv[threadIdx.x] = invert_warp(th[threadIdx.x], h, w, align);
+    int y0 = 0, y1 = h - 1, x0 = 0, x1 = w - 1;
+    if (bbox != nullptr) {
+      const int* b = bbox + ((long)n * T + threadIdx.x) * 4;       // ymin, ymax, xmin, xmax at (H0, W0); empty: ymax < ymin
+      const float sy = (float)h / (float)H0, sx = (float)w / (float)W0;
+      y0 = (int)floorf((float)(b[0] - 1) * sy) - 2; y1 = (int)ceilf((float)(b[1] + 1) * sy) + 2;
+      x0 = (int)floorf((float)(b[2] - 1) * sx) - 2; x1 = (int)ceilf((float)(b[3] + 1) * sx) + 2;
+      if (b[1] < b[0] || b[3] < b[2]) { y0 = h + 8; y1 = -8; x0 = w + 8; x1 = -8; }
+    }
+    mb[threadIdx.x][0] = y0; mb[threadIdx.x][1] = y1; mb[threadIdx.x][2] = x0; mb[threadIdx.x][3] = x1;
   }
   for (int k = threadIdx.x; k < w; k += 256) xs_t[k] = warp_norm_coord(k, w, align);
   for (int k = threadIdx.x; k < h; k += 256) ys_t[k] = warp_norm_coord(k, h, align);
@@ -447,6 +488,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
       const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
       const int nj = j1 - j0 + 1, tot = nj * (i1 - i0 + 1);
       if (nj <= 0 || tot <= 0) continue;
+      if (i1 < mb[t][0] || i0 > mb[t][1] || j1 < mb[t][2] || j0 > mb[t][3]) continue;      // every candidate has a zero mask
       float mv[GATHER_CAP];
       int ci[GATHER_CAP], cj[GATHER_CAP];
       {
@@ -687,10 +729,24 @@ extern "C" int pg_warp_mask_max_fwd(const float* feat, const float* aff, const f
   return pg_warp_mask_max_fwd_io(feat, aff, warps, lvl_masks, N, T, C, h, w, H0, W0, align_corners, out, argmax, 0, stream);
 }
 
-// io_flags: bit 0 = `gout` is bf16, bit 1 = `dfeat` is bf16
-extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, const float* warps,
-                                       const float* lvl_masks, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w,
-                                       int32_t H0, int32_t W0, int32_t align_corners, void* dfeat, int32_t io_flags, void* stream) {
+extern "C" int pg_mask_bbox(const void* masks, int32_t is_f64, int32_t N, int32_t T, int32_t H0, int32_t W0, int32_t* bbox,
+                            void* stream) {
+  PG_REQUIRE(masks && bbox && N > 0 && T > 0 && H0 > 0 && W0 > 0, "pg_mask_bbox: bad arguments");
+  if (is_f64)
+    PG_KLAUNCH(mask_bbox_kernel<double>, dim3((unsigned)(N * T)), dim3(256), 0, (hipStream_t)stream, (const double*)masks, H0, W0,
+               (int*)bbox);
+  else
+    PG_KLAUNCH(mask_bbox_kernel<float>, dim3((unsigned)(N * T)), dim3(256), 0, (hipStream_t)stream, (const float*)masks, H0, W0,
+               (int*)bbox);
+  PG_LAUNCH_OK("pg_mask_bbox");
+  return 0;
+}
+
+// io_flags: bit 0 = `gout` is bf16, bit 1 = `dfeat` is bf16.  bbox: NULL, or the [N][T][4] boxes of pg_mask_bbox over the
+// full-resolution masks the level masks were made from.
+extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax, const float* warps, const float* lvl_masks,
+                                         const int32_t* bbox, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w, int32_t H0,
+                                         int32_t W0, int32_t align_corners, void* dfeat, int32_t io_flags, void* stream) {
   PG_REQUIRE(gout && argmax && warps && lvl_masks && dfeat, "pg_warp_mask_max_bwd: null pointer");
   PG_REQUIRE(T >= 1 && T <= MAXT && C % 4 == 0 && N > 0, "pg_warp_mask_max_bwd: need T<=32, C%%4==0");
   static const bool no_gather = getenv("PG_WARP_BWD_SCATTER") != nullptr;       // ablation: round-1 scatter kernel only
@@ -711,9 +767,10 @@ extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, 
     static const bool no_v8b = getenv("PG_WARP_NO_V8") != nullptr;
     if (gb && db && C % 8 == 0 && !no_v8b)
       PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8>), dim3(gtiles, N), dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w,
-                 H0, W0, align_corners, dfeat);
+                 H0, W0, align_corners, dfeat, (const int*)bbox);
     else
-      PGW_BWD(warp_bwd_gather_kernel, dim3(gtiles, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat);
+      PGW_BWD(warp_bwd_gather_kernel, dim3(gtiles, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat,
+              (const int*)bbox);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
     // (a sample without wide transforms costs one early-exiting workgroup round: keep that grid small)
     PGW_BWD(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
@@ -726,6 +783,12 @@ extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, 
 #undef PGW_BWD
   PG_LAUNCH_OK("pg_warp_mask_max_bwd");
   return 0;
+}
+extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, const float* warps,
+                                       const float* lvl_masks, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w,
+                                       int32_t H0, int32_t W0, int32_t align_corners, void* dfeat, int32_t io_flags, void* stream) {
+  return pg_warp_mask_max_bwd_bbox(gout, argmax, warps, lvl_masks, nullptr, N, T, C, h, w, H0, W0, align_corners, dfeat, io_flags,
+                                   stream);
 }
 extern "C" int pg_warp_mask_max_bwd(const float* gout, const uint8_t* argmax, const float* warps,
                                     const float* lvl_masks, int32_t N, int32_t T, int32_t C, int32_t h, int32_t w,

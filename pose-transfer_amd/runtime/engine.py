@@ -325,6 +325,7 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
     return ent[2 + idx]
 
 
+WARP_BBOX = os.environ.get("PG_NO_WARP_BBOX") is None    # ablation switch: warp backward without the mask bounding boxes
 BATCH_WT = os.environ.get("PG_NO_BATCH_WT") is None      # ablation switch: one pg_weights_to_bf16 launch per layer and step
 _BF_W_EXT = {}              # (data_ptr, numel, transposed) -> (weakref to the weight tensor, its bf16 buffer)
 # bf16 STORAGE (round 3): on the bf16 data path the GENERATOR keeps its raw activations and the gradients flowing through
@@ -978,6 +979,7 @@ class GeneratorEngine:
         self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh): weight- and data-gradient operand
         self.wt_out = torch.zeros((2 if deformable else 1) * self.enc[0] + self.dec[-2], 32, **f32)   # [cin][(tap, co)]
         self.warps = torch.empty(N, max(self.T, 1), 8, **f32)
+        self.mask_bbox = torch.empty(N, max(self.T, 1), 4, dtype=torch.int32, device=device) if self.masked else None
         self.input = None
         self._drop_counter = 0
         self.drop_stream = "drop"      # mixed into the dropout key (the trainer sets seed / rank / global iteration)
@@ -1067,6 +1069,9 @@ class GeneratorEngine:
                 for l in range(self.nwarp):
                     L.call("pg_mask_pyramid", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W,
                            self.hw[l][0], self.hw[l][1], L.ptr(self.lvl_masks[l]), L.stream())
+                if WARP_BBOX:       # bounding boxes of the non-zero mask regions: the warp backward skips what cannot contribute
+                    L.call("pg_mask_bbox", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W, L.ptr(self.mask_bbox),
+                           L.stream())
         # ---- encoders (reference networks.py:193-202)
         bfs = self.bfs
         assert bfs == (bf16_store() and bfs), "the engine was built for another storage mode (PRECISION changed?)"
@@ -1262,14 +1267,10 @@ class GeneratorEngine:
                         self._dsts_for(srcs, True))
         # ---- deformable skips
         for l in range(self.nwarp):
-            if self.bfs:
-                L.call("pg_warp_mask_max_bwd_io", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
-                       L.ptr(self.lvl_masks[l]), N, self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align,
-                       L.ptr(self.e_dz["encoder_app"][l]), 3, L.stream())
-                continue
-            L.call("pg_warp_mask_max_bwd", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
-                   L.ptr(self.lvl_masks[l]), N, self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align,
-                   L.ptr(self.e_dz["encoder_app"][l]), L.stream())
+            L.call("pg_warp_mask_max_bwd_bbox", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
+                   L.ptr(self.lvl_masks[l]), L.ptr(self.mask_bbox) if (self.masked and WARP_BBOX) else None, N, self.T, self.enc[l],
+                   self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.e_dz["encoder_app"][l]), 3 if self.bfs else 0,
+                   L.stream())
         # ---- encoders
         for l in range(self.nlev - 1, 0, -1):
             for e in self.encs:

@@ -135,6 +135,9 @@ _PROTOS = {
     "pg_norm_bwd_apply_io": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
     "pg_warp_mask_max_fwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "pg_warp_mask_max_bwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "pg_debug_conv_timeline": [_vp, _i32],
+    "pg_mask_bbox": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pg_warp_mask_max_bwd_bbox": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "pg_stem_conv_bf16_v3": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp],
     "pg_stem_wgrad_bf16_ex": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
     "pg_bias_grad_bf16": [_vp, _i64, _i32, _vp, _vp],

@@ -332,3 +332,67 @@ def test_launch_tape_replay_matches_eager(prec, monkeypatch):
     a, b, c = batches
     m2.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3]}, b[0], b[1], od)
     assert m2.disc.arena.step == 5
+
+
+# ------------------------------------------------------------------------------------------ warp backward, mask boxes
+@pytest.mark.parametrize("io", [0, 3])
+@pytest.mark.parametrize("case", ["limbs_256_s2", "limbs_96x80_s4", "bands_and_empty", "single_pixels"])
+def test_warp_backward_with_mask_boxes_equals_unpruned(case, io):
+    """pg_mask_bbox against numpy, and pg_warp_mask_max_bwd_bbox (pairs whose candidates lie outside the scaled box are
+    skipped) against the same kernel without boxes: a skipped pair can only have carried zero masks, so the two differ by
+    the summation order alone (the per-pixel candidate lists are filled by racing waves): a few fp32 ulps, one bf16 ulp."""
+    if case == "limbs_256_s2":
+        N, C, H0, W0, s = 2, 64, 256, 256, 2
+        wr, mk = synth.warps_and_masks(31, case, N, H0, W0)
+    elif case == "limbs_96x80_s4":
+        N, C, H0, W0, s = 3, 8, 96, 80, 4
+        wr, mk = synth.warps_and_masks(32, case, N, H0, W0)
+    elif case == "bands_and_empty":
+        N, C, H0, W0, s = 2, 8, 48, 40, 2
+        wr, _ = synth.warps_and_masks(33, case, N, H0, W0, p_nopoint=0.0)
+        mk = np.zeros((N, 10, H0, W0), np.float32)
+        mk[:, 0] = 1.0
+        for k in range(1, 8):
+            mk[:, k, (k * 5) % H0:(k * 5) % H0 + 9, 3 * k:3 * k + 11] = 0.5 + 0.05 * k
+        mk[0, 8, 0, 0] = 1.0; mk[0, 8, H0 - 1, W0 - 1] = 1.0               # corners only: the box is the whole plane
+    else:
+        N, C, H0, W0, s = 2, 8, 64, 64, 2
+        wr, _ = synth.warps_and_masks(34, case, N, H0, W0, p_nopoint=0.0)
+        mk = np.zeros((N, 10, H0, W0), np.float32)
+        for k in range(10):                                                 # 2x2 blobs, on level-pixel borders too
+            y, x = (7 * k + 3) % (H0 - 1), (8 * k + 7) % (W0 - 1)
+            mk[:, k, y:y + 2, x:x + 2] = 1.0
+    h, w = H0 // s, W0 // s
+    mkd, wrd = t(mk).to(DEV), t(wr).to(DEV)
+    box = torch.empty(N, 10, 4, dtype=torch.int32, device=DEV)
+    for dt in (torch.float32, torch.float64):
+        md = mkd.to(dt)
+        L.call("pg_mask_bbox", L.ptr(md), 1 if dt == torch.float64 else 0, N, 10, H0, W0, L.ptr(box), L.stream())
+        b = box.cpu().numpy()
+        for n in range(N):
+            for k in range(10):
+                ys, xs = np.nonzero(mk[n, k])
+                if len(ys) == 0:
+                    assert b[n, k, 1] < b[n, k, 0], (n, k, b[n, k])
+                else:
+                    assert tuple(b[n, k]) == (ys.min(), ys.max(), xs.min(), xs.max()), (n, k, b[n, k])
+    lvl = torch.empty(N, h, w, 10, device=DEV)
+    L.call("pg_mask_pyramid", L.ptr(mkd), 0, N, 10, H0, W0, h, w, L.ptr(lvl), L.stream())
+    dt = torch.bfloat16 if io else torch.float32
+    feat = nhwc(t(synth.normal(31, case + "/f", (N, C, h, w)))).to(DEV).to(dt).contiguous()
+    go = nhwc(t(synth.normal(31, case + "/go", (N, C, h, w)))).to(DEV).to(dt).contiguous()
+    out = torch.empty(N, h, w, C, device=DEV, dtype=dt)
+    arg = torch.empty(N, h, w, C, dtype=torch.uint8, device=DEV)
+    L.call("pg_warp_mask_max_fwd_io", L.ptr(feat), None, L.ptr(wrd), L.ptr(lvl), N, 10, C, h, w, H0, W0, 0, L.ptr(out), L.ptr(arg),
+           io, L.stream())
+    res = []
+    for bx in (None, box):
+        d = torch.zeros(N, h, w, C, device=DEV, dtype=dt)
+        L.call("pg_warp_mask_max_bwd_bbox", L.ptr(go), L.ptr(arg), L.ptr(wrd), L.ptr(lvl), L.ptr(bx) if bx is not None else None,
+               N, 10, C, h, w, H0, W0, 0, L.ptr(d), io, L.stream())
+        res.append(d.float().cpu())
+    assert float(res[0].abs().max()) > 0.1, (float(out.float().abs().max()), arg.unique().tolist(), float(go.float().abs().max()),
+                                             float(lvl.max()), float(feat.float().abs().max()))
+    tol = (2.0 ** -7 if io else 4e-6) * float(res[0].abs().max())
+    assert float((res[0] - res[1]).abs().max()) <= tol, float((res[0] - res[1]).abs().max())
+    assert (res[0] != res[1]).float().mean() < (0.02 if io else 0.2)
