@@ -206,6 +206,263 @@ __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Data gradient AND weight gradient of the output convolution in ONE pass on the matrix cores (round 3, bf16 STORAGE, DIRECT
+// gradient).  The streaming kernels above are VALU-bound (27 v_readlane + 54 packed FMAs + ~40 epilogue instructions per pixel
+// and wave) and each reads the three activated forward tensors: 0.85 + 0.68 ms at batch 32 for 1.07 GB read + 1.07 GB written.
+// As matrix products the layer is tiny:
+//     dX^T[ci][pixel] = Wt[ci][t] * G^T[t][pixel]            (K = 27 -> 32)
+//     dW[t][ci]       = sum_pixels G[pixel][t] * x[pixel][ci] (K = pixels)
+// A workgroup walks 32-pixel tiles (one image-row segment); wave w owns channels 64 w .. 64 w + 63 (two 32-channel tiles):
+//   * the tile's 3 x 3 x 34 patch of dpre (NCHW, zero outside the image) is staged once per workgroup in LDS (double-buffered,
+//     one raw s_barrier per tile); both G operands are gathered from it with ds_read_b32 — data gradient: lane = pixel, 16 of
+//     the 32 k values; weight gradient: lane = t = (tap, channel), 16 of the 32 pixels;
+//   * the wave's forward values arrive as 16 bytes per lane (full 64-byte channel runs per pixel) into a wave-private LDS
+//     tile [32 pixels][64 channels]; from there: act' per accumulator quad (lane = pixel, 4 consecutive channels: ds_read_b64)
+//     and the weight gradient's A operand [m = ci][k = pixel] through ds_read_b64_tr_b16 (addressing as wgrad_bf16.hip);
+//   * M = channel, N = pixel for the data gradient, so an accumulator register quad is four consecutive channels of one pixel;
+//     the results go back through the same LDS tile and leave as 16 bytes per lane;
+//   * the weight gradient accumulates in two persistent accumulator tiles per wave, written once per workgroup to the partial
+//     buffer of out_conv_wgrad_reduce_kernel;
+//   * the next tile's global loads are requested BEFORE this tile's stores: gfx950 counts loads and stores in one vmcnt, a
+//     load waited for behind a store also waits for the store's acknowledgement.
+// Host: every destination bf16 with an ACTIVATED bf16 forward operand, no affine / mask / accumulate, C % 32 == 0, W % 32 == 0.
+typedef __bf16 obf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned opack_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+constexpr int OPATCH = 336;        // 3 channels x 3 rows x pitch 36 (34 used) = 324 floats + spare
+
+__global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgradK p) {
+  __shared__ __attribute__((aligned(16))) uint4 a_lds[8 * 2 * 64];          // [channel tile][k step][lane]: 16 KB
+  __shared__ __attribute__((aligned(16))) char x_lds[4 * 32 * 128];         // per wave: [32 pixels][64 channels] bf16
+  __shared__ float patch[2][OPATCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int nct = p.Ctot / 32;
+  for (int i = tid; i < 8 * 2 * 64; i += 256) {
+    const int ct = i >> 7, ks = (i >> 6) & 1, ln = i & 63;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (ct < nct) {
+      const int k0 = ks * 16 + (ln >> 5) * 8;
+      const float* w = p.Wt + (long)(ct * 32 + (ln & 31)) * 32 + k0;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (k0 + j < ODG_T) ? w[j] : 0.f;        // the pad columns of Wt are not read
+      o = make_uint4(opack_bf16(v[0], v[1]), opack_bf16(v[2], v[3]), opack_bf16(v[4], v[5]), opack_bf16(v[6], v[7]));
+    }
+    a_lds[i] = o;
+  }
+  for (int i = tid; i < 2 * OPATCH; i += 256) patch[0][i] = 0.f;
+  const int HW = p.H * p.W;
+  // data-gradient gather: k = ks*16 + lhi*8 + j = (tap, channel) of THIS lane's pixel: patch[c][1 + dy][1 + l31 + dx];
+  // k >= 27 reads the spare cell (0)
+  int goff[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = (q >> 3) * 16 + lhi * 8 + (q & 7);
+    const int tap = k / 3, c = k - tap * 3, r = tap / 3, s_ = tap - r * 3;
+    goff[q] = k < ODG_T ? c * 108 + (2 - r) * 36 + (2 - s_) + l31 : 330;
+  }
+  // weight-gradient gather: lane t = l31 = (tap, channel), pixel k of the tile: patch[c][1 + dy][1 + k + dx]; lanes t >= 27 read
+  // t = 0's cells (their accumulator columns are never stored)
+  const int tt = l31 < ODG_T ? l31 : 0;
+  const int t_tap = tt / 3, t_c = tt - t_tap * 3, t_r = t_tap / 3, t_s = t_tap - t_r * 3;
+  const int tbase = t_c * 108 + (2 - t_r) * 36 + (2 - t_s) + lhi * 8;
+
+  const int tpr = p.W / 32;
+  const int ntiles = p.npix / 32;
+  const int ct0 = 2 * wave;
+  const bool act0 = ct0 < nct, act1 = ct0 + 1 < nct;
+  // destinations of this wave's two channel tiles (wave-uniform, fixed for the launch; constant-index picks)
+  unsigned short* g16[2]; const unsigned short* f16[2]; int Cd[2], c0d[2]; float dsl[2];
+#pragma unroll
+  for (int cq = 0; cq < 2; ++cq) {
+    const int ct = min(ct0 + cq, nct - 1);
+    float* gp = p.dst[0].grad; const float* fp = p.dst[0].fwd; int C = p.dst[0].C, st = p.dstart[0], ac = p.dst[0].act;
+#pragma unroll
+    for (int q = 1; q < PG_MAX_SRC; ++q)
+      if (q < p.ndst && ct * 32 >= p.dstart[q]) { gp = p.dst[q].grad; fp = p.dst[q].fwd; C = p.dst[q].C; st = p.dstart[q]; ac = p.dst[q].act; }
+    g16[cq] = reinterpret_cast<unsigned short*>(gp); f16[cq] = reinterpret_cast<const unsigned short*>(fp);
+    Cd[cq] = C; c0d[cq] = ct * 32 - st; dsl[cq] = act_slope(ac);
+  }
+  char* const xt_ = x_lds + wave * 32 * 128;
+  const unsigned xb = (unsigned)(size_t)xt_;
+  const int r4 = (lane >> 2) & 3, cql = lane & 3, mb = (lane >> 4) & 1;
+  unsigned fa[2];
+#pragma unroll
+  for (int cq = 0; cq < 2; ++cq) fa[cq] = xb + (unsigned)((8 * lhi + r4) * 128) + (unsigned)((((cq * 32) >> 3) + 2 * mb + (cql >> 1)) << 4) + ((cql & 1) << 3);
+  char* const xq = xt_ + l31 * 128 + 8 * lhi;            // accumulator layout: this lane's pixel row, + (cq*32 + 8 g) * 2
+  char* const xr = xt_ + (lane >> 2) * 128 + (lane & 3) * 16;      // row-major layout: + i * 16 * 128 + cq * 64
+
+  f32x16 accw[2];
+#pragma unroll
+  for (int cq = 0; cq < 2; ++cq)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[cq][r] = 0.f;
+
+  // the tile's forward values (row-major, [cq][i]) and this thread's patch elements (tid, tid + 256 < 306) — scalars, not arrays:
+  // arrays written through a lambda stayed in scratch memory (144 bytes, every access a vmcnt round trip: 0.95 ms per launch)
+  uint4 xin00, xin01, xin10, xin11;
+  float pin0, pin1;             // raw loads; zeroed at PG_OCB_PUT_PATCH (a select right behind the load would wait for it)
+  bool pok0 = false, pok1 = false;
+  int pix0 = 0;
+  const int pi0 = tid, pi1 = tid + 256;
+  const int pc0 = pi0 / 102, prr0 = (pi0 - pc0 * 102) / 34, pxx0 = pi0 - pc0 * 102 - prr0 * 34;
+  const int pc1 = pi1 / 102, prr1 = (pi1 - pc1 * 102) / 34, pxx1 = pi1 - pc1 * 102 - prr1 * 34;
+  const bool p1_on = pi1 < 306;
+  const int pslot0 = pc0 * 108 + prr0 * 36 + pxx0, pslot1 = p1_on ? pc1 * 108 + prr1 * 36 + pxx1 : 331;
+  const unsigned xoff0 = (unsigned)(lane >> 2) * (unsigned)Cd[0] + (unsigned)(c0d[0] + (lane & 3) * 8);
+  const unsigned xoff1 = (unsigned)(lane >> 2) * (unsigned)Cd[1] + (unsigned)(c0d[1] + (lane & 3) * 8);
+#define PG_OCB_REQUEST(T)                                                                                          \
+  do {                                                                                                             \
+    const int row_ = (T) / tpr, xt_i = (T) - row_ * tpr;                                                           \
+    const int n_ = row_ / p.H, y_ = row_ - n_ * p.H;                                                               \
+    pix0 = row_ * p.W + xt_i * 32;                                                                                 \
+    const unsigned e0_ = act0 ? (unsigned)pix0 * (unsigned)Cd[0] + xoff0 : 0u;                                     \
+    const unsigned e1_ = act1 ? (unsigned)pix0 * (unsigned)Cd[1] + xoff1 : 0u;                                     \
+    xin00 = *reinterpret_cast<const uint4*>(f16[0] + e0_);                                                         \
+    xin01 = *reinterpret_cast<const uint4*>(f16[0] + e0_ + (act0 ? 16u * (unsigned)Cd[0] : 0u));                   \
+    xin10 = *reinterpret_cast<const uint4*>(f16[1] + e1_);                                                         \
+    xin11 = *reinterpret_cast<const uint4*>(f16[1] + e1_ + (act1 ? 16u * (unsigned)Cd[1] : 0u));                   \
+    const int gy0_ = y_ - 1 + prr0, gx0_ = xt_i * 32 - 1 + pxx0;                                                   \
+    const bool ok0_ = gy0_ >= 0 && gy0_ < p.H && gx0_ >= 0 && gx0_ < p.W;                                          \
+    const float v0_ = p.dpre[ok0_ ? ((long)(n_ * 3 + pc0) * p.H + gy0_) * p.W + gx0_ : 0];                         \
+    pin0 = v0_; pok0 = ok0_;                                                                                       \
+    const int gy1_ = y_ - 1 + prr1, gx1_ = xt_i * 32 - 1 + pxx1;                                                   \
+    const bool ok1_ = p1_on && gy1_ >= 0 && gy1_ < p.H && gx1_ >= 0 && gx1_ < p.W;                                 \
+    const float v1_ = p.dpre[ok1_ ? ((long)(n_ * 3 + pc1) * p.H + gy1_) * p.W + gx1_ : 0];                         \
+    pin1 = v1_; pok1 = ok1_;                                                                                       \
+  } while (0)
+#define PG_OCB_PUT_PATCH(BUF)                                        \
+  do {                                                               \
+    patch[BUF][pslot0] = pok0 ? pin0 : 0.f;                          \
+    if (p1_on) patch[BUF][pslot1] = pok1 ? pin1 : 0.f;               \
+  } while (0)
+
+  int tile = blockIdx.x;           // host: gridDim.x <= ntiles
+  PG_OCB_REQUEST(tile);
+  __syncthreads();                 // weights, zeroed patches
+  PG_OCB_PUT_PATCH(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int buf = 0;
+  while (true) {
+    const int cpix0 = pix0;
+    // ---- forward values -> the wave's LDS tile; both gradient operands from the patch
+    *reinterpret_cast<uint4*>(xr) = xin00;
+    *reinterpret_cast<uint4*>(xr + 16 * 128) = xin01;
+    *reinterpret_cast<uint4*>(xr + 64) = xin10;
+    *reinterpret_cast<uint4*>(xr + 16 * 128 + 64) = xin11;
+    // the next tile's global loads go out NOW (their registers are free again): a whole tile of work hides their latency, and
+    // they precede this tile's stores
+    tile += gridDim.x;
+    const bool more = tile < ntiles;
+    if (more) PG_OCB_REQUEST(tile);
+    float gv[16], gt[16];
+    const float* const pb = patch[buf];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gv[q] = pb[goff[q]];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gt[q] = pb[tbase + (q >> 3) * 16 + (q & 7)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint2 fw[8];
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fw[cq * 4 + g] = *reinterpret_cast<const uint2*>(xq + (cq * 32 + 8 * g) * 2);
+    const obf16x8 b0 = __builtin_bit_cast(obf16x8, make_uint4(opack_bf16(gv[0], gv[1]), opack_bf16(gv[2], gv[3]), opack_bf16(gv[4], gv[5]), opack_bf16(gv[6], gv[7])));
+    const obf16x8 b1 = __builtin_bit_cast(obf16x8, make_uint4(opack_bf16(gv[8], gv[9]), opack_bf16(gv[10], gv[11]), opack_bf16(gv[12], gv[13]), opack_bf16(gv[14], gv[15])));
+    const obf16x8 gb0 = __builtin_bit_cast(obf16x8, make_uint4(opack_bf16(gt[0], gt[1]), opack_bf16(gt[2], gt[3]), opack_bf16(gt[4], gt[5]), opack_bf16(gt[6], gt[7])));
+    const obf16x8 gb1 = __builtin_bit_cast(obf16x8, make_uint4(opack_bf16(gt[8], gt[9]), opack_bf16(gt[10], gt[11]), opack_bf16(gt[12], gt[13]), opack_bf16(gt[14], gt[15])));
+    // ---- data gradient
+    uint2 res[8];
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int ct = ct0 + cq;
+      const obf16x8 a0 = __builtin_bit_cast(obf16x8, a_lds[((ct & 7) * 2 + 0) * 64 + lane]);
+      const obf16x8 a1 = __builtin_bit_cast(obf16x8, a_lds[((ct & 7) * 2 + 1) * 64 + lane]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint2 f = fw[cq * 4 + g];
+        const float f4[4] = {__uint_as_float(f.x << 16), __uint_as_float(f.x & 0xffff0000u), __uint_as_float(f.y << 16),
+                             __uint_as_float(f.y & 0xffff0000u)};
+        float r4v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r4v[e] = acc[4 * g + e] * act_grad_s(f4[e], dsl[cq]);
+        res[cq * 4 + g] = make_uint2(opack_bf16(r4v[0], r4v[1]), opack_bf16(r4v[2], r4v[3]));
+      }
+    }
+    // ---- weight gradient (k = the tile's 32 pixels)
+    {
+      unsigned long long x00l, x00h, x01l, x01h, x10l, x10h, x11l, x11h;      // x^T fragments [cq][k step] lo / hi
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
+          "ds_read_b64_tr_b16 %2, %8 offset:2048\n\tds_read_b64_tr_b16 %3, %8 offset:2560\n\t"
+          "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:512\n\t"
+          "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:2560\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(x00l), "=&v"(x00h), "=&v"(x01l), "=&v"(x01h), "=&v"(x10l), "=&v"(x10h), "=&v"(x11l), "=&v"(x11h)
+          : "v"(fa[0]), "v"(fa[1])
+          : "memory");
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      accw[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(obf16x8, (u64x2){x00l, x00h}), gb0, accw[0], 0, 0, 0);
+      accw[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(obf16x8, (u64x2){x01l, x01h}), gb1, accw[0], 0, 0, 0);
+      accw[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(obf16x8, (u64x2){x10l, x10h}), gb0, accw[1], 0, 0, 0);
+      accw[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(obf16x8, (u64x2){x11l, x11h}), gb1, accw[1], 0, 0, 0);
+    }
+    // ---- the next tile's patch into the other buffer (its last readers passed the previous barrier) — BEFORE this tile's stores:
+    // behind them (conditional on the channel tile being live) the compiler's vmcnt for these loads would also wait for stores
+    if (more) { if (buf) PG_OCB_PUT_PATCH(0); else PG_OCB_PUT_PATCH(1); }
+    // ---- results back through the LDS tile (every read of the forward values is done: the asm above waited), row-major out
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(xq + (cq * 32 + 8 * g) * 2) = res[cq * 4 + g];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const uint4 o00 = *reinterpret_cast<const uint4*>(xr), o01 = *reinterpret_cast<const uint4*>(xr + 16 * 128);
+      const uint4 o10 = *reinterpret_cast<const uint4*>(xr + 64), o11 = *reinterpret_cast<const uint4*>(xr + 16 * 128 + 64);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (act0) {
+        const unsigned e = (unsigned)cpix0 * (unsigned)Cd[0] + xoff0;
+        *reinterpret_cast<uint4*>(g16[0] + e) = o00;
+        *reinterpret_cast<uint4*>(g16[0] + e + 16u * (unsigned)Cd[0]) = o01;
+      }
+      if (act1) {
+        const unsigned e = (unsigned)cpix0 * (unsigned)Cd[1] + xoff1;
+        *reinterpret_cast<uint4*>(g16[1] + e) = o10;
+        *reinterpret_cast<uint4*>(g16[1] + e + 16u * (unsigned)Cd[1]) = o11;
+      }
+    }
+    if (!more) break;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+  }
+  // ---- this workgroup's weight-gradient partial: accw[cq][r] = dW[t = l31][ci = (ct0 + cq) * 32 + 8 (r >> 2) + 4 lhi + (r & 3)]
+  if (l31 < ODG_T) {
+    float* const dstp = p.wpart + (long)blockIdx.x * p.Ctot * 28;
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq)
+      if (cq == 0 ? act0 : act1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dstp[((ct0 + cq) * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3)) * 28 + l31] = accw[cq][r];
+      }
+  }
+}
+
 // dW[t][ci] += sum over workgroup partials [nb][Ctot][28]; blockIdx.y = slice of the partial list (float atomics into dW: one
 // serial walk over 1024 partials per thread took 160 us at batch 4)
 __global__ __launch_bounds__(256) void out_conv_wgrad_reduce_kernel(const float* part, int nb, int Ctot, float* dW) {
@@ -297,6 +554,23 @@ extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const f
   long blocks = (k.npix + 15) / 16;
   if (blocks > 256 * 12) blocks = 256 * 12;
   hipStream_t st = (hipStream_t)stream, wst = wg_stream ? (hipStream_t)wg_stream : st;
+  bool mfma = g_is_dpre && W % 32 == 0 && c % 32 == 0 && (double)N * H * W * 256 < 2147483648.0 && getenv("PG_NO_OUT_DGRAD_MFMA") == nullptr;
+  for (int j = 0; j < ndst; ++j) mfma = mfma && dst[j].C % 32 == 0 && dst[j].accumulate == 0;
+  static const bool fuse = getenv("PG_NO_OUT_BWD_FUSED") == nullptr;
+  if (mfma && fuse && workspace_floats / ((long)c * 28) >= 64) {
+    // ONE pass: data gradient + weight gradient on the matrix cores (out_conv_bwd_mfma_kernel), on `stream`
+    long cap = workspace_floats / ((long)c * 28);
+    long fb = (long)k.npix / 32;
+    static const long fcap = getenv("PG_OUT_BWD_WGS") ? atol(getenv("PG_OUT_BWD_WGS")) : 512;      // persistent: two workgroups per CU
+    if (fb > fcap) fb = fcap;
+    if (fb > cap) fb = cap;
+    k.wpart = workspace;
+    PG_KLAUNCH(pg::out_conv_bwd_mfma_kernel, dim3((unsigned)fb), dim3(256), 0, st, k);
+    PG_LAUNCH_OK("pg_out_conv_bwd_direct (fused MFMA pass)");
+    PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, 16), dim3(256), 0, st, workspace, (int)fb, c, dW);
+    PG_LAUNCH_OK("pg_out_conv_bwd_direct (reduce)");
+    return 0;
+  }
   if (g_is_dpre) PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, k);
   else PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (data gradient)");

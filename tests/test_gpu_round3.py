@@ -396,3 +396,58 @@ def test_warp_backward_with_mask_boxes_equals_unpruned(case, io):
     tol = (2.0 ** -7 if io else 4e-6) * float(res[0].abs().max())
     assert float((res[0] - res[1]).abs().max()) <= tol, float((res[0] - res[1]).abs().max())
     assert (res[0] != res[1]).float().mean() < (0.02 if io else 0.2)
+
+
+# ------------------------------------------------------------------------------------------ output conv backward, MFMA form
+@pytest.mark.parametrize("shape", [(2, 16, 32, (128, 64, 64)), (1, 5, 64, (64, 32)), (3, 8, 96, (32, 32, 32))])
+def test_output_conv_data_gradient_mfma(shape, monkeypatch):
+    """pg_out_conv_bwd_direct's fused MFMA pass (data gradient + weight gradient; bf16 STORAGE: dX^T = Wt * G^T as v_mfma_f32_32x32x16_bf16, the 27 values
+    of a pixel gathered from the NCHW gradient) against (a) the fp32 contraction of the bf16-ROUNDED operands with relu' of
+    the activated forward operand, to one bf16 ulp of the stored result, and (b) the streaming kernel it replaces
+    (PG_NO_OUT_DGRAD_MFMA), which contracts the unrounded fp32 operands.  The pad columns of Wt hold NaN: never read."""
+    N, H, W, Cs = shape
+    C = sum(Cs)
+    dpre = t(synth.normal(51, "ocm/g", (N, 3, H, W))).to(DEV).contiguous()
+    wt = torch.full((C, 32), float("nan"), device=DEV)
+    wt[:, :27] = t(synth.normal(51, "ocm/w", (C, 27))).to(DEV) * 0.1
+    fw = [torch.relu(nhwc(t(synth.normal(51, "ocm/f%d" % j, (N, c, H, W)))).to(DEV)).to(torch.bfloat16).contiguous() for j, c in enumerate(Cs)]
+    ws = torch.zeros(1024 * C * 28, device=DEV)
+
+    def run():
+        grads = [torch.full((N, H, W, c), float("nan"), device=DEV, dtype=torch.bfloat16) for c in Cs]
+        dsts = [L.make_dst(g, c, fwd=f, act=L.ACT_RELU) for g, f, c in zip(grads, fw, Cs)]
+        arr = (L.Dst * len(dsts))(*dsts)
+        dW = torch.zeros(27, C, device=DEV)
+        L.call("pg_out_conv_bwd_direct", L.ptr(dpre), 1, L.ptr(wt), N, H, W, arr, len(dsts), L.ptr(dW), L.ptr(ws), ws.numel(), None,
+               L.stream())
+        torch.cuda.synchronize()
+        return torch.cat([g.float() for g in grads], -1).cpu(), dW.cpu()
+
+    got, dw_m = run()
+    monkeypatch.setenv("PG_NO_OUT_DGRAD_MFMA", "1")
+    old, dw_s = run()
+    monkeypatch.delenv("PG_NO_OUT_DGRAD_MFMA")
+    # reference from the bf16-rounded operands
+    gp = F.pad(dpre.cpu(), (1, 1, 1, 1))
+    cols = []
+    for r in range(3):
+        for s in range(3):
+            for c in range(3):
+                cols.append(gp[:, c, 2 - r:2 - r + H, 2 - s:2 - s + W])           # dpre[n][c][y + 1 - r][x + 1 - s]
+    G = torch.stack(cols, -1)                                                      # (N, H, W, 27)
+    Gb = G.to(torch.bfloat16).float()
+    Wb = wt[:, :27].cpu().to(torch.bfloat16).float()
+    ref = torch.einsum("nhwt,ct->nhwc", Gb.double(), Wb.double()).float()
+    mask = torch.cat([f.float().cpu() for f in fw], -1) > 0
+    ref = ref * mask
+    assert not torch.isnan(got).any()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2.0 ** -7 * scale
+    assert float((got - ref).abs().mean()) <= 2.0 ** -9 * float(ref.abs().mean()) + 1e-12
+    assert float((got - old).abs().max()) <= 0.03 * scale                          # bf16 operands against fp32 operands
+    # weight gradient of the same (fused) pass: dW[t][ci] = sum_pixels bf16(G)[pixel][t] * x[pixel][ci], x = the bf16 operand
+    X = torch.cat([f.float().cpu() for f in fw], -1)
+    dw_ref = torch.einsum("nhwt,nhwc->tc", Gb.double(), X.double()).float()
+    assert rel(dw_m, dw_ref) < 1e-4
+    assert rel(dw_s, torch.einsum("nhwt,nhwc->tc", G.double(), X.double()).float()) < 1e-4      # the streaming pass: fp32 G
+    assert rel(dw_m, dw_s) < 1e-2
