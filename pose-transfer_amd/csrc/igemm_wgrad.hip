@@ -784,7 +784,11 @@ extern "C" int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, f
              "pg_bias_grad_bf16: dense NHWC bf16 tensor with C %% 4 == 0 and 256 %% (C / 4) == 0 required");
   const int ppb = 256 / (C / 4);
   long blocks = (npix + (long)ppb * 16 - 1) / ((long)ppb * 16);
-  if (blocks > 96) blocks = 96;
+  // 96 workgroups keep ~1.5 MB in flight (8-byte loads): enough for the batch-4 tensors, a third of HBM rate on the 268 MB ones
+  // of batch 32 (0.118 ms each).  Large tensors take up to 384 (the trailing atomics stay under the streaming time).
+  static const long bcap = getenv("PG_BIAS_GRAD_WGS") ? atol(getenv("PG_BIAS_GRAD_WGS")) : 384;
+  const long cap = (double)npix * C * 2 >= 64e6 ? bcap : 96;
+  if (blocks > cap) blocks = cap;
   PG_KLAUNCH(pg::bias_grad_nhwc_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float*>(dY_bf16), (long)npix, C, db);
   PG_LAUNCH_OK("pg_bias_grad_bf16");

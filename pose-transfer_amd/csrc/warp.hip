@@ -90,19 +90,35 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(const TIn* m, int N, 
 // Bounding box of the non-zero pixels of every (sample, transform) mask plane (N, T, H0, W0): out[(n*T+t)*4 ..] = ymin, ymax, xmin,
 // xmax; an empty plane gives ymax < ymin.  One workgroup per plane, coalesced scan (84 MB at batch 32: ~20 us).
 template <typename TIn>
-__global__ __launch_bounds__(256) void mask_bbox_kernel(const TIn* m, int H0, int W0, int* out) {
-  __shared__ int red[4][256];
+__global__ __launch_bounds__(1024) void mask_bbox_kernel(const TIn* m, int H0, int W0, int* out) {
+  __shared__ int red[4][1024];
   const TIn* b = m + (long)blockIdx.x * H0 * W0;
   int y0 = H0, y1 = -1, x0 = W0, x1 = -1;
-  for (int i = threadIdx.x; i < H0 * W0; i += 256) {
-    if (b[i] != (TIn)0) {
-      const int y = i / W0, x = i - y * W0;
-      y0 = min(y0, y); y1 = max(y1, y); x0 = min(x0, x); x1 = max(x1, x);
+  const int total = H0 * W0;
+  // four elements per lane and step (16-byte loads when the plane allows it): 320 planes of 256 KB are read in ~25 us
+  if (sizeof(TIn) == 4 && (W0 & 3) == 0 && (((size_t)b) & 15) == 0) {
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (int i = threadIdx.x; i < total / 4; i += 1024) {
+      const float4 v = b4[i];
+      if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) {
+        const int e = i * 4, y = e / W0, x = e - y * W0;          // W0 % 4 == 0: the four share a row
+        y0 = min(y0, y); y1 = max(y1, y);
+        const int xa = v.x != 0.f ? x : (v.y != 0.f ? x + 1 : (v.z != 0.f ? x + 2 : x + 3));
+        const int xb = v.w != 0.f ? x + 3 : (v.z != 0.f ? x + 2 : (v.y != 0.f ? x + 1 : x));
+        x0 = min(x0, xa); x1 = max(x1, xb);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += 1024) {
+      if (b[i] != (TIn)0) {
+        const int y = i / W0, x = i - y * W0;
+        y0 = min(y0, y); y1 = max(y1, y); x0 = min(x0, x); x1 = max(x1, x);
+      }
     }
   }
   red[0][threadIdx.x] = y0; red[1][threadIdx.x] = y1; red[2][threadIdx.x] = x0; red[3][threadIdx.x] = x1;
   __syncthreads();
-  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+  for (int s_ = 512; s_ > 0; s_ >>= 1) {
     if ((int)threadIdx.x < s_) {
       red[0][threadIdx.x] = min(red[0][threadIdx.x], red[0][threadIdx.x + s_]);
       red[1][threadIdx.x] = max(red[1][threadIdx.x], red[1][threadIdx.x + s_]);
@@ -733,10 +749,10 @@ extern "C" int pg_mask_bbox(const void* masks, int32_t is_f64, int32_t N, int32_
                             void* stream) {
   PG_REQUIRE(masks && bbox && N > 0 && T > 0 && H0 > 0 && W0 > 0, "pg_mask_bbox: bad arguments");
   if (is_f64)
-    PG_KLAUNCH(mask_bbox_kernel<double>, dim3((unsigned)(N * T)), dim3(256), 0, (hipStream_t)stream, (const double*)masks, H0, W0,
+    PG_KLAUNCH(mask_bbox_kernel<double>, dim3((unsigned)(N * T)), dim3(1024), 0, (hipStream_t)stream, (const double*)masks, H0, W0,
                (int*)bbox);
   else
-    PG_KLAUNCH(mask_bbox_kernel<float>, dim3((unsigned)(N * T)), dim3(256), 0, (hipStream_t)stream, (const float*)masks, H0, W0,
+    PG_KLAUNCH(mask_bbox_kernel<float>, dim3((unsigned)(N * T)), dim3(1024), 0, (hipStream_t)stream, (const float*)masks, H0, W0,
                (int*)bbox);
   PG_LAUNCH_OK("pg_mask_bbox");
   return 0;
