@@ -221,6 +221,12 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
 constexpr int TL_WGS = 16384, TL_SLOTS = 16;      // 8..10: inside the epilogue (see the stamps)
 static __device__ unsigned long long kTimeline[TL_WGS * TL_SLOTS];
 
+// Build-time experiment (round 3): -DPG_BIG_3STAGE=1 gives the BN = 128 variant a third 48 KB stage (a DMA then has two K tiles
+// to land).  Measured on dec.5 forward at batch 32: K loop 41.2 us per workgroup against 38.5 - 40.5 with two stages — the
+// 128-wide variant is not waiting for its operands; off.
+#ifndef PG_BIG_3STAGE
+#define PG_BIG_3STAGE 0
+#endif
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   constexpr int BM = (BN == 64) ? 512 : 256;                // BN = 64 (N = 64 layers at full resolution): 512 x 64, a wave owns 64 x 64
@@ -229,7 +235,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   constexpr int A_PASS = BM / 64, B_PASS = BN / 64;      // global_load_lds per thread and tile (64 rows per pass)
   constexpr int A_ST = BM * 128, B_ST = BN * 128;        // bytes per stage
   constexpr int STAGE = A_ST + B_ST;
-  constexpr int ROWS_OFF = 2 * STAGE, TAPS_OFF = ROWS_OFF + BM * (int)sizeof(RowB);
+  constexpr int NST = (BN == 128 && PG_BIG_3STAGE) ? 3 : 2;
+  constexpr int ROWS_OFF = NST * STAGE, TAPS_OFF = ROWS_OFF + BM * (int)sizeof(RowB);
   constexpr int STAT_OFF = (TAPS_OFF + MAXTAP * 4 + 7) & ~7, STAT_N = 8;         // per-workgroup statistics: STAT_N samples x (sum, sum of squares)
   __shared__ __attribute__((aligned(1024))) char smem[STAT_OFF + STAT_N * 2 * 8];     // ONE LDS object (see header)
   RowB* rows = reinterpret_cast<RowB*>(smem + ROWS_OFF);
@@ -439,6 +446,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   // (2048 SIMD cycles with two waves per SIMD) lies between a DMA's issue and the vmcnt(0) that waits for it
   // (PMC, round 2: with the issue after those MFMAs the waves were parked at the wait for 37 % of their cycles).
   if (kt0 + 1 < kt1) { issue(1); advance(); }
+  if constexpr (NST == 3) {
+    if (kt0 + 2 < kt1) { issue(2); advance(); }
+  }
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
     __builtin_amdgcn_sched_barrier(0);
@@ -452,15 +462,22 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     PGB_LDS_WAIT(NRD);
     mfmas(va0, vb0);
     // tile switch: this wave's last operand fetch of the stage has landed (lgkmcnt(0)), its share of the next tile has
-    // landed (vmcnt(0)); after the barrier both hold for every wave
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // landed (two stages: vmcnt(0); three: the DMA instructions of tile kt + 2, issued later, may stay in flight); after the
+    // barrier both hold for every wave
+    if constexpr (NST == 3) {
+      if (kt + 2 < kt1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(A_PASS + B_PASS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < kt1) { issue(stage); advance(); }          // tile kt + 2 into the stage this tile just released
+    if (kt + NST < kt1) { issue(stage); advance(); }        // tile kt + NST into the stage this tile just released
     __builtin_amdgcn_sched_barrier(0);
-    if (more) fetch(stage ^ 1, 0, va0, vb0);
+    const int nstage = (NST == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
+    if (more) fetch(nstage, 0, va0, vb0);
     mfmas(va1, vb1);
-    stage ^= 1;
+    stage = nstage;
   }
 
   // ------------------------------------------------------------------ epilogue (operand stages are free after a barrier)
@@ -570,9 +587,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
 #pragma unroll
       for (int h = 0; h < TM / 2; ++h) {
         if (p.dst_io == 0)
-          vec_scatter_64x64<TN, 0>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+          vec_scatter_64x64<TN, 0, RowB, false>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
         else
-          vec_scatter_64x64<TN, 2>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
+          vec_scatter_64x64<TN, 2, RowB, false>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, ld, cval, p.Ho, p.Wo);
       }
     }
   }

@@ -181,7 +181,7 @@ struct LaneDst {
 };
 // IO: 0 = fp32 tensors, 1 = gradient AND forward tensor in bf16 STORAGE (compile-time: the batched loads stay straight-line
 // code), 2 = per-destination run-time flags (mixed launches; the loads sit under wave-uniform branches)
-template <int TN_, int IO = 0, typename RowT = RowInfo>
+template <int TN_, int IO = 0, typename RowT = RowInfo, bool PIPE = true>
 __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowT* rows, int wm0, int lane,
                                                   const LaneDst& d, bool cval, int Ho, int Wo) {
   const bool gbf = IO == 1 ? true : (IO == 0 ? false : d.grad_bf16);
@@ -189,6 +189,81 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
   constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR;     // lanes per row, rows per pass
   const int l31 = lane & 31, lhi = lane >> 5;
   const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
+  if constexpr (!PIPE) {       // the round-2 order (256-row kernel's fp32 / mixed destinations: no registers to spare there)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+  #pragma unroll
+      for (int j = 0; j < TN_; ++j)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[i][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+  #pragma unroll
+      for (int h = 0; h < 32 / RPP / 4; ++h) {             // batches of four row passes: 16 loads in flight per lane
+        float4 f[4], m[4], old[4], v[4];
+        float2 ab[4];
+        unsigned idx[4];
+        bool ok[4];
+  #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = (h * 4 + u) * RPP + rsel;
+          const RowT ri = rows[wm0 + i * 32 + row];
+          ok[u] = (ri.n >= 0) & cval;
+          const int nn = ok[u] ? ri.n : 0;
+          idx[u] = ok[u] ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
+          v[u] = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
+          f[u] = ld4_any(d.fwdp, d.has_fwd ? idx[u] : (unsigned)d.c, IO == 2 ? (d.has_fwd ? fbf : gbf) : fbf);
+          ab[u] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nn);
+          m[u] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nn * d.C + d.c : (d.c & 511)));
+          old[u] = ld4_any(d.gradp, d.accum ? idx[u] : (unsigned)d.c, gbf);
+        }
+  #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float g4[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, f4[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+          const float m4[4] = {m[u].x, m[u].y, m[u].z, m[u].w}, o4[4] = {old[u].x, old[u].y, old[u].z, old[u].w};
+          float r4[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(f4[e], ab[u].x, ab[u].y) * m4[e];
+            r4[e] = fmaf(g4[e] * m4[e], act_grad_s(z, d.dslope), d.accum ? o4[e] : 0.f);
+          }
+          if (ok[u]) st4_any(d.gradp, idx[u], gbf, make_float4(r4[0], r4[1], r4[2], r4[3]));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  // Batches of four row passes (16 loads in flight per lane).  The loads of batch b+1 are issued BEFORE the stores of batch b
+  // (whose results wait in 16 registers): gfx950 counts loads and stores in ONE vmcnt, so a load waited for behind a store
+  // also waits for that store's acknowledgement — the round-2 order (loads, wait, compute, stores per batch) paid a store
+  // round trip per batch (tools/conv_timeline.py, round 3).
+  constexpr int NB = 32 / RPP / 4;
+  struct Batch {
+    float4 f[4], m[4], old[4];
+    float2 ab[4];
+    unsigned idx[4];
+    unsigned ok;
+  };
+  auto issue = [&](int i, int h, Batch& L) {
+    L.ok = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = (h * 4 + u) * RPP + rsel;
+      const RowT ri = rows[wm0 + i * 32 + row];
+      const bool ok = (ri.n >= 0) & cval;
+      const int nn = ok ? ri.n : 0;
+      L.ok |= (ok ? 1u : 0u) << u;
+      L.idx[u] = ok ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
+      L.f[u] = ld4_any(d.fwdp, d.has_fwd ? L.idx[u] : (unsigned)d.c, IO == 2 ? (d.has_fwd ? fbf : gbf) : fbf);
+      L.ab[u] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nn);
+      L.m[u] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nn * d.C + d.c : (d.c & 511)));
+      L.old[u] = ld4_any(d.gradp, d.accum ? L.idx[u] : (unsigned)d.c, gbf);
+    }
+  };
+  Batch cur;
+  issue(0, 0, cur);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -198,36 +273,31 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int h = 0; h < 32 / RPP / 4; ++h) {             // batches of four row passes: 16 loads in flight per lane
-      float4 f[4], m[4], old[4], v[4];
-      float2 ab[4];
-      unsigned idx[4];
-      bool ok[4];
+    for (int h = 0; h < NB; ++h) {
+      float4 res[4];
+      unsigned sidx[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int row = (h * 4 + u) * RPP + rsel;
-        const RowT ri = rows[wm0 + i * 32 + row];
-        ok[u] = (ri.n >= 0) & cval;
-        const int nn = ok[u] ? ri.n : 0;
-        idx[u] = ok[u] ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
-        v[u] = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
-        f[u] = ld4_any(d.fwdp, d.has_fwd ? idx[u] : (unsigned)d.c, IO == 2 ? (d.has_fwd ? fbf : gbf) : fbf);
-        ab[u] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nn);
-        m[u] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nn * d.C + d.c : (d.c & 511)));
-        old[u] = ld4_any(d.gradp, d.accum ? idx[u] : (unsigned)d.c, gbf);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float g4[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, f4[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
-        const float m4[4] = {m[u].x, m[u].y, m[u].z, m[u].w}, o4[4] = {old[u].x, old[u].y, old[u].z, old[u].w};
+        const float4 v = *reinterpret_cast<const float4*>(&T[row * PITCH + c4]);
+        const float g4[4] = {v.x, v.y, v.z, v.w}, f4[4] = {cur.f[u].x, cur.f[u].y, cur.f[u].z, cur.f[u].w};
+        const float m4[4] = {cur.m[u].x, cur.m[u].y, cur.m[u].z, cur.m[u].w};
+        const float o4[4] = {cur.old[u].x, cur.old[u].y, cur.old[u].z, cur.old[u].w};
         float r4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float z = fmaf(f4[e], ab[u].x, ab[u].y) * m4[e];
+          const float z = fmaf(f4[e], cur.ab[u].x, cur.ab[u].y) * m4[e];
           r4[e] = fmaf(g4[e] * m4[e], act_grad_s(z, d.dslope), d.accum ? o4[e] : 0.f);
         }
-        if (ok[u]) st4_any(d.gradp, idx[u], gbf, make_float4(r4[0], r4[1], r4[2], r4[3]));
+        res[u] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        sidx[u] = cur.idx[u];
       }
+      const unsigned sok = cur.ok;
+      if (h + 1 < NB) issue(i, h + 1, cur);
+      else if (i == 0) issue(1, 0, cur);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if ((sok >> u) & 1u) st4_any(d.gradp, sidx[u], gbf, res[u]);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
