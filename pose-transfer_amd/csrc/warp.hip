@@ -404,12 +404,13 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
       int bi[V];
 #pragma unroll
       for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 255; }
+      // A transform whose mask is 0 here contributes the candidate (0, "no transform").  Only the FIRST such transform can
+      // change (best, arg): afterwards best >= 0 and `0 > best` stays false — so the later ones cost one LDS read and a branch
+      // instead of 3 V instructions each (PMC, round 3: the kernel is instruction-bound, 1.3 issue-active SIMD cycles per
+      // cycle; ~9 of the 10 transforms are masked out at a typical pixel).
+      bool zero_done = false;
       for (int t = 0; t < T; ++t) {
         const float m = mval[pl * T + t];
-        float cand[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) cand[e] = 0.f;
-        int id = 255;
         if (m != 0.f) {
 #pragma clang fp contract(off)
           const WarpTap tp = taps[pl * T + t];
@@ -424,12 +425,16 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
 #pragma unroll
             for (int e = 0; e < V; ++e) s[e] = s[e] + ((v[k][e] * a) + b) * tp.w[k];
 #pragma unroll
-          for (int e = 0; e < V; ++e) cand[e] = s[e] * m;
-          id = t;
-        }
+          for (int e = 0; e < V; ++e) {
+            const float cand = s[e] * m;
+            if (cand > best[e]) { best[e] = cand; bi[e] = t; }
+          }
+        } else if (!zero_done) {
+          zero_done = true;
 #pragma unroll
-        for (int e = 0; e < V; ++e)
-          if (cand[e] > best[e]) { best[e] = cand[e]; bi[e] = id; }
+          for (int e = 0; e < V; ++e)
+            if (0.f > best[e]) { best[e] = 0.f; bi[e] = 255; }
+        }
       }
       const long o = ((long)n * npix + pix) * C + cc;
       if (relu_out) {
