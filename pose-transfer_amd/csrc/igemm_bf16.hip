@@ -130,7 +130,9 @@ __device__ __forceinline__ void big_store_64x64(const f32x16 (&acc)[2][TN_], flo
 // Here the global loads of 32-row half h+1 (forward values, previous gradients, the two candidate samples' affine / mask) are
 // issued BEFORE the stores of half h (whose results wait in 16 registers), and nothing else reads global memory: one counted
 // wait per half, never behind a store.
-template <int TM_, int TN_>
+// SIMPLE (wave-uniform, decided by the caller): no lane's destination has a dropout mask or accumulates — the case of the large
+// decoder data gradients; drops the previous-gradient and mask loads and about half of the VALU work per element.
+template <int TM_, int TN_, bool SIMPLE>
 __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], float* T, const RowB* rows, int wm0, int lane,
                                                  const LaneDst& d, bool cval, int m_first, int gg, int M, int N) {
   constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
@@ -157,17 +159,17 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
       const unsigned idx = ok ? (unsigned)ro.y * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
       L.ok |= (ok ? 1u : 0u) << it;
       L.fb[it] = *reinterpret_cast<const uint2*>(fwd16 + (d.has_fwd ? idx : (unsigned)d.c));
-      L.ob[it] = *reinterpret_cast<const uint2*>(grad16 + (d.accum ? idx : (unsigned)d.c));
+      if constexpr (!SIMPLE) L.ob[it] = *reinterpret_cast<const uint2*>(grad16 + (d.accum ? idx : (unsigned)d.c));
     }
     L.ab[0] = *reinterpret_cast<const float2*>(d.affp + d.affmul * L.nlo);
     L.ab[1] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nhi);
-    L.mk[0] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? L.nlo * d.C + d.c : (d.c & 511)));
-    L.mk[1] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nhi * d.C + d.c : (d.c & 511)));
+    if constexpr (!SIMPLE) {
+      L.mk[0] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? L.nlo * d.C + d.c : (d.c & 511)));
+      L.mk[1] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nhi * d.C + d.c : (d.c & 511)));
+    }
   };
-  Half cur;
-  issue(0, cur);
-#pragma unroll
-  for (int hh = 0; hh < TM_; ++hh) {
+  // one 32-row half: `cur` holds its loads; before its stores go out the loads of half `nh` are issued into `nx` (nh < 0: none)
+  auto step = [&](int hh, Half& cur, Half& nx, int nh) {
 #pragma unroll
     for (int j = 0; j < TN_; ++j)
 #pragma unroll
@@ -191,16 +193,21 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
         const int it = b * 4 + u;
         const bool hi = ro[u].x > cur.nlo;
         const float a = hi ? cur.ab[1].x : cur.ab[0].x, bb = hi ? cur.ab[1].y : cur.ab[0].y;
-        const float m4[4] = {hi ? cur.mk[1].x : cur.mk[0].x, hi ? cur.mk[1].y : cur.mk[0].y, hi ? cur.mk[1].z : cur.mk[0].z,
-                             hi ? cur.mk[1].w : cur.mk[0].w};
         const float g4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
         const float f4[4] = {bf16_lo_f32(cur.fb[it].x), bf16_hi_f32(cur.fb[it].x), bf16_lo_f32(cur.fb[it].y), bf16_hi_f32(cur.fb[it].y)};
-        const float o4[4] = {bf16_lo_f32(cur.ob[it].x), bf16_hi_f32(cur.ob[it].x), bf16_lo_f32(cur.ob[it].y), bf16_hi_f32(cur.ob[it].y)};
         float r4[4];
+        if constexpr (SIMPLE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = fmaf(f4[e], a, bb) * m4[e];
-          r4[e] = fmaf(g4[e] * m4[e], act_grad_s(z, d.dslope), d.accum ? o4[e] : 0.f);
+          for (int e = 0; e < 4; ++e) r4[e] = g4[e] * act_grad_s(fmaf(f4[e], a, bb), d.dslope);
+        } else {
+          const float m4[4] = {hi ? cur.mk[1].x : cur.mk[0].x, hi ? cur.mk[1].y : cur.mk[0].y, hi ? cur.mk[1].z : cur.mk[0].z,
+                               hi ? cur.mk[1].w : cur.mk[0].w};
+          const float o4[4] = {bf16_lo_f32(cur.ob[it].x), bf16_hi_f32(cur.ob[it].x), bf16_lo_f32(cur.ob[it].y), bf16_hi_f32(cur.ob[it].y)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(f4[e], a, bb) * m4[e];
+            r4[e] = fmaf(g4[e] * m4[e], act_grad_s(z, d.dslope), d.accum ? o4[e] : 0.f);
+          }
         }
         res[it] = make_uint2(pack_bf16(r4[0], r4[1]), pack_bf16(r4[2], r4[3]));
         oidx[it] = (unsigned)ro[u].y * (unsigned)d.C + (unsigned)d.c;
@@ -209,10 +216,25 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const unsigned okh = cur.ok;
-    if (hh + 1 < TM_) issue(hh + 1, cur);        // the next half's loads go out BEFORE this half's stores
+    if (nh >= 0 && nh < TM_) issue(nh, nx);       // later halves' loads go out BEFORE this half's stores
 #pragma unroll
     for (int it = 0; it < NP; ++it)
       if ((okh >> it) & 1u) *reinterpret_cast<uint2*>(grad16 + oidx[it]) = res[it];
+  };
+  Half ha, hb, hc;
+  issue(0, ha);
+  if constexpr (SIMPLE) {
+    // few registers per half: two halves of loads in flight (the whole HBM latency is behind a half of compute)
+    if (TM_ > 1) issue(1, hb);
+    step(0, ha, hc, 2);
+    if (TM_ > 1) step(1, hb, ha, 3);
+    if (TM_ > 2) step(2, hc, hb, -1);
+    if (TM_ > 3) step(3, ha, hb, -1);
+  } else {
+    step(0, ha, hb, 1);
+    if (TM_ > 1) step(1, hb, ha, 2);
+    if (TM_ > 2) step(2, ha, hb, 3);
+    if (TM_ > 3) step(3, hb, ha, -1);
   }
 }
 
@@ -582,7 +604,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     if (p.xcd_swizzle & 128) ld.accum = false;
     stamp(8);
     if (p.dst_io == 1) {          // host: every destination and forward tensor in bf16 STORAGE, >= 32 pixels per sample
-      big_scatter_tile<TM, TN>(acc, T, rows, wm0, lane, ld, cval, __builtin_amdgcn_readfirstlane(m0 + wm0), p.Gy * p.Gx, p.M, p.N);
+      const bool plain = __builtin_amdgcn_ballot_w64(ld.has_mask || ld.accum) == 0;       // wave-uniform
+      if (plain) big_scatter_tile<TM, TN, true>(acc, T, rows, wm0, lane, ld, cval, __builtin_amdgcn_readfirstlane(m0 + wm0), p.Gy * p.Gx, p.M, p.N);
+      else big_scatter_tile<TM, TN, false>(acc, T, rows, wm0, lane, ld, cval, __builtin_amdgcn_readfirstlane(m0 + wm0), p.Gy * p.Gx, p.M, p.N);
     } else {
 #pragma unroll
       for (int h = 0; h < TM / 2; ++h) {
