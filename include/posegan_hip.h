@@ -397,6 +397,9 @@ int pg_debug_spin(int32_t microseconds, void* stream);
  * kernel stamps its phases (0 start, 1 row table built, 2 first K tile landed, 3 K loop done, 4 epilogue done: shader clock;
  * 5 / 6 the 100 MHz wall clock at start / end; 7 the XCD); this copies the stamps of the LAST launch: n_wgs x 8 uint64. */
 int pg_debug_conv_timeline(unsigned long long* host_out, int32_t n_wgs);
+/* Test aid: number of 32-pixel tiles the LAST gather-form warp backward handed to its full-capacity second launch (a pixel's
+ * 48-entry candidate list overflowed); synchronises the device. */
+int pg_debug_warp_gather_overflows(int32_t* count);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Round 3 — bf16 STORAGE on the bf16 data path (PG_PREC_BF16_DATA).  Raw convolution outputs (the tensors the reference's

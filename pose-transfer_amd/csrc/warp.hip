@@ -292,6 +292,9 @@ __device__ __forceinline__ void wstv(char* base, size_t byte_off, const float (&
 // selected that transform.  No atomics, deterministic, one 16-byte store per 4 elements, no zero-fill of the destination.
 // "Wide" transforms (a strongly shrinking limb fit; rare) take the scatter kernel below with float atomics.
 constexpr int GATHER_MAXDIM = 1024;                                  // per-image coordinate tables of the gather kernel
+constexpr int GATHER_OVF_MAX = 65536;                                // tiles the fast kernel can hand to the full-capacity kernel
+static __device__ int g_gather_ovf[1 + GATHER_OVF_MAX];               // [0] = count, then (sample << 20 | tile)
+constexpr int GATHER_FLAT = 48;                                      // list capacity per input pixel (see the kernel)
 constexpr int GATHER_CAP = 16, GATHER_PIX = 32, GATHER_T = 10;      // T <= 10 on the gather path (10 limb transforms / 1)
 
 struct WarpInv { float jx, jy, ix_, iy_, cx, cy, ej, ei; int narrow; };
@@ -452,20 +455,28 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
   }
 }
 
-template <bool GB, bool DB, int V = 4>
+// LIST = false (the launch over all tiles): per-pixel candidate lists of GATHER_FLAT = 48 entries — 12 KB per workgroup instead of
+// the 40 KB of the worst case 10 x 16 (PMC: 2.4 waves per SIMD, 65 % of the wave cycles waiting; 1.06 -> 0.83 ms per pass at
+// batch 32).  A tile in which a pixel's list would overflow (several masks overlapping at a strongly minified spot) is not written
+// but appended to g_gather_ovf; LIST = true (a small second launch with the worst-case capacity) walks that list.
+template <bool GB, bool DB, int V = 4, bool LIST = false>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, const uint8_t* amax, const float* warps,
                                                               const float* masks, int T, int C, int h, int w, int H0, int W0,
                                                               int align, void* dfeat, const int* bbox) {
   // GB / DB: the incoming gradient / the written input gradient are bf16 tensors (bf16 STORAGE)
   constexpr int ESG = GB ? 2 : 4, ESD = DB ? 2 : 4;
-  constexpr int FLAT = GATHER_T * GATHER_CAP;             // worst case per input pixel: no overflow possible
+  constexpr int FLAT = LIST ? GATHER_T * GATHER_CAP : GATHER_FLAT;
   __shared__ Theta th[MAXT];
   __shared__ WarpInv inv[MAXT];
-  __shared__ int e_pix[GATHER_PIX][FLAT];                 // output pixel | transform << 24      (20 KB)
-  __shared__ float e_w[GATHER_PIX][FLAT];                 // mask x bilinear weight              (20 KB)
+  __shared__ int e_pix[GATHER_PIX][FLAT];                 // output pixel | transform << 24
+  __shared__ float e_w[GATHER_PIX][FLAT];                 // mask x bilinear weight
   __shared__ int e_cnt[GATHER_PIX];
+  __shared__ int e_ovf;
   __shared__ float xs_t[GATHER_MAXDIM], ys_t[GATHER_MAXDIM];      // normalised grid coordinate per column / row (host: h, w <= 1024)
-  const int n = blockIdx.y;
+  const int nent = LIST ? min(g_gather_ovf[0], GATHER_OVF_MAX) : 1;
+  for (int ent = LIST ? (int)blockIdx.x : 0; ent < nent; ent += LIST ? (int)gridDim.x : 1) {
+  const int n = LIST ? (g_gather_ovf[1 + ent] >> 20) : (int)blockIdx.y;
+  if (LIST) __syncthreads();                                // the previous entry's tables are consumed
   // bbox (optional, pg_mask_bbox): per (sample, transform) the bounding box of the non-zero FULL-resolution mask.  At this level a
   // mask pixel can be non-zero only inside the box scaled to the level and grown by the bilinear down-sampling's reach; a
   // (pixel, transform) pair whose candidate box misses it is skipped before any mask load — the limb masks cover a few per cent
@@ -489,66 +500,83 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   const long nb = (long)n * h * w;
   // persistent workgroups (round 3): the per-sample set-up above (ten inverted transforms, w + h table entries) cost more
   // than the 32 pixels of work behind it when every tile was its own workgroup (65536 workgroups at 256^2, batch 32)
-  const int ntiles = (h * w + GATHER_PIX - 1) / GATHER_PIX;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int ntiles = LIST ? (g_gather_ovf[1 + ent] & 0xfffff) + 1 : (h * w + GATHER_PIX - 1) / GATHER_PIX;
+  for (int tile = LIST ? ntiles - 1 : (int)blockIdx.x; tile < ntiles; tile += LIST ? 1 : (int)gridDim.x) {
   __syncthreads();                                           // the previous tile's lists are consumed
   if (threadIdx.x < GATHER_PIX) e_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) e_ovf = 0;
   __syncthreads();
   const int P0 = tile * GATHER_PIX;
+  // the candidates of (input pixel P = (X, Y), transform t): output pixels of the pre-image box whose mask is non-zero and whose
+  // bilinear footprint contains P; ep[e] = output pixel | t << 24 (or -1), ew[e] = mask x bilinear weight.  Returns the count.
+  auto candidates = [&](int P, int X, int Y, int t, int (&ep)[GATHER_CAP], float (&ew)[GATHER_CAP]) -> int {
+    const WarpInv v = inv[t];
+    if (!v.narrow || P >= h * w) return 0;
+    const float dx = (float)X - v.cx, dy = (float)Y - v.cy;
+    const float jc = v.jx * dx + v.jy * dy, ic = v.ix_ * dx + v.iy_ * dy;
+    if (!(jc + v.ej >= 0.f && jc - v.ej <= (float)w && ic + v.ei >= 0.f && ic - v.ei <= (float)h)) return 0;
+    const int j0 = max((int)ceilf(jc - v.ej), 0), j1 = min((int)floorf(jc + v.ej), w - 1);
+    const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
+    const int nj = j1 - j0 + 1, tot = nj * (i1 - i0 + 1);
+    if (nj <= 0 || tot <= 0) return 0;
+    if (i1 < mb[t][0] || i0 > mb[t][1] || j1 < mb[t][2] || j0 > mb[t][3]) return 0;      // every candidate has a zero mask
+    float mv[GATHER_CAP];
+    int ci[GATHER_CAP], cj[GATHER_CAP];
+    {
+      int ii = i0, jj = j0;
+#pragma unroll
+      for (int e = 0; e < GATHER_CAP; ++e) {
+        const bool val = e < tot;
+        ci[e] = ii; cj[e] = jj;
+        mv[e] = val ? masks[(nb + (long)ii * w + jj) * T + t] : 0.f;
+        ++jj;
+        if (jj > j1) { jj = j0; ii = min(ii + 1, i1); }
+      }
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < GATHER_CAP; ++e) {
+      ep[e] = -1; ew[e] = 0.f;
+      if (mv[e] != 0.f) {
+        const Taps tp = make_taps_xy(th[t], xs_t[cj[e]], ys_t[ci[e]], h, w, align);      // division-free (tables)
+        const int kx = X - tp.x0, ky = Y - tp.y0;
+        if ((unsigned)kx <= 1u && (unsigned)ky <= 1u) {
+          const float wk = ky ? (kx ? tp.w11 : tp.w10) : (kx ? tp.w01 : tp.w00);
+          ep[e] = (ci[e] * w + cj[e]) | (t << 24); ew[e] = mv[e] * wk; ++cnt;
+        }
+      }
+    }
+    return cnt;
+  };
   // ---- phase 1: one lane per (input pixel, transform); the <= 16 mask values of the pre-image box are loaded as ONE batch
   {
     const int p = threadIdx.x & (GATHER_PIX - 1), P = P0 + p;
     const int Y = P / w, X = P - Y * w;
     for (int t = threadIdx.x / GATHER_PIX; t < T; t += 256 / GATHER_PIX) {
-      const WarpInv v = inv[t];
-      if (!v.narrow || P >= h * w) continue;
-      const float dx = (float)X - v.cx, dy = (float)Y - v.cy;
-      const float jc = v.jx * dx + v.jy * dy, ic = v.ix_ * dx + v.iy_ * dy;
-      if (!(jc + v.ej >= 0.f && jc - v.ej <= (float)w && ic + v.ei >= 0.f && ic - v.ei <= (float)h)) continue;
-      const int j0 = max((int)ceilf(jc - v.ej), 0), j1 = min((int)floorf(jc + v.ej), w - 1);
-      const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
-      const int nj = j1 - j0 + 1, tot = nj * (i1 - i0 + 1);
-      if (nj <= 0 || tot <= 0) continue;
-      if (i1 < mb[t][0] || i0 > mb[t][1] || j1 < mb[t][2] || j0 > mb[t][3]) continue;      // every candidate has a zero mask
-      float mv[GATHER_CAP];
-      int ci[GATHER_CAP], cj[GATHER_CAP];
-      {
-        int ii = i0, jj = j0;
-#pragma unroll
-        for (int e = 0; e < GATHER_CAP; ++e) {
-          const bool val = e < tot;
-          ci[e] = ii; cj[e] = jj;
-          mv[e] = val ? masks[(nb + (long)ii * w + jj) * T + t] : 0.f;
-          ++jj;
-          if (jj > j1) { jj = j0; ii = min(ii + 1, i1); }
-        }
-      }
       int ep[GATHER_CAP];
       float ew[GATHER_CAP];
-      int cnt = 0;
-#pragma unroll
-      for (int e = 0; e < GATHER_CAP; ++e) {
-        ep[e] = -1; ew[e] = 0.f;
-        if (mv[e] != 0.f) {
-          const Taps tp = make_taps_xy(th[t], xs_t[cj[e]], ys_t[ci[e]], h, w, align);      // division-free (tables)
-          const int kx = X - tp.x0, ky = Y - tp.y0;
-          if ((unsigned)kx <= 1u && (unsigned)ky <= 1u) {
-            const float wk = ky ? (kx ? tp.w11 : tp.w10) : (kx ? tp.w01 : tp.w00);
-            ep[e] = (ci[e] * w + cj[e]) | (t << 24); ew[e] = mv[e] * wk; ++cnt;
-          }
-        }
-      }
+      const int cnt = candidates(P, X, Y, t, ep, ew);
       if (cnt) {
         int at = atomicAdd(&e_cnt[p], cnt);
+        if (!LIST && at + cnt > FLAT) e_ovf = 1;
+        else {
 #pragma unroll
-        for (int e = 0; e < GATHER_CAP; ++e)
-          if (ep[e] >= 0) { e_pix[p][at] = ep[e]; e_w[p][at] = ew[e]; ++at; }
+          for (int e = 0; e < GATHER_CAP; ++e)
+            if (ep[e] >= 0) { e_pix[p][at] = ep[e]; e_w[p][at] = ew[e]; ++at; }
+        }
       }
     }
   }
   __syncthreads();
-  // ---- phase 2: lanes = V channels of an input pixel; entries in batches of four (independent loads in flight)
   const int cq = C / V;
+  if (!LIST && e_ovf) {       // rare: hand the tile to the full-capacity launch (host: N * tiles <= GATHER_OVF_MAX)
+    if (threadIdx.x == 0) {
+      const int slot = atomicAdd(&g_gather_ovf[0], 1);
+      if (slot < GATHER_OVF_MAX) g_gather_ovf[1 + slot] = (n << 20) | tile;
+    }
+    continue;
+  }
+  // ---- phase 2: lanes = V channels of an input pixel; entries in batches of four (independent loads in flight)
   for (int q = threadIdx.x; q < GATHER_PIX * cq; q += 256) {
     const int p = q / cq, c4 = (q - p * cq) * V;
     const int P = P0 + p;
@@ -582,6 +610,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
     wstv<DB, V>(reinterpret_cast<char*>(dfeat), (size_t)((nb + P) * C + c4) * ESD, acc);
   }
   }   // tile loop
+  }   // LIST: entry loop
 }
 
 // Scatter form (float atomics), `wide_only`: only the elements whose selected transform is not "narrow" — the complement
@@ -780,18 +809,37 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
     else if (db) PG_KLAUNCH((KERNEL<false, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
     else PG_KLAUNCH((KERNEL<false, false>), GRID, dim3(256), 0, st, __VA_ARGS__);            \
   } while (0)
-  if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM) {
+  const long all_tiles = (long)N * (((long)h * w + GATHER_PIX - 1) / GATHER_PIX);
+  if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM && all_tiles <= GATHER_OVF_MAX &&
+      N < 2048) {
     // gather kernel OVERWRITES dfeat (narrow transforms), then the scatter kernel adds the wide ones
     static const int gcap = getenv("PG_WARP_BWD_TILES") ? atoi(getenv("PG_WARP_BWD_TILES")) : 256;     // workgroups per sample
     int gtiles = (h * w + GATHER_PIX - 1) / GATHER_PIX;
     if (gtiles > gcap) gtiles = gcap;
     static const bool no_v8b = getenv("PG_WARP_NO_V8") != nullptr;
-    if (gb && db && C % 8 == 0 && !no_v8b)
-      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8>), dim3(gtiles, N), dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w,
-                 H0, W0, align_corners, dfeat, (const int*)bbox);
-    else
-      PGW_BWD(warp_bwd_gather_kernel, dim3(gtiles, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat,
-              (const int*)bbox);
+    static void* ovf_dev = nullptr;                      // g_gather_ovf: tiles whose 48-entry lists overflowed
+    if (ovf_dev == nullptr) PG_REQUIRE(hipGetSymbolAddress(&ovf_dev, HIP_SYMBOL(g_gather_ovf)) == hipSuccess, "pg_warp_mask_max_bwd: symbol");
+    PG_MEMSET_ASYNC(ovf_dev, 0, 4, st);
+    const dim3 g1(gtiles, N), g2(64);                    // second launch: worst-case capacity over the overflow list (usually empty)
+    if (gb && db && C % 8 == 0 && !no_v8b) {
+      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
+                 align_corners, dfeat, (const int*)bbox);
+      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
+                 align_corners, dfeat, (const int*)bbox);
+    } else {
+#define PGW_GATHER(GBv, DBv)                                                                                                    \
+  do {                                                                                                                          \
+    PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, \
+               align_corners, dfeat, (const int*)bbox);                                                                         \
+    PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,  \
+               align_corners, dfeat, (const int*)bbox);                                                                         \
+  } while (0)
+      if (gb && db) PGW_GATHER(true, true);
+      else if (gb) PGW_GATHER(true, false);
+      else if (db) PGW_GATHER(false, true);
+      else PGW_GATHER(false, false);
+#undef PGW_GATHER
+    }
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
     // (a sample without wide transforms costs one early-exiting workgroup round: keep that grid small)
     PGW_BWD(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
@@ -803,6 +851,16 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
   PGW_BWD(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
 #undef PGW_BWD
   PG_LAUNCH_OK("pg_warp_mask_max_bwd");
+  return 0;
+}
+// test aid: how many tiles the LAST gather-form backward handed to its full-capacity second launch (synchronises the device)
+extern "C" int pg_debug_warp_gather_overflows(int32_t* count) {
+  PG_REQUIRE(count != nullptr, "pg_debug_warp_gather_overflows: null pointer");
+  PG_REQUIRE(hipDeviceSynchronize() == hipSuccess, "pg_debug_warp_gather_overflows: synchronize");
+  int c = 0;
+  PG_REQUIRE(hipMemcpyFromSymbol(&c, HIP_SYMBOL(pg::g_gather_ovf), sizeof(int), 0, hipMemcpyDeviceToHost) == hipSuccess,
+             "pg_debug_warp_gather_overflows: copy");
+  *count = c;
   return 0;
 }
 extern "C" int pg_warp_mask_max_bwd_io(const void* gout, const uint8_t* argmax, const float* warps,

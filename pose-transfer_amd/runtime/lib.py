@@ -136,6 +136,7 @@ _PROTOS = {
     "pg_warp_mask_max_fwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "pg_warp_mask_max_bwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "pg_debug_conv_timeline": [_vp, _i32],
+    "pg_debug_warp_gather_overflows": [_vp],
     "pg_mask_bbox": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_warp_mask_max_bwd_bbox": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "pg_stem_conv_bf16_v3": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp],

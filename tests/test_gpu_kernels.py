@@ -199,6 +199,7 @@ def test_warp_backward_wide_and_degenerate_transforms(scatter, monkeypatch):
     assert (d > 2e-5 * float(gref.abs().max())).float().mean() < 2e-3 and float(gref.abs().max()) > 1.0, float(d.max())
 
 
+
 def test_warp_with_deferred_affine():
     N, C, h, w = 2, 8, 16, 12
     raw = t(synth.normal(6, "wa/f", (N, C, h, w)))

@@ -451,3 +451,52 @@ def test_output_conv_data_gradient_mfma(shape, monkeypatch):
     assert rel(dw_m, dw_ref) < 1e-4
     assert rel(dw_s, torch.einsum("nhwt,nhwc->tc", G.double(), X.double()).float()) < 1e-4      # the streaming pass: fp32 G
     assert rel(dw_m, dw_s) < 1e-2
+
+
+def test_warp_backward_candidate_list_overflow():
+    """Ten minifying transforms (0.72 - 0.8 x, small rotations and shifts) whose masks all cover the whole image: an input pixel
+    collects more than the 48 candidates its LDS list holds, the tile goes to the overflow list and the full-capacity second
+    launch of the gather-form backward (csrc/warp.hip, LIST = true) writes it.  Against the oracle's autograd, fp32 and bf16."""
+    import ctypes
+    from pose_transfer_amd.utils.pose_transform import AffineTransformLayer
+    N, C, h, w, H0, W0 = 2, 16, 24, 20, 48, 40
+    feat = t(synth.normal(61, "ovf/f", (N, C, h, w)))
+    go = t(synth.normal(61, "ovf/go", (N, C, h, w)))
+    sc = synth.uniform(61, "ovf/s", (N, 10), 0.72, 0.8)
+    ph = synth.uniform(61, "ovf/p", (N, 10), -0.15, 0.15)
+    wr = np.zeros((N, 10, 8), np.float32)
+    wr[..., 0] = sc * np.cos(ph); wr[..., 1] = -sc * np.sin(ph); wr[..., 3] = sc * np.sin(ph); wr[..., 4] = sc * np.cos(ph)
+    wr[..., 2] = synth.uniform(61, "ovf/tx", (N, 10), 2.0, 8.0); wr[..., 5] = synth.uniform(61, "ovf/ty", (N, 10), 2.0, 8.0)
+    mk = np.ones((N, 10, H0, W0), np.float32)
+    fr = feat.clone().requires_grad_(True)
+    ref = R.warp_mask_max(fr, t(wr), t(mk), (H0, W0))
+    (gref,) = torch.autograd.grad((ref * go).sum(), fr)
+    fd = feat.to(DEV).requires_grad_(True)
+    out = AffineTransformLayer(10, (H0, W0), "mask")(fd, t(wr).to(DEV), t(mk).to(DEV))
+    (gin,) = torch.autograd.grad((out * go.to(DEV)).sum(), fd)
+    cnt = ctypes.c_int32(-1)
+    L.check(L.load().pg_debug_warp_gather_overflows(ctypes.byref(cnt)), "pg_debug_warp_gather_overflows")
+    assert cnt.value > 0, cnt.value                                  # the second launch had work
+    assert maxdiff(out, ref) < 2e-5
+    d = (gin.cpu() - gref).abs()
+    assert (d > 2e-5 * float(gref.abs().max())).float().mean() < 2e-3 and float(gref.abs().max()) > 1.0, float(d.max())
+    # bf16 STORAGE through the C ABI, against the fp32 result of the same kernels (one bf16 ulp of the largest gradient)
+    lvl = torch.empty(N, h, w, 10, device=DEV)
+    mkd, wrd = t(mk).to(DEV), t(wr).to(DEV)
+    L.call("pg_mask_pyramid", L.ptr(mkd), 0, N, 10, H0, W0, h, w, L.ptr(lvl), L.stream())
+    fb = nhwc(feat).to(DEV).to(torch.bfloat16).contiguous()
+    gb = nhwc(go).to(DEV).to(torch.bfloat16).contiguous()
+    ob = torch.empty(N, h, w, C, device=DEV, dtype=torch.bfloat16)
+    arg = torch.empty(N, h, w, C, dtype=torch.uint8, device=DEV)
+    L.call("pg_warp_mask_max_fwd_io", L.ptr(fb), None, L.ptr(wrd), L.ptr(lvl), N, 10, C, h, w, H0, W0, 0, L.ptr(ob), L.ptr(arg), 3,
+           L.stream())
+    db = torch.zeros(N, h, w, C, device=DEV, dtype=torch.bfloat16)
+    L.call("pg_warp_mask_max_bwd_io", L.ptr(gb), L.ptr(arg), L.ptr(wrd), L.ptr(lvl), N, 10, C, h, w, H0, W0, 0, L.ptr(db), 3, L.stream())
+    L.check(L.load().pg_debug_warp_gather_overflows(ctypes.byref(cnt)), "pg_debug_warp_gather_overflows")
+    assert cnt.value > 0
+    # reference for the bf16 run: autograd of the oracle on the bf16-rounded tensors
+    f2 = nchw(fb.float().cpu()).clone().requires_grad_(True)
+    r2 = R.warp_mask_max(f2, t(wr), t(mk), (H0, W0))
+    (g2,) = torch.autograd.grad((r2 * nchw(gb.float().cpu())).sum(), f2)
+    d2 = (nchw(db.float().cpu()) - g2).abs()
+    assert (d2 > 2.0 ** -7 * float(g2.abs().max())).float().mean() < 5e-3, float(d2.max())
