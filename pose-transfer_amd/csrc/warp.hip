@@ -423,14 +423,31 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
           float s[V];
 #pragma unroll
           for (int e = 0; e < V; ++e) s[e] = 0.f;
+          if constexpr (IB && OB) {
+            // bf16 STORAGE: the result is rounded to bf16 anyway, so the deferred affine is applied once per pixel instead of
+            // once per tap (sum_k ((v_k a + b) w_k) = a sum_k v_k w_k + b sum_k w_k) and the taps are FMAs: 1 instruction per
+            // (tap, channel) instead of 4 — the kernel is instruction-bound.  The fp32 instantiations keep the reference's order.
+            const float wsum = (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]);
+            const float am = a * m, bm = b * wsum * m;
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int e = 0; e < V; ++e) s[e] = s[e] + ((v[k][e] * a) + b) * tp.w[k];
+              for (int e = 0; e < V; ++e) s[e] = __builtin_fmaf(v[k][e], tp.w[k], s[e]);
 #pragma unroll
-          for (int e = 0; e < V; ++e) {
-            const float cand = s[e] * m;
-            if (cand > best[e]) { best[e] = cand; bi[e] = t; }
+            for (int e = 0; e < V; ++e) {
+              const float cand = __builtin_fmaf(s[e], am, bm);
+              if (cand > best[e]) { best[e] = cand; bi[e] = t; }
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+              for (int e = 0; e < V; ++e) s[e] = s[e] + ((v[k][e] * a) + b) * tp.w[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const float cand = s[e] * m;
+              if (cand > best[e]) { best[e] = cand; bi[e] = t; }
+            }
           }
         } else if (!zero_done) {
           zero_done = true;
