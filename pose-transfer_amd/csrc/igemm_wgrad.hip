@@ -705,6 +705,28 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dY, long ro
   const float t = block_sum_256(acc, red);
   if (threadIdx.x == 0) atomicAdd(db + c, t);
 }
+// planar (NCHW) gradient: rows_inner contiguous floats per (outer row, channel) plane (s_inner == 1, 16-byte aligned, rows_inner %
+// 4 == 0).  grid.x = plane (outer * C + c), grid.y = slice of the plane; 16-byte loads, four in flight per lane.  The generic
+// kernel above pays a 64-bit division per element (67 us for the 25 MB gradient of the output image at batch 32; this: ~10 us).
+__global__ __launch_bounds__(256) void bias_grad_planar_kernel(const float* dY, long rows_inner, int C, long s_outer, long sC, float* db) {
+  __shared__ float red[4];
+  const long o = blockIdx.x / C;
+  const int c = blockIdx.x - (int)o * C;
+  const float4* p4 = reinterpret_cast<const float4*>(dY + o * s_outer + (long)c * sC);
+  const long n4 = rows_inner >> 2;
+  const long per = (n4 + gridDim.y - 1) / gridDim.y;
+  const long i0 = (long)blockIdx.y * per, i1 = min(n4, i0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  long i = i0 + threadIdx.x;
+  for (; i + 768 < i1; i += 1024) {
+    const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+    a0 += (v0.x + v0.y) + (v0.z + v0.w); a1 += (v1.x + v1.y) + (v1.z + v1.w);
+    a2 += (v2.x + v2.y) + (v2.z + v2.w); a3 += (v3.x + v3.y) + (v3.z + v3.w);
+  }
+  for (; i < i1; i += 256) { const float4 v = p4[i]; a0 += (v.x + v.y) + (v.z + v.w); }
+  const float t = block_sum_256((a0 + a1) + (a2 + a3), red);
+  if (threadIdx.x == 0) atomicAdd(db + c, t);
+}
 // channel-contiguous (NHWC) gradient with C % 4 == 0 and 256 % (C/4) == 0: every lane streams float4s of its channel
 // quad over the pixels (fully coalesced, each byte read once); the generic kernel above reads 4 useful bytes per
 // 64-byte sector and every channel block re-reads the same lines
@@ -752,6 +774,40 @@ __global__ __launch_bounds__(256) void bias_grad_nhwc_kernel(const float* dY, lo
     atomicAdd(db + threadIdx.x * 4 + 2, t.z); atomicAdd(db + threadIdx.x * 4 + 3, t.w);
   }
 }
+// bf16 tensors, 8 channels (16 bytes) per lane: twice the bytes in flight per lane of the 4-channel form above
+__global__ __launch_bounds__(256) void bias_grad_bf16x8_kernel(const unsigned short* dY, long npix, int C, float* db) {
+  __shared__ float red[256][8];
+  const int cq = C >> 3;                       // 16-byte chunks per pixel
+  const int chunk = threadIdx.x % cq, prow = threadIdx.x / cq, ppb = 256 / cq;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const long step = (long)gridDim.x * ppb;
+  long pix = (long)blockIdx.x * ppb + prow;
+  auto add = [&](const uint4 u) {
+    acc[0] += __uint_as_float(u.x << 16); acc[1] += __uint_as_float(u.x & 0xffff0000u);
+    acc[2] += __uint_as_float(u.y << 16); acc[3] += __uint_as_float(u.y & 0xffff0000u);
+    acc[4] += __uint_as_float(u.z << 16); acc[5] += __uint_as_float(u.z & 0xffff0000u);
+    acc[6] += __uint_as_float(u.w << 16); acc[7] += __uint_as_float(u.w & 0xffff0000u);
+  };
+  for (; pix + 7 * step < npix; pix += 8 * step) {      // eight independent 16-byte loads in flight per lane
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(dY + (pix + u * step) * C + chunk * 8);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) add(v[u]);
+  }
+  for (; pix < npix; pix += step) add(*reinterpret_cast<const uint4*>(dY + pix * C + chunk * 8));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < cq * 8) {
+    const int ch = threadIdx.x;                // channel; chunk = ch / 8, element = ch % 8
+    float t = 0.f;
+    for (int r = 0; r < ppb; ++r) t += red[r * cq + (ch >> 3)][ch & 7];
+    atomicAdd(db + ch, t);
+  }
+}
 }  // namespace pg
 
 extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,
@@ -769,6 +825,15 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
     PG_LAUNCH_OK("pg_bias_grad");
     return 0;
   }
+  if (s_inner == 1 && rows_inner % 4 == 0 && rows_inner >= 4096 && s_outer % 4 == 0 && sC % 4 == 0 && ((size_t)dY & 15) == 0 &&
+      rows_outer * C <= 65535) {
+    int sl = (int)((rows_inner / 4 + 4095) / 4096);       // >= 16 K floats per workgroup
+    if (sl > 64) sl = 64;
+    PG_KLAUNCH(pg::bias_grad_planar_kernel, dim3((unsigned)(rows_outer * C), sl), dim3(256), 0, (hipStream_t)stream, dY, (long)rows_inner, C,
+               (long)s_outer, (long)sC, db);
+    PG_LAUNCH_OK("pg_bias_grad");
+    return 0;
+  }
   int slices = (int)((rows + 256 * 16 - 1) / (256 * 16));
   if (slices > 64) slices = 64;
   if (slices < 1) slices = 1;
@@ -782,6 +847,17 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
 extern "C" int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, float* db, void* stream) {
   PG_REQUIRE(dY_bf16 && db && npix > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ((size_t)dY_bf16 & 7) == 0,
              "pg_bias_grad_bf16: dense NHWC bf16 tensor with C %% 4 == 0 and 256 %% (C / 4) == 0 required");
+  if (C % 8 == 0 && 256 % (C / 8) == 0 && ((size_t)dY_bf16 & 15) == 0 && getenv("PG_BIAS_GRAD_X4") == nullptr) {
+    const int ppb8 = 256 / (C / 8);
+    long blocks8 = (npix + (long)ppb8 * 16 - 1) / ((long)ppb8 * 16);
+    static const long bcap8 = getenv("PG_BIAS_GRAD_WGS") ? atol(getenv("PG_BIAS_GRAD_WGS")) : 384;
+    const long cap8 = (double)npix * C * 2 >= 64e6 ? bcap8 : 96;
+    if (blocks8 > cap8) blocks8 = cap8;
+    PG_KLAUNCH(pg::bias_grad_bf16x8_kernel, dim3((int)blocks8), dim3(256), 0, (hipStream_t)stream,
+               reinterpret_cast<const unsigned short*>(dY_bf16), (long)npix, C, db);
+    PG_LAUNCH_OK("pg_bias_grad_bf16");
+    return 0;
+  }
   const int ppb = 256 / (C / 4);
   long blocks = (npix + (long)ppb * 16 - 1) / ((long)ppb * 16);
   // 96 workgroups keep ~1.5 MB in flight (8-byte loads): enough for the batch-4 tensors, a third of HBM rate on the 268 MB ones

@@ -561,6 +561,11 @@ def test_bias_grad():
     g2d = g2.to(DEV)
     L.call("pg_bias_grad", L.ptr(g2d), 3, 99, 3, 3 * 99, 1, 99, L.ptr(db2), L.stream())
     assert rel(db2.cpu(), g2.sum((0, 2, 3))) < 1e-5
+    g4 = t(synth.normal(8, "bg4", (3, 3, 72, 68)))             # planar (NCHW) planes of >= 4096 floats: the 16-byte planar kernel
+    db4 = torch.full((3,), -1.5, device=DEV)
+    g4d = g4.to(DEV)
+    L.call("pg_bias_grad", L.ptr(g4d), 3, 72 * 68, 3, 3 * 72 * 68, 1, 72 * 68, L.ptr(db4), L.stream())
+    assert rel(db4.cpu() + 1.5, g4.sum((0, 2, 3))) < 1e-5
 
 
 # ----------------------------------------------------------------------------------------- losses

@@ -500,3 +500,13 @@ def test_warp_backward_candidate_list_overflow():
     (g2,) = torch.autograd.grad((r2 * nchw(gb.float().cpu())).sum(), f2)
     d2 = (nchw(db.float().cpu()) - g2).abs()
     assert (d2 > 2.0 ** -7 * float(g2.abs().max())).float().mean() < 5e-3, float(d2.max())
+
+
+@pytest.mark.parametrize("npix,C", [(5000, 64), (777, 128), (33, 8), (4096, 32)])
+def test_bias_gradient_of_bf16_tensor(npix, C):
+    """pg_bias_grad_bf16 (16-byte loads when C % 8 == 0 and 256 % (C / 8) == 0, 8-byte form otherwise): db[c] += sum over pixels."""
+    x = t(synth.normal(71, "bgb/%d_%d" % (npix, C), (npix, C))).to(DEV).to(torch.bfloat16).contiguous()
+    db = torch.full((C,), 0.5, device=DEV)
+    L.call("pg_bias_grad_bf16", L.ptr(x), npix, C, L.ptr(db), L.stream())
+    ref = x.float().double().sum(0).float().cpu() + 0.5
+    assert float((db.cpu() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
