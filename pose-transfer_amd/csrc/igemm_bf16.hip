@@ -70,6 +70,7 @@ template <int TN_, bool OB>
 __device__ __forceinline__ void big_store_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowB* rows, int wm0, int lane, void* obase,
                                                 int n_cnt, int ngc, bool has_bias, float4 bv, bool do_stats, int n_lo, bool one_sample,
                                                 float (&st_s)[2], float (&st_q)[2], double* stats) {
+  const bool cval = ngc < n_cnt;             // n_cnt < the tile width only on the 32-column output-convolution launch
   constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void big_store_64x64(const f32x16 (&acc)[2][TN_], flo
     }
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
-      const bool ok = ro[it].x >= 0;
+      const bool ok = (ro[it].x >= 0) & cval;
       if (has_bias) { v[it].x += bv.x; v[it].y += bv.y; v[it].z += bv.z; v[it].w += bv.w; }
       if (ok) {
         char* const dst = ob + (size_t)(unsigned)ro[it].y * rowb;

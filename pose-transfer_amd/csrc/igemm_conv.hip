@@ -1715,9 +1715,12 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   // 256-row bf16 kernel (igemm_bf16.hip) for launches with enough 256 x BN tiles to fill the chip (one workgroup per CU)
   if (bf16_data && tb == nullptr && ks == 1 && amode == A_VEC && bmode == B_NT && d->out_act == PG_OUT_NONE &&
       ((d->epilogue == 0 && k.vec_out) || (d->epilogue == 1 && k.vec_dst)) && getenv("PG_NO_BF16_BIG") == nullptr) {
-    const int bn = (k.n_cnt % 256 == 0) ? 256 : (k.n_cnt % 128 == 0 ? 128 : (k.n_cnt == 64 && getenv("PG_NO_BF16_BIG64") == nullptr ? 64 : 0));
+    // (n_cnt == 32: the output convolution's 27 -> 32 tap columns on the 512 x 64 tile, half of its columns masked: half the fp32
+    //  bytes of the 64-column padding; plain epilogue without statistics only)
+    const bool n32 = k.n_cnt == 32 && d->epilogue == 0 && d->stats == nullptr && k.nphase == 1;
+    const int bn = (k.n_cnt % 256 == 0) ? 256 : (k.n_cnt % 128 == 0 ? 128 : ((k.n_cnt == 64 || n32) && getenv("PG_NO_BF16_BIG64") == nullptr ? 64 : 0));
     if (bn != 0) {
-      const int mtb = cdiv(k.M, bn == 64 ? 512 : 256), ntb = k.n_cnt / bn;
+      const int mtb = cdiv(k.M, bn == 64 ? 512 : 256), ntb = cdiv(k.n_cnt, bn);
       const long wgs = (long)mtb * ntb * k.nphase;
       static const long big_min = getenv("PG_BF16_BIG_MIN") ? atol(getenv("PG_BF16_BIG_MIN")) : 192;   // swept (tools/sweep_bf16_big_min.sh): 448 -> 523 / 814, 192 -> 529 / 832 img/s (256^2 batch 4 / 224^2 batch 8)
       if (wgs >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr) {

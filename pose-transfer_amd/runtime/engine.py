@@ -446,7 +446,7 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
     prec = PRECISION
     if prec == 3:
         ncols = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
-        ok = (not scalar_in and n_off == 0 and n_cnt == 0 and ncols > 32 and all(s.C % 64 == 0 for s in srcs)
+        ok = (not scalar_in and n_off == 0 and n_cnt == 0 and ncols >= 32 and all(s.C % 64 == 0 for s in srcs)
               and isinstance(W, torch.Tensor))
         if ok:      # bf16 tensors in, K-contiguous bf16 weights (per-tap transposed copy for the data-gradient)
             srcs = _bf16_sources(srcs, N, Hi, Wi, act, W.device)
@@ -972,9 +972,13 @@ class GeneratorEngine:
         self.out = torch.empty(N, 3, H, W, **f32)
         cin0 = {"encoder_app": 3 + pose_dim, "encoder_pose": pose_dim, "encoder": 3 + 2 * pose_dim}
         self.wt0 = {e: torch.empty(stem_pack_floats(3, cin0[e]), **f32) for e in self.encs}    # [Cin][9][64] repack of conv 0
-        self.y_taps = torch.empty(N, H, W, 64 if self.bfs else 27, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
+        # bf16 STORAGE: the 27 tap columns are padded to 32 when the launch is large enough for the 512 x 64 bf16 kernel (which
+        # masks the upper half of its tile: half the fp32 bytes), else to the 64 columns every bf16 kernel takes
+        self.fin_cols = 27 if not self.bfs else (32 if (N * H * W) // 512 >= int(os.environ.get("PG_BF16_BIG_MIN", "192")) and
+                                                 os.environ.get("PG_NO_FIN32") is None else 64)
+        self.y_taps = torch.empty(N, H, W, self.fin_cols, **f32)       # output conv as a 1x1 with N = 9 taps x 3 channels
         cin_fin = (2 if deformable else 1) * self.enc[0] + self.dec[-2]
-        self.wt_fin = torch.zeros(64, cin_fin, **f32) if self.bfs else None    # bf16 STORAGE: weight padded to the 512 x 64 kernel
+        self.wt_fin = torch.zeros(self.fin_cols, cin_fin, **f32) if self.bfs else None    # bf16 STORAGE: weight padded to the tile
         self.fin_ws = torch.empty(1024 * cin_fin * 28, **f32) if (self.bfs and cin_fin <= 256) else None
         self.g_taps = torch.empty(N, H, W, 32, **f32)       # im2col of d(pre-tanh): weight- and data-gradient operand
         self.wt_out = torch.zeros((2 if deformable else 1) * self.enc[0] + self.dec[-2], 32, **f32)   # [cin][(tap, co)]
@@ -1150,8 +1154,8 @@ class GeneratorEngine:
             # bf16 STORAGE: the three sources are bf16 operands already (normalised block output, relu'd warp, the stem's
             # ReLU copy); the 27 tap columns are padded to the 64-column tile of the bf16 kernels
             dev_copy(self.wt_fin[:27], A.p("decoder.net.%d.weight" % (i + 1)).view(27, cin))
-            _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W, self.wt_fin, 64, cin, out=self.y_taps)
-            L.call("pg_tap_gather_pitch", L.ptr(self.y_taps), 64, N, H, W, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
+            _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W, self.wt_fin, self.fin_cols, cin, out=self.y_taps)
+            L.call("pg_tap_gather_pitch", L.ptr(self.y_taps), self.fin_cols, N, H, W, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
                    L.OUT_TANH, L.ptr(self.out), 3 * H * W, H * W, W, 1, L.stream())
             return self.out
         _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W,
