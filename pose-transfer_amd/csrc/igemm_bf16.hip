@@ -493,9 +493,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    if (!(p.xcd_swizzle & 256)) __builtin_amdgcn_s_barrier();      // bit 8: PG_DEBUG_NO_KBARRIER (timing experiment, wrong results)
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + NST < kt1) { issue(stage); advance(); }        // tile kt + NST into the stage this tile just released
+    if (kt + NST < kt1 && !(p.xcd_swizzle & 512)) { issue(stage); advance(); }        // tile kt + NST into the stage this tile just released (bit 9: PG_DEBUG_NO_KDMA)
     __builtin_amdgcn_sched_barrier(0);
     const int nstage = (NST == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
     if (more) fetch(nstage, 0, va0, vb0);
