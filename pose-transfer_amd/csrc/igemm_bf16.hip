@@ -250,6 +250,13 @@ static __device__ unsigned long long kTimeline[TL_WGS * TL_SLOTS];
 #ifndef PG_BIG_3STAGE
 #define PG_BIG_3STAGE 0
 #endif
+// PG_BIG_SPLIT_DMA: a tile's DMA instructions go out in two halves — the A rows right behind the tile-switch barrier (as before),
+// the B rows behind the next tile's first k-step — instead of all 8 per wave at the one moment when every wave of the CU is in
+// the same state.  K loop in shader cycles (the clock moves with the load): dec.4 forward 223 k -> 209 k, dec.5 data gradient
+// 115.6 k -> 112.4 k, dec.5 forward (128 wide) unchanged; three parts: no further gain.
+#ifndef PG_BIG_SPLIT_DMA
+#define PG_BIG_SPLIT_DMA 1
+#endif
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   constexpr int BM = (BN == 64) ? 512 : 256;                // BN = 64 (N = 64 layers at full resolution): 512 x 64, a wave owns 64 x 64
@@ -423,6 +430,20 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pb[i]), Bs + (i * 8 + wave) * 256, 16, 0, 0);
   };
 
+  // the same in two halves (PG_BIG_SPLIT_DMA): A rows / B rows of the tile
+  auto issue_a = [&](int stage) {
+    float* const As = reinterpret_cast<float*>(smem + stage * STAGE);
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pa[i]), As + (i * 8 + wave) * 256, 16, 0, 0);
+  };
+  auto issue_b = [&](int stage) {
+    float* const Bs = reinterpret_cast<float*>(smem + stage * STAGE + A_ST);
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(pb[i]), Bs + (i * 8 + wave) * 256, 16, 0, 0);
+  };
+
   // ---- operand fetch: k-step ks (16 k's) of a stage -> one register set (TM + TN ds_read_b128)
   const int swr = (l31 >> 1) & 7;
   unsigned fa[4], fb[4];
@@ -472,15 +493,21 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   if constexpr (NST == 3) {
     if (kt0 + 2 < kt1) { issue(2); advance(); }
   }
+  bool pend = false;                 // PG_BIG_SPLIT_DMA: the B half of the tile issued at the last switch is still to be issued
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
     __builtin_amdgcn_sched_barrier(0);
     fetch(stage, 1, va1, vb1);
     PGB_LDS_WAIT(NRD);
     mfmas(va0, vb0);
+    if constexpr (PG_BIG_SPLIT_DMA && NST == 2) {
+      if (pend) { issue_b(stage ^ 1); advance(); pend = false; }      // the B half behind the first k-step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
     fetch(stage, 2, va0, vb0);
     PGB_LDS_WAIT(NRD);
     mfmas(va1, vb1);
+
     fetch(stage, 3, va1, vb1);
     PGB_LDS_WAIT(NRD);
     mfmas(va0, vb0);
@@ -495,7 +522,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     }
     if (!(p.xcd_swizzle & 256)) __builtin_amdgcn_s_barrier();      // bit 8: PG_DEBUG_NO_KBARRIER (timing experiment, wrong results)
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + NST < kt1 && !(p.xcd_swizzle & 512)) { issue(stage); advance(); }        // tile kt + NST into the stage this tile just released (bit 9: PG_DEBUG_NO_KDMA)
+    if (kt + NST < kt1 && !(p.xcd_swizzle & 512)) {        // tile kt + NST into the stage this tile just released (bit 9: PG_DEBUG_NO_KDMA)
+      if constexpr (PG_BIG_SPLIT_DMA && NST == 2) { issue_a(stage); pend = true; }
+      else { issue(stage); advance(); }
+    }
     __builtin_amdgcn_sched_barrier(0);
     const int nstage = (NST == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
     if (more) fetch(nstage, 0, va0, vb0);
