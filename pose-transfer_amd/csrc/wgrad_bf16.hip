@@ -318,6 +318,9 @@ struct Wg4K {
 
 // R2: the small grid has 32 columns — a K tile is TWO small-grid rows; the large patch holds the two large rows 2 (qy + i) + r - 1,
 // 66 pixels each, image row i at plane rows 36 i .. (36 = 32 + 4: the four pixel rows of a transposing read stay aligned).
+#ifndef PG_WG4_SPLIT_DMA
+#define PG_WG4_SPLIT_DMA 1
+#endif
 template <int BM, int BN, int AS, bool R2 = false>
 __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
   constexpr int BS = AS ? BM : BN, BL = AS ? BN : BM;         // widths of the small-grid (shared) / large-grid (per-tap) operand
@@ -390,7 +393,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
   }
   const unsigned Cs2 = (unsigned)p.Cs * 2u, Cl2 = (unsigned)p.Cl * 2u;
   const int Wl = 2 * p.Ws, Hl = 2 * p.Hs;
-  auto issue = [&](int stage, int kt) {
+  // part: 0 = both operands, 1 = the small-grid rows only, 2 = the large-grid patch only (PG_WG4_SPLIT_DMA)
+  auto issue = [&](int stage, int kt, int part = 0) {
     // tile coordinates are wave-uniform: small pixels q0 .. q0 + 63 of row (n, qy), columns qx0 ..; large row Y = 2 qy + tr - 1,
     // patch pixel P <-> large column 2 qx0 - 1 + P
     const int q0 = kt << 6;
@@ -407,11 +411,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
     const unsigned l_off1 = l_off + 2u * (unsigned)Wl * Cl2;
     float* const st = reinterpret_cast<float*>(smem + stage * STAGE);
     const char* const zp = zero_pg + (lane & 7) * 16;
+    if (part != 2) {
 #pragma unroll
     for (int i = 0; i < S_PASS; ++i) {
       const char* src = live ? s_base + (s_off + s_cofs[i]) : zp;
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), st + min(i * 8 + wave, S_NI - 1) * 256, 16, 0, 0);
     }
+    }
+    if (part == 1) return;
 #pragma unroll
     for (int i = 0; i < L_PASS; ++i) {
       const bool rok = R2 ? (l_i[i] ? row_ok1 : row_ok) : row_ok;
@@ -495,12 +502,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
   FragSet f0, f1;
   fetch(0, K0{}, f0);
   int stage = 0;
+  int pend_stage = -1, pend_kt = 0;          // PG_WG4_SPLIT_DMA: the large-grid half of the last issued tile is still to go out
   for (int kt = kt0; kt < kt1; ++kt) {
     const int nstage = stage == NST - 1 ? 0 : stage + 1;
     __builtin_amdgcn_sched_barrier(0);
     fetch(stage, K1{}, f1);
     PGW_WAIT(NRD);
     mfmas(f0);
+    if constexpr (PG_WG4_SPLIT_DMA) {
+      if (pend_stage >= 0) { issue(pend_stage, pend_kt, 2); pend_stage = -1; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     fetch(stage, K2{}, f0);
     PGW_WAIT(NRD);
     mfmas(f1);
@@ -512,7 +524,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr4_kernel(const Wg4K p) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    issue(stage, kt + 3);
+    if constexpr (PG_WG4_SPLIT_DMA) {
+      if (kt + 1 < kt1) { issue(stage, kt + 3, 1); pend_stage = stage; pend_kt = kt + 3; }      // the rest behind the next tile's first k-step
+      else issue(stage, kt + 3);                    // last iteration: keep the vmcnt accounting complete
+    } else {
+      issue(stage, kt + 3);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < kt1) fetch(nstage, K0{}, f0);
     mfmas(f1);
