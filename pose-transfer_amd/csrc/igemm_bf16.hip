@@ -523,7 +523,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     if (!(p.xcd_swizzle & 256)) __builtin_amdgcn_s_barrier();      // bit 8: PG_DEBUG_NO_KBARRIER (timing experiment, wrong results)
     __builtin_amdgcn_sched_barrier(0);
     if (kt + NST < kt1 && !(p.xcd_swizzle & 512)) {        // tile kt + NST into the stage this tile just released (bit 9: PG_DEBUG_NO_KDMA)
-      if constexpr (PG_BIG_SPLIT_DMA && NST == 2) { issue_a(stage); pend = true; }
+      if constexpr (PG_BIG_SPLIT_DMA && NST == 2) {
+        if (!((p.xcd_swizzle & 1024) && (kt & 3))) issue_a(stage);      // bit 10: PG_DEBUG_A_EVERY_4TH (timing experiment: A rows on one K tile in four)
+        pend = true;
+      }
       else { issue(stage); advance(); }
     }
     __builtin_amdgcn_sched_barrier(0);

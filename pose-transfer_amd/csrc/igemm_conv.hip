@@ -1734,6 +1734,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
         if (getenv("PG_DEBUG_EPI_NOACC")) k.xcd_swizzle |= 128;
         if (getenv("PG_DEBUG_NO_KBARRIER")) k.xcd_swizzle |= 256;
         if (getenv("PG_DEBUG_NO_KDMA")) k.xcd_swizzle |= 512;
+        if (getenv("PG_DEBUG_A_EVERY_4TH")) k.xcd_swizzle |= 1024;
         if (k.dst_io == 1 && k.Gy * k.Gx < 32) k.dst_io = 2;      // the pipelined bf16 scatter assumes <= 2 samples per 32 rows
         launch_conv_bf16_big(k, bn, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
