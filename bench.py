@@ -161,6 +161,8 @@ HBM_MODELS = {
     "pg_warp_mask_max_fwd_io": lambda a: _ival(a[4]) * _ival(a[7]) * _ival(a[8]) * (
         _ival(a[6]) * ((2 if _ival(a[14]) & 1 else 4) + (2 if _ival(a[14]) & 2 else 4)) + 4 * _ival(a[5])),
     "pg_warp_mask_max_bwd_io": lambda a: int(_ival(a[4]) * _ival(a[7]) * _ival(a[8]) * _ival(a[6]) * (8.25 if _ival(a[13]) == 3 else 16.5)),
+    # (round 3) the backward with the limb masks' bounding boxes: same bytes, `bbox` sits in front of N
+    "pg_warp_mask_max_bwd_bbox": lambda a: int(_ival(a[5]) * _ival(a[8]) * _ival(a[9]) * _ival(a[7]) * (8.25 if _ival(a[14]) == 3 else 16.5)),
     "pg_norm_bwd_reduce_ex": lambda a: (4 if _ival(a[6]) == 3 else 8) * _ival(a[3]) * _ival(a[4]),
     "pg_norm_bwd_apply_io": lambda a: (6 if _ival(a[10]) == 3 else (14 if a[9] else 12)) * _ival(a[5]) * _ival(a[6]),
     "pg_materialise_bf16_ex": lambda a: ((2 if _ival(a[1]) else 4) + (4 if a[9] else 2)) * _ival(a[5]) * _ival(a[6]) * _ival(a[7]),
@@ -174,8 +176,8 @@ HBM_MODELS = {
                              * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
     "pg_bias_grad_bf16": lambda a: 2 * _ival(a[1]) * _ival(a[2]),
     "pg_tap_gather_pitch": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (27 * 4 + 12),
-    # output-conv backward, bf16 storage: data gradient (dpre + activated operand + gradient write) + weight gradient (dpre + operand)
-    "pg_out_conv_bwd_direct": lambda a: _ival(a[3]) * _ival(a[4]) * _ival(a[5]) * (24 + 6 * sum(a[6][i].C for i in range(_ival(a[7])))),
+    # output-conv backward, bf16 storage, ONE pass: dpre (12 B / pixel) + activated operand read once + gradient write (2 + 2 B / channel)
+    "pg_out_conv_bwd_direct": lambda a: _ival(a[3]) * _ival(a[4]) * _ival(a[5]) * (12 + 4 * sum(a[6][i].C for i in range(_ival(a[7])))),
     "pg_l1_loss": lambda a: 12 * _ival(a[2]),
     "pg_tanh_bwd": lambda a: 12 * _ival(a[2]),
 }
