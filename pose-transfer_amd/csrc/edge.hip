@@ -50,6 +50,29 @@ __global__ __launch_bounds__(256) void tap_gather_333_kernel(const float* Y, int
   const int n = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const int xlo = max(x0 - 1, 0), xhi = min(x0 + TW + 1, W);          // staged columns [xlo, xhi)
   const int run = (xhi - xlo) * CT, lpad = (xlo - (x0 - 1)) * CT;
+  if (pitch >= 28 && (pitch & 3) == 0 && (((size_t)Y) & 15) == 0) {
+    // padded pixel rows (round 3: pitch 32 / 64 behind the bf16 contraction): one item = a pixel of the halo, its 27 floats arrive
+    // as seven 16-byte loads (the 4-byte form below pays an integer division per float and 27 load instructions per pixel)
+    for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 256) {
+      const int r = i / (TW + 2), c = i - r * (TW + 2);
+      const int yy = y0 + r - 1, xx = x0 + c - 1;
+      float* tp = tile + i * CT;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+#pragma unroll
+        for (int k = 0; k < CT; ++k) tp[k] = 0.f;
+      } else {
+        const float4* src = reinterpret_cast<const float4*>(Y + (((long)n * H + yy) * W + xx) * pitch);
+        float4 v[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) v[q] = src[q];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          tp[4 * q] = v[q].x; tp[4 * q + 1] = v[q].y; tp[4 * q + 2] = v[q].z;
+          if (q < 6) tp[4 * q + 3] = v[q].w;
+        }
+      }
+    }
+  } else
   for (int r = 0; r < TH + 2; ++r) {
     const int yy = y0 + r - 1;
     float* trow = tile + r * (TW + 2) * CT;

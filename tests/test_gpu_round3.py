@@ -510,3 +510,25 @@ def test_bias_gradient_of_bf16_tensor(npix, C):
     L.call("pg_bias_grad_bf16", L.ptr(x), npix, C, L.ptr(db), L.stream())
     ref = x.float().double().sum(0).float().cpu() + 0.5
     assert float((db.cpu() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("pitch", [27, 32, 64])
+def test_tap_gather_with_padded_pixel_rows(pitch):
+    """pg_tap_gather_pitch (k3 p1, 3 output channels: sum of the 9 shifted taps + bias + tanh) on tap tensors whose pixel rows are
+    27 (dense), 32 or 64 floats apart — the padded forms take 16-byte staging loads — against the same sum in torch."""
+    N, H, W = 2, 19, 45                                    # ragged against the 8 x 32 tile
+    taps = t(synth.normal(91, "tgp/%d" % pitch, (N, H, W, 27)))
+    Y = torch.full((N, H, W, pitch), float("nan"))
+    Y[..., :27] = taps
+    bias = t(synth.normal(91, "tgp/b", (3,)))
+    Yd, bd = Y.to(DEV).contiguous(), bias.to(DEV)
+    out = torch.full((N, 3, H, W), float("nan"), device=DEV)
+    L.call("pg_tap_gather_pitch", L.ptr(Yd), pitch, N, H, W, L.ptr(bd), L.OUT_TANH, L.ptr(out), 3 * H * W, H * W, W, 1, L.stream())
+    P = F.pad(taps.double(), (0, 0, 1, 1, 1, 1))           # pad W and H
+    ref = torch.zeros(N, 3, H, W, dtype=torch.float64)
+    for r in range(3):
+        for s in range(3):
+            for co in range(3):
+                ref[:, co] += P[:, r:r + H, s:s + W, (r * 3 + s) * 3 + co]
+    ref = torch.tanh(ref + bias.double().view(1, 3, 1, 1)).float()
+    assert maxdiff(out, ref) < 2e-6
