@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const bool resident = p.ngroups == 1 && NST == 1;         // the whole filter stays in LDS across tiles
+  // (round 3: the filter stage is re-read per tile — 28 KB from L2 — because the epilogue's transposition tiles reuse its LDS)
+  const bool resident = false;
 
   for (int i = tid; i < PATCH_B / 16; i += 256) reinterpret_cast<float4*>(patch)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto stage_w = [&](int g, int st) {
@@ -178,43 +179,46 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
         }
       }
     }
-    // ---- epilogue: + bias, raw fp32 NHWC store (32 consecutive channels per half wave = 128-byte segments)
+    // ---- epilogue (round 3): + bias, then every M-tile (32 pixels x 64 channels) goes through a wave-private LDS tile (pitch 68
+    //      floats, in the filter stage's memory) and comes back as 4 consecutive channels of a pixel per lane: 16-byte fp32 /
+    //      8-byte bf16 stores, a full 128-byte bf16 row per 16 lanes.  One transposition serves all outputs — the optional fp32
+    //      tensor and up to three bf16(act_k(out)) tensors (raw bf16 STORAGE / the next layers' activated operands).  The
+    //      channel-per-lane form cost a lane exchange + a 4-byte store per two values and output: the kernel was bound by it.
+    __syncthreads();                                        // every wave is done with the filter stage
+    {
+      float* const T = reinterpret_cast<float*>(smem + PATCH_B) + wave * (32 * 68);
 #pragma unroll
-    for (int i = 0; i < TMW; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
-        if (p.out != nullptr && oy < p.Ho && ox < p.Wo) {
-          float* o = p.out + (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + l31;
-          o[0] = acc[i][0][r] + bias0;
-          o[32] = acc[i][1][r] + bias1;
-        }
-      }
-    // ---- optional second output: the activated bf16 operand of the next layer (saves its pg_materialise_bf16 pass).  Lane
-    //      pairs exchange one value so that every lane stores 4 bytes: even lanes (channel c, c+1) of row r, odd lanes of r+1.
-#pragma unroll
-    for (int ob = 0; ob < 3; ++ob) {
-      unsigned short* const optr = ob == 0 ? p.out_bf16 : (ob == 1 ? p.obf2 : p.obf3);
-      const float oslope = ob == 0 ? p.slope : (ob == 1 ? p.slope2 : p.slope3);
-      if (optr == nullptr) continue;
-#pragma unroll
-      for (int i = 0; i < TMW; ++i)
+      for (int i = 0; i < TMW; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float bj = j ? bias1 : bias0;
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const float va = apply_act_s(acc[i][j][r] + bj, oslope), vb = apply_act_s(acc[i][j][r + 1] + bj, oslope);
-            const float got = __shfl_xor((lane & 1) ? va : vb, 1, 64);
-            const int rr = r + (lane & 1);
-            const unsigned pk = (lane & 1) ? pack_bf16(got, vb) : pack_bf16(va, got);
-            const int m = (rr & 3) + 8 * (rr >> 2) + 4 * lhi;
-            const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
-            if (oy < p.Ho && ox < p.Wo)
-              *reinterpret_cast<unsigned*>(optr + (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + j * 32 + (l31 & ~1)) = pk;
+          for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 68 + j * 32 + l31] = acc[i][j][r] + bj;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const float4*>(&T[(it * 4 + (lane >> 4)) * 68 + (lane & 15) * 4]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int m = it * 4 + (lane >> 4);
+          const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
+          if (oy >= p.Ho || ox >= p.Wo) continue;
+          const long o = (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + (lane & 15) * 4;
+          if (p.out != nullptr) *reinterpret_cast<float4*>(p.out + o) = v[it];
+#pragma unroll
+          for (int ob = 0; ob < 3; ++ob) {
+            unsigned short* const optr = ob == 0 ? p.out_bf16 : (ob == 1 ? p.obf2 : p.obf3);
+            const float oslope = ob == 0 ? p.slope : (ob == 1 ? p.slope2 : p.slope3);
+            if (optr == nullptr) continue;
+            *reinterpret_cast<uint2*>(optr + o) = make_uint2(pack_bf16(apply_act_s(v[it].x, oslope), apply_act_s(v[it].y, oslope)),
+                                                             pack_bf16(apply_act_s(v[it].z, oslope), apply_act_s(v[it].w, oslope)));
           }
         }
+      }
     }
   }
 }
@@ -415,7 +419,7 @@ static int launch_stem_conv(StemK& k, hipStream_t st) {
   constexpr int PH = (TH - 1) * S + K, PW = 15 * S + K, PWH = (PW + 1) / 2, ROWP = (S == 1) ? PW : 2 * PWH;
   constexpr int PATCH_B = (PH * ROWP * CG * 2 + 15) / 16 * 16;
   constexpr int NCH = ((K == 3) ? 9 : 4) * (CG / 8), NKS = (NCH + 1) / 2;
-  constexpr int LDS = PATCH_B + 2 * NKS * 1024;
+  constexpr int LDS = PATCH_B + (2 * NKS * 1024 > 4 * 32 * 68 * 4 ? 2 * NKS * 1024 : 4 * 32 * 68 * 4);      // filter stage / the epilogue's four transposition tiles
   static_assert(LDS <= 160 * 1024, "stem conv: LDS");
   k.tiles_x = (k.Wo + 15) / 16; k.tiles_y = (k.Ho + TH - 1) / TH;
   k.ntiles = k.tiles_x * k.tiles_y * k.N;
