@@ -279,31 +279,40 @@ __global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float* W, in
   }
 }
 // All transposed bf16 weight copies of an arena in ONE launch (round 3: 23 launches per iteration before — launch-count bound at
-// small batch).  table[k] = {float offset of tensor k in the arena, taps, Cout, Cin, first tile}; a workgroup = one 32 x 32 tile
-// of one tap of one tensor; out_t[off + tap*Cout*Cin + ci*Cout + co] = bf16(W[off + tap*Cout*Cin + co*Cin + ci]).
+// small batch).  table[k] = {float offset of tensor k in the arena, taps, Cout, Cin, first tile}; a workgroup = one 64 (Cout) x 32 (Cin)
+// tile of one tap of one tensor; out_t[off + tap*Cout*Cin + ci*Cout + co] = bf16(W[off + tap*Cout*Cin + co*Cin + ci]).
 struct WtTab { long off; int taps, Cout, Cin, tile0; };
 __global__ __launch_bounds__(256) void weights_to_bf16_batch_kernel(const float* arena, const WtTab* tab, int ntab, unsigned short* out_t) {
-  __shared__ float tile[32][33];
+  // a workgroup = one tile of 64 output channels x 32 input channels of one tap (host: tile0 counts such tiles); read as 128-byte
+  // rows, written as 128-byte rows of bf16 PAIRS (two consecutive output channels per lane) when Cout is even
+  __shared__ float tile[64][33];
   int k = 0;
   const int b = blockIdx.x;
   while (k + 1 < ntab && tab[k + 1].tile0 <= b) ++k;
   const WtTab e = tab[k];
-  const int tci = (e.Cin + 31) / 32, tco = (e.Cout + 31) / 32;
+  const int tci = (e.Cin + 31) / 32, tco = (e.Cout + 63) / 64;
   int r = b - e.tile0;
   const int tap = r / (tci * tco); r -= tap * tci * tco;
-  const int co0 = (r / tci) * 32, ci0 = (r % tci) * 32;
+  const int co0 = (r / tci) * 64, ci0 = (r % tci) * 32;
   const long base = e.off + (long)tap * e.Cout * e.Cin;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
-  for (int q = ty; q < 32; q += 8) {
+  for (int q = ty; q < 64; q += 8) {
     const int co = co0 + q, ci = ci0 + tx;
     tile[q][tx] = (co < e.Cout && ci < e.Cin) ? arena[base + (long)co * e.Cin + ci] : 0.f;
   }
   __syncthreads();
+  const bool pairs = (e.Cout & 1) == 0;
 #pragma unroll
   for (int q = ty; q < 32; q += 8) {
-    const int ci = ci0 + q, co = co0 + tx;
-    if (ci < e.Cin && co < e.Cout) out_t[base + (long)ci * e.Cout + co] = (unsigned short)(pack2_bf16(tile[tx][q], 0.f) & 0xffffu);
+    const int ci = ci0 + q, co = co0 + 2 * tx;
+    if (ci >= e.Cin) continue;
+    if (pairs) {
+      if (co < e.Cout) *reinterpret_cast<unsigned*>(out_t + base + (long)ci * e.Cout + co) = pack2_bf16(tile[2 * tx][q], tile[2 * tx + 1][q]);
+    } else {
+      if (co < e.Cout) out_t[base + (long)ci * e.Cout + co] = (unsigned short)(pack2_bf16(tile[2 * tx][q], 0.f) & 0xffffu);
+      if (co + 1 < e.Cout) out_t[base + (long)ci * e.Cout + co + 1] = (unsigned short)(pack2_bf16(tile[2 * tx + 1][q], 0.f) & 0xffffu);
+    }
   }
 }
 }  // namespace pg

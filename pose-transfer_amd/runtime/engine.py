@@ -182,7 +182,7 @@ class ParamArena:
                     continue
                 taps, co, ci = ps[0] * ps[1], ps[2], ps[3]
                 rec.append((self.off[k], taps, co, ci, tile0))
-                tile0 += taps * ((co + 31) // 32) * ((ci + 31) // 32)
+                tile0 += taps * ((co + 63) // 64) * ((ci + 31) // 32)       # 64 x 32 tiles (csrc/optim.hip)
             tab = np.zeros(len(rec), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("co", "<i4"), ("ci", "<i4"), ("t0", "<i4")]))
             for i, r in enumerate(rec):
                 tab[i] = r
