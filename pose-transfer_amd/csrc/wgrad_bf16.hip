@@ -665,7 +665,11 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
     // 64 -> 681 / 439 / 656.
     const long base = (long)mt * nt * 16;
     static const int target = getenv("PG_WGTR_TARGET") ? atoi(getenv("PG_WGTR_TARGET")) : 128;
-    ks = (int)((target + base - 1) / base);
+    // thin tiles with a long K (the discriminator's 64 -> 128 layer on 63 x 63 maps: one 128 x 64 tile per tap, 1985 K tiles — 0.59 ms
+    // per launch at batch 32 with 8 splits): these are latency-bound per workgroup, so they take 512 workgroups
+    static const int thin_target = getenv("PG_WGTR_THIN_TARGET") ? atoi(getenv("PG_WGTR_THIN_TARGET")) : 512;
+    const long tgt = ((long)bm * bn <= 128 * 64 && ktot >= 1024) ? thin_target : target;
+    ks = (int)((tgt + base - 1) / base);
     if (ks > ktot / 16) ks = ktot / 16;
     if (ks < 1) ks = 1;
   }
