@@ -51,6 +51,9 @@ __device__ __forceinline__ void lds_tr64(unsigned long long& v, unsigned addr) {
 template <int CPR>
 __device__ __forceinline__ int wg_swz(int pixel) { return CPR >= 16 ? ((pixel & 3) << 2) : (((pixel >> 1) & 1) << 2); }
 
+#ifndef PG_WG1_SPLIT_DMA
+#define PG_WG1_SPLIT_DMA 1
+#endif
 template <int BM, int BN, int AS>
 __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) {
   constexpr int WGN = (BN == 64) ? 2 : (BM == 64 ? 4 : ((BN == 256) ? 4 : (BM == 256 ? 2 : 4)));
@@ -156,13 +159,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
   // discriminator (127 -> 63 -> 31 ...), where tap 3 of the last row is still inside
   const bool edge_y0 = tr == 0, edge_x0 = ts == 0;
   const int ylim = (p.Hl - tr + 2) >> 1, xlim = (p.Wl - ts + 2) >> 1;
-  auto issue = [&](int stage, int kt) {
+  // part: 0 = both operands, 1 = the small-grid rows, 2 = the large-grid rows (PG_WG1_SPLIT_DMA: two halves, see igemm_bf16.hip)
+  auto issue = [&](int stage, int kt, int part = 0) {
     (void)kt;
     float* const As = reinterpret_cast<float*>(smem + stage * STAGE);
     float* const Bs = reinterpret_cast<float*>(smem + stage * STAGE + A_ST);
     float* const Ss = AS ? As : Bs;
     float* const Ls = AS ? Bs : As;
     const char* const zp = zero_pg + (lane & 7) * 16;
+    if (part != 2) {
 #pragma unroll
     for (int i = 0; i < S_PASS; ++i) {
       const bool ok = s_q[i] < Q32;
@@ -170,6 +175,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), Ss + (i * 8 + wave) * 256, 16, 0, 0);
       s_q[i] += 64; s_off[i] += s_step;
     }
+    }
+    if (part == 1) return;
 #pragma unroll
     for (int i = 0; i < L_PASS; ++i) {
       const bool oob = (ln[i] >= p.N) | (edge_y0 & (ly0[i] == 0)) | (ly0[i] >= ylim) | (edge_x0 & (lx0[i] == 0)) | (lx0[i] >= xlim);
@@ -250,12 +257,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
   fetch(0, K0{}, va0, vb0);
   int stage = 0;
   if (kt0 + 1 < kt1) issue(1, kt0 + 1);
+  bool pend = false;
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
     __builtin_amdgcn_sched_barrier(0);
     fetch(stage, K1{}, va1, vb1);
     PGW_WAIT(NRD);
     mfmas(va0, vb0);
+    if constexpr (PG_WG1_SPLIT_DMA) {
+      if (pend) { issue(stage ^ 1, kt + 1, 2); pend = false; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     fetch(stage, K2{}, va0, vb0);
     PGW_WAIT(NRD);
     mfmas(va1, vb1);
@@ -265,7 +277,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_tr_kernel(const WgBf16K p) 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < kt1) issue(stage, kt + 2);       // the stage this tile just released; a full tile of MFMA time ahead of its wait
+    if (kt + 2 < kt1) {                           // the stage this tile just released; a full tile of MFMA time ahead of its wait
+      if constexpr (PG_WG1_SPLIT_DMA) { issue(stage, kt + 2, 1); pend = true; }
+      else issue(stage, kt + 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (more) fetch(stage ^ 1, K0{}, va0, vb0);
     mfmas(va1, vb1);
