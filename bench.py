@@ -6,7 +6,13 @@ src_deformable warp_skip=mask, fasion 256x256, 18 key-points, batch 4 per GPU, f
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+    python bench.py --gpus N              # without a launcher: re-executes itself under torch.distributed.run with N ranks
+
 Prints ONE JSON line (rank 0).  `value` = global images / second with inputs resident in HBM.
+`parity` (N=1): the SAME first iteration (same weights, batches, dropout masks) on the device and in the CPU oracle:
+max-abs(out_gen) and the relative error of the loss triples (<= 1e-3 / <= 1e-4 in fp32).
+`north_star` / `bf16_data_b32_img_s` (N=1): BASELINE.json's sub-metric — generator forward+backward at 256x256, batch 32
+on the bf16 data path against the dense bf16 MFMA peak — and the full training iteration in that configuration.
 `roofline`: the dominant contraction kernel family timed per launch with HIP events on the launch stream
 (a separate, un-timed profiled iteration) against the fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
 `cpu_baseline`: the CPU oracle (oracle/ref_cpu.py, torch-CPU restatement of the reference) timed on this
@@ -73,45 +79,157 @@ def step_flops(size, pose_dim):
     return 4 * fg + 8 * fd, fg, fd
 
 
-def cpu_baseline(args):
+def parity_device_iteration(args, device, rank):
+    """The FIRST training iteration of the bench configuration on the device with everything pinned: the timed model's
+    initial weights (init_seed=0), the bench batches, explicit dropout masks, eager losses.  Returns what the oracle needs to
+    repeat exactly that iteration (cpu_baseline) and the device's results."""
+    n = min(args.batch, 4)
+    o = make_opt(args)
+    o.batch_size = n
+    model = DeformablePose_GAN(o, device=device, init_seed=0)
+    gsd = {k: v.detach().cpu().clone() for k, v in model.gen.state_dict().items()}
+    dsd = {k: v.detach().cpu().clone() for k, v in model.disc.state_dict().items()}
+    host = [synth.batch(1234 + rank, "bench/%s" % s_, n, P, args.size, args.size) for s_ in "ABC"]
+    drops = [synth.dropout_masks(1234 + rank, "bench/d%s" % s_, n) for s_ in "AC"]
+    dev = lambda arrs: [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in arrs]
+    a, b, c = [dev(h) for h in host]
+    dA, dC = [dev(d) for d in drops]
+    od = dict(vars(o), lazy_losses=False)
+    dl = model.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3], "drop_masks": dA}, b[0], b[1], od)
+    og, _, gl = model.gen_update(c[0], c[1], {"warps": c[2], "masks": c[3], "drop_masks": dC}, od)
+    res = {"dis": [float(v) for v in dl], "gen": [float(v) for v in gl], "out_gen": og.detach().cpu()}
+    del model
+    torch.cuda.empty_cache()
+    return {"n": n, "gen_sd": gsd, "disc_sd": dsd, "host": host, "drops": drops, "device": res}
+
+
+def cpu_baseline(args, pin=None):
     """Oracle (kind 'port') on the host cores: dis_update + gen_update at the bench resolution and per-GPU batch (capped at
-    4), 1 warm-up + up to 3 timed iterations; timing stops early once 45 s of timed work are spent so that
-    the default run stays within minutes."""
+    4), 1 warm-up + 3 timed iterations.  With `pin` (parity_device_iteration) the oracle starts from the SAME
+    weights, batches and dropout masks as the device did, and its warm-up iteration doubles as the parity check."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_cpu as R
     n = min(args.batch, 4)
     size = args.size
     enc, dec = synth.nfilters((size, size))
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
     cfg = dict(pose_dim=P, image_size=(size, size), batch_size=n, gan_penalty_weight=1.0,
                l1_penalty_weight=args.l1_penalty_weight, learning_rate=2e-4,
                content_loss_layer=args.content_loss_layer, nn_loss_area_size=args.nn_loss_area_size,
                nfilters_enc=enc, nfilters_dec=dec, aten_warp=True)
-    gp = {k: t(v) for k, v in synth.init_params(1, "cpu/gen", synth.generator_spec(P, enc, dec)).items()}
-    dpar = {k: t(v) for k, v in synth.init_params(1, "cpu/disc", synth.discriminator_spec(3 + 2 * P + 3)).items()}
+    if pin is not None:
+        gp, dpar = {k: t(v) for k, v in pin["gen_sd"].items()}, {k: t(v) for k, v in pin["disc_sd"].items()}
+        b = [[t(a) for a in h] for h in pin["host"]]
+        dA, dC = [[t(m) for m in d] for d in pin["drops"]]
+    else:
+        gp = {k: t(v) for k, v in synth.init_params(1, "cpu/gen", synth.generator_spec(P, enc, dec)).items()}
+        dpar = {k: t(v) for k, v in synth.init_params(1, "cpu/disc", synth.discriminator_spec(3 + 2 * P + 3)).items()}
+        b = [[t(a) for a in synth.batch(1, "cpu/%s" % s, n, P, size, size)] for s in "ABC"]
+        dA = dC = [t(m) for m in synth.dropout_masks(1, "cpu/d", n)]
     vgg = (t(synth.xavier_uniform(14, "vgg/w", (64, 3, 3, 3))), t(synth.uniform(14, "vgg/b", (64,), -0.1, 0.1)))
     tr = R.Trainer(cfg, gp, dpar, vgg)
-    b = [[t(a) for a in synth.batch(1, "cpu/%s" % s, n, P, size, size)] for s in "ABC"]
-    d = [t(m) for m in synth.dropout_masks(1, "cpu/d", n)]
     cores = torch.get_num_threads()
+    last = {}
 
     def iteration():
         t0 = time.time()
-        tr.dis_update(b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], d)
-        tr.gen_update(b[2][0], b[2][1], b[2][2], b[2][3], d)
+        last["dis"] = tr.dis_update(b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], dA)
+        last["out_gen"], last["gen"] = tr.gen_update(b[2][0], b[2][1], b[2][2], b[2][3], dC)
         return time.time() - t0
 
     warm = iteration()
-    times = []
-    while len(times) < 3 and (not times or sum(times) + times[-1] < 45.0):
-        times.append(iteration())
+    parity = None
+    if pin is not None:
+        dv = pin["device"]
+        rel = lambda x, y: float(max(abs(p - q) / max(abs(q), 1e-12) for p, q in zip(x, y)))
+        parity = {"out_gen_max_abs": float((dv["out_gen"] - last["out_gen"]).abs().max()),
+                  "dis_losses_rel": rel(dv["dis"], last["dis"]), "gen_losses_rel": rel(dv["gen"], last["gen"]),
+                  "device_losses": {"dis": dv["dis"], "gen": dv["gen"]},
+                  "oracle_losses": {"dis": [float(v) for v in last["dis"]], "gen": [float(v) for v in last["gen"]]},
+                  "what": "first dis_update+gen_update from identical weights / batches / dropout masks, %dx%d, batch %d, %s "
+                          "on the device vs oracle/ref_cpu.py (fp32, torch-CPU); bars (fp32): out_gen <= 1e-3 max-abs, losses <= "
+                          "1e-4 relative (SURVEY.md 8d)" % (size, size, n, args.precision)}
+    times = [iteration() for _ in range(args.cpu_iters)]
     dt = sum(times) / len(times)
-    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "work": "4 F_G + 8 F_D port (the reference as written executes 6 F_G + 9 F_D: its dis_update also back-propagates "
-                    "through the generator, pose_gan.py:129,166 — the reference itself would be ~1.4x slower than this baseline)",
-            "sample": "%d timed iteration(s) after 1 warm-up (%.1f s) of dis_update+gen_update, %dx%d, batch %d, fp32, "
-                      "oracle/ref_cpu.py on torch-CPU (%d threads), %.1f s per iteration"
-                      % (len(times), warm, size, size, n, cores, dt)}
+    out = {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+           "work": "4 F_G + 8 F_D port (the reference as written executes 6 F_G + 9 F_D: its dis_update also back-propagates "
+                   "through the generator, pose_gan.py:129,166 — the reference itself would be ~1.4x slower than this baseline)",
+           "iteration_s": [round(x, 2) for x in times],
+           "sample": "%d timed iteration(s) after 1 warm-up (%.1f s) of dis_update+gen_update, %dx%d, batch %d, fp32, "
+                     "oracle/ref_cpu.py on torch-CPU (%d threads), %.1f s per iteration"
+                     % (len(times), warm, size, size, n, cores, dt)}
+    return out, parity
+
+
+def north_star_legs(device, passes, steps):
+    """BASELINE.json north_star sub-metric under the driver's clock: generator forward + backward at 256x256, batch 32, 18
+    key-points on the bf16 data path (3 F_G x 32 = 13.25 TFLOP per pass) against the dense bf16 MFMA peak, timed with HIP
+    events on the launch stream; then the full training iteration (dis_update + gen_update, 3 independent batches) in the same
+    configuration.  Single GPU, rank 0 only; the default (fp32) model has been freed before."""
+    import ctypes
+    from pose_transfer_amd.runtime import lib as _L
+    N, size, kp = 32, 256, 18
+    prev = E.PRECISION
+    E.PRECISION = 3
+    try:
+        o = SimpleNamespace(image_size=(size, size), use_input_pose=True, pose_dim=kp, batch_size=N, num_stacks=4,
+                            gen_type="baseline", dataset="fasion", warp_skip="mask", learning_rate=2e-4,
+                            content_loss_layer="none", nn_loss_area_size=1, gan_penalty_weight=1.0, l1_penalty_weight=100.0)
+        model = DeformablePose_GAN(o, device=device, init_seed=0)
+        dev = lambda arrs: [torch.from_numpy(a).to(device) for a in arrs]
+        batches = [dev(synth.batch(1234, "ns/%s" % s_, N, kp, size, size)) for s_ in "ABC"]
+        inp, _, wr, mk = batches[0]
+        gout = torch.from_numpy(synth.normal(1234, "ns/gout", (N, 3, size, size))).to(device)
+        eng = model.gen.engine(N)
+        eng.set_dropout(None, train=True, seed=0)
+
+        def one_pass():
+            model.gen.zero_grad()
+            eng.forward(inp, wr, mk)
+            eng.backward(gout)
+
+        for _ in range(3):
+            one_pass()
+        torch.cuda.synchronize()
+        lib = _L.load()
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        lib.pg_event_create(ctypes.byref(e0)); lib.pg_event_create(ctypes.byref(e1))
+        lib.pg_event_record(e0, _L.stream())
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            one_pass()
+        lib.pg_event_record(e1, _L.stream())
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / passes * 1e3
+        ms = ctypes.c_float()
+        lib.pg_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+        lib.pg_event_destroy(e0); lib.pg_event_destroy(e1)
+        ms = ms.value / passes
+        _, fg, _ = step_flops(size, kp)
+        flops = 3.0 * fg * N
+        tf = flops / ms / 1e9
+        ns = {"ms": round(ms, 3), "wall_ms": round(wall, 3), "tflops": round(tf, 1),
+              "frac_of_bf16_peak": round(tf / PEAK_BF16_MFMA_TFLOPS, 4), "peak": PEAK_BF16_MFMA_TFLOPS, "passes": passes,
+              "flop_per_pass": flops,
+              "workload": "Deformable_Generator forward + backward, 256x256, 18 kpts, batch 32, bf16 data path "
+                          "(bf16 operands and storage, fp32 accumulate / statistics / master weights), warp_skip=mask, "
+                          "random dropout; target >= 0.5 (<= 10.6 ms)"}
+        od = dict(vars(o), lazy_losses=True)
+        for _ in range(3):
+            iteration(model, batches, od)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            iteration(model, batches, od)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        b32 = {"value": round(N / dt, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+               "workload": "dis_update + gen_update, 256x256, 18 kpts, batch 32, bf16 data path, L1 loss, 1 GPU"}
+        del model, eng, batches
+        torch.cuda.empty_cache()
+        return ns, b32
+    finally:
+        E.PRECISION = prev
 
 
 PREC_TEXT = {"f32": "fp32", "bf16x3": "fp32 storage, bf16x3 split MFMA operands", "bf16": "fp32 storage, bf16 MFMA operands",
@@ -183,6 +301,17 @@ HBM_MODELS = {
 }
 
 
+def _small_cin_flops(a):
+    ho = (_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1
+    wo = (_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1
+    return 2.0 * _ival(a[2]) * ho * wo * 64 * sum(a[0][i].C for i in range(_ival(a[1]))) * _ival(a[5]) ** 2
+
+
+# entry points of this table that are NOT memory-bound in fp32: the first layers contract K = taps x Cin (189 ... 672) on the
+# fp32 matrix pipe (52 - 170 FLOP per byte); their line also carries TFLOP/s against the fp32 MFMA peak
+MFMA_FLOPS = {"pg_small_cin_conv": _small_cin_flops, "pg_small_cin_wgrad": _small_cin_flops}
+
+
 class HbmProfiler:
     """HIP events (on the launch stream) around every call of a memory-bound entry point during ONE un-timed iteration."""
 
@@ -202,22 +331,40 @@ class HbmProfiler:
         lib.pg_event_record(e0, L.stream())
         launch()
         lib.pg_event_record(e1, L.stream())
-        self.rec.append((name, model(args), e0, e1))
+        fl = MFMA_FLOPS.get(name)
+        self.rec.append((name, model(args), e0, e1, fl(args) if fl else 0.0))
 
-    def summary(self):
+    def summary(self, repeats=1):
+        """Per entry point: calls, summed time, algorithmic bytes.  repeats > 1: the records hold that many identical
+        iterations back to back; every call is credited with the MINIMUM over its repeats (round 3's single pass once
+        reported a 58 us kernel at 0.96 ms: the bracket had swallowed a first-use allocation)."""
         lib, ct = self.L.load(), self.ct
-        out = {}
-        for name, nbytes, e0, e1 in self.rec:
+        times = []
+        for name, nbytes, e0, e1, _fl in self.rec:
             ms = ct.c_float()
             lib.pg_event_elapsed_ms(e0, e1, ct.byref(ms))
             lib.pg_event_destroy(e0); lib.pg_event_destroy(e1)
-            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
-            d["calls"] += 1; d["ms"] += ms.value; d["bytes"] += nbytes
+            times.append(ms.value)
+        n = len(self.rec) // max(1, repeats)
+        aligned = repeats > 1 and n * repeats == len(self.rec) and all(
+            self.rec[i][:2] == self.rec[i + r * n][:2] for r in range(1, repeats) for i in range(n))
+        if not aligned:
+            n, repeats = len(self.rec), 1
+        out = {}
+        for i in range(n):
+            name, nbytes = self.rec[i][:2]
+            ms = min(times[i + r * n] for r in range(repeats))
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0.0})
+            d["calls"] += 1; d["ms"] += ms; d["bytes"] += nbytes; d["flops"] += self.rec[i][4]
         res = []
         for name, d in sorted(out.items(), key=lambda kv: -kv[1]["ms"]):
             tbs = d["bytes"] / max(d["ms"], 1e-9) * 1e-9
-            res.append({"kernel": name, "calls": d["calls"], "ms": round(d["ms"], 4), "algorithmic_MB": round(d["bytes"] / 1e6, 2),
-                        "TB_per_s": round(tbs, 3), "frac_of_hbm_peak": round(tbs / PEAK_HBM_TBS, 4)})
+            e = {"kernel": name, "calls": d["calls"], "ms": round(d["ms"], 4), "algorithmic_MB": round(d["bytes"] / 1e6, 2),
+                 "TB_per_s": round(tbs, 3), "frac_of_hbm_peak": round(tbs / PEAK_HBM_TBS, 4)}
+            if d["flops"] > 0:
+                tf = d["flops"] / max(d["ms"], 1e-9) * 1e-9
+                e.update(bound="mfma", tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+            res.append(e)
         return res
 
 
@@ -235,6 +382,65 @@ def pmc_traffic(kernel):
         except Exception:
             continue
     return None, None
+
+
+def fail(msg, code=2):
+    sys.stderr.write(msg + "\n")
+    sys.stderr.flush()
+    sys.exit(code)
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: start the N ranks ourselves (one process per
+    GPU, torch.distributed.run on 127.0.0.1) and exit with the launcher's status.  Fails loudly when fewer than N devices are
+    visible — a silent 1-GPU number labelled N would be worse than no number."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not args.dry_run and ndev < args.gpus:
+        fail("bench.py: --gpus %d but only %d GPU(s) are visible on this node; not starting (the path has no CPU fallback)"
+             % (args.gpus, ndev))
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(world, rank, local):
+    """Launcher / rendezvous check without a model: every rank contributes rank+1 to an all-reduce (gloo without GPUs, nccl =
+    RCCL with them, plus the C-ABI communicator the trainer uses) and rank 0 prints what came back."""
+    import torch.distributed as dist
+    on_gpu = torch.cuda.is_available() and torch.cuda.device_count() > local
+    if on_gpu:
+        torch.cuda.set_device(local)
+    t = torch.tensor([float(rank + 1)], device="cuda:%d" % local if on_gpu else "cpu")
+    if world > 1:
+        dist.all_reduce(t)
+    rccl = None
+    if on_gpu and world > 1:
+        import ctypes
+        from pose_transfer_amd.runtime import lib as _Lc
+        comm = dp.rccl_comm("cuda:%d" % local)
+        r_, w_ = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        _Lc.check(_Lc.load().pg_comm_ranks(comm, ctypes.byref(r_), ctypes.byref(w_)), "pg_comm_ranks")
+        rccl = int(w_.value)
+        dp.destroy_comms()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "sum_of_ranks_plus_1": float(t.item()),
+                          "expected": world * (world + 1) / 2.0, "backend": dist.get_backend() if world > 1 else None,
+                          "rccl_ranks": rccl}), flush=True)
+    ok = abs(float(t.item()) - world * (world + 1) / 2.0) < 1e-6
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    if not ok:
+        fail("bench.py --dry-run: the all-reduce returned %r" % float(t.item()), 3)
 
 
 def main():
@@ -258,7 +464,14 @@ def main():
                     help="replay the iteration from the library's launch tape (runtime/tape.py: ONE host call per iteration, the "
                          "launches stay on their streams; single GPU only) — removes the Python enqueue cost of the small-batch "
                          "configurations; an extra measurement, the default line is the eager loop")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle leg (and with it `parity`)")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed oracle iterations after its warm-up (SURVEY.md 8d: 3)")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip the bf16 batch-32 legs (`north_star`, `bf16_data_b32_img_s`; N=1 only)")
+    ap.add_argument("--north-star-passes", type=int, default=20)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check: the ranks rendezvous, all-reduce their rank numbers and rank 0 prints one JSON line; no "
+                         "model (works without a GPU: gloo)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--launch-table", default=None, help="write one line per contraction launch of the profiled iteration here")
     args = ap.parse_args()
@@ -266,14 +479,27 @@ def main():
     P = args.pose_dim
     E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[args.precision]
 
+    maybe_spawn(args)                 # --gpus N without a launcher: re-executes under torch.distributed.run, never returns
     world = dp.init_from_env()
     rank = dp.rank()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        fail("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); start it as `python bench.py --gpus %d` or "
+             "`python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d`"
+             % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(world, rank, local)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        fail("bench.py: rank %d needs GPU %d but %d GPU(s) are visible (no CPU fallback exists)"
+             % (rank, local, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     device = "cuda:%d" % local
     torch.cuda.set_device(device)
 
     opt = make_opt(args)
+    # N=1: the pinned first iteration for the `parity` field (its own model instance; the oracle repeats it in cpu_baseline)
+    pin = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        pin = parity_device_iteration(args, device, rank)
     model = DeformablePose_GAN(opt, device=device, init_seed=0)
     od = dict(vars(opt), lazy_losses=True)
     dev = lambda arrs: [torch.from_numpy(a).to(device) for a in arrs]
@@ -305,12 +531,28 @@ def main():
     elapsed = time.perf_counter() - t0
     if graphed is not None:
         graphed.close()
+    per_rank = [args.batch * args.steps / elapsed]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(allt, tt)
+        per_rank = [args.batch * args.steps / float(x.item()) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
     global_batch = args.batch * world
     ips = global_batch * args.steps / elapsed
+    # what the data-parallel transport itself reports (RCCL communicator behind the C ABI: ncclCommCount)
+    rccl_ranks, transport = 1, "single process (no collective)"
+    red = getattr(model, "g_reducer", None)
+    if red is not None:
+        if red.comm is not None:
+            import ctypes
+            from pose_transfer_amd.runtime import lib as _Lc
+            r_, w_ = ctypes.c_int32(-1), ctypes.c_int32(-1)
+            _Lc.check(_Lc.load().pg_comm_ranks(red.comm, ctypes.byref(r_), ctypes.byref(w_)), "pg_comm_ranks")
+            rccl_ranks, transport = int(w_.value), "RCCL ncclAllReduce behind the C ABI (pg_comm_*), %s buckets" % red.grad_dtype
+        else:
+            rccl_ranks, transport = torch.distributed.get_world_size(), "torch.distributed all_reduce (%s), %s buckets" % (
+                torch.distributed.get_backend(), red.grad_dtype)
 
     # ---- roofline leg: one extra profiled iteration, HIP events around every contraction launch
     roof = None
@@ -355,15 +597,21 @@ def main():
         side, E.SIDE_STREAM = E.SIDE_STREAM, False
         _L.CALL_HOOK = prof.hook
         try:
-            iteration(model, batches, od)
+            for _ in range(3):
+                iteration(model, batches, od)
             torch.cuda.synchronize()
         finally:
             _L.CALL_HOOK = None
             E.SIDE_STREAM = side
-        hbm = prof.summary()
-    cpu = None
+        hbm = prof.summary(repeats=3)
+    ns = b32 = None
+    if rank == 0 and world == 1 and not args.no_north_star:
+        del model, batches, step, graphed
+        torch.cuda.empty_cache()
+        ns, b32 = north_star_legs(device, args.north_star_passes, args.north_star_passes)
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+        cpu, parity = cpu_baseline(args, pin)
 
     if rank == 0:
         sf, fg, fd = step_flops(args.size, P)
@@ -382,7 +630,9 @@ def main():
                        **({"launch_tape": True} if args.tape else {})},
             "step_tflops": round(sf * ips / 1e12, 2),
             "step_frac_of_f32_mfma_peak": round(sf * ips / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,
+            "roofline": roof, "parity": parity, "north_star": ns, "bf16_data_b32_img_s": b32,
+            "rccl_ranks": rccl_ranks, "dp_transport": transport, "per_rank_img_s": [round(v, 3) for v in per_rank],
+            "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -365,11 +365,14 @@ int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_bf16, int32_
  *   pg_comm_unique_id : rank 0 draws the 128-byte rendezvous token (ncclGetUniqueId); the host broadcasts it out of band
  *   pg_comm_init      : every rank joins (ncclCommInitRank) -> opaque handle
  *   pg_comm_allreduce_bucket : in-place SUM over ranks of `count` elements, dtype 0 = fp32 / 1 = bf16, enqueued on `stream`
- *   pg_pack_bf16      : fp32 -> bf16 (RNE) staging of a finished gradient range before a bf16 bucket is reduced          */
+ *   pg_pack_bf16      : fp32 -> bf16 (RNE) staging of a finished gradient range before a bf16 bucket is reduced
+ *   pg_comm_ranks     : what RCCL itself reports for the communicator (ncclCommUserRank / ncclCommCount) — bench.py prints
+ *                       it as `rccl_ranks` so that a scaling line proves how many ranks the collective really spanned      */
 int pg_comm_unique_id(void* out128);
 int pg_comm_init(const void* unique_id128, int32_t rank, int32_t world, void** comm);
 int pg_comm_allreduce_bucket(void* comm, void* buf, int64_t count, int32_t dtype, void* stream);
 int pg_comm_destroy(void* comm);
+int pg_comm_ranks(void* comm, int32_t* rank, int32_t* world);
 int pg_pack_bf16(const float* src, void* dst, int64_t n, void* stream);
 
 /* channel-dropout multipliers in {0, 1/(1-p)} from a stateless counter hash (nn.Dropout2d, networks.py:161). */

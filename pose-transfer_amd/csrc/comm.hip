@@ -21,11 +21,12 @@ typedef int (*fn_init_rank)(nccl_comm_t*, int, nccl_uid_t, int);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_destroy)(nccl_comm_t);
 typedef const char* (*fn_err)(int);
+typedef int (*fn_count)(nccl_comm_t, int*);
 
 struct Rccl {
   void* h = nullptr;
   fn_get_uid get_uid = nullptr; fn_init_rank init_rank = nullptr; fn_all_reduce all_reduce = nullptr;
-  fn_destroy destroy = nullptr; fn_err err = nullptr;
+  fn_destroy destroy = nullptr; fn_err err = nullptr; fn_count count = nullptr, user_rank = nullptr;
 };
 
 static Rccl& rccl() { static Rccl r; return r; }
@@ -45,6 +46,8 @@ static int load_rccl() {
   r.all_reduce = (fn_all_reduce)dlsym(r.h, "ncclAllReduce");
   r.destroy = (fn_destroy)dlsym(r.h, "ncclCommDestroy");
   r.err = (fn_err)dlsym(r.h, "ncclGetErrorString");
+  r.count = (fn_count)dlsym(r.h, "ncclCommCount");
+  r.user_rank = (fn_count)dlsym(r.h, "ncclCommUserRank");
   if (!r.get_uid || !r.init_rank || !r.all_reduce || !r.destroy) { r.h = nullptr; PG_FAIL(4, "pg_comm: librccl lacks an entry point"); }
   return 0;
 }
@@ -105,6 +108,18 @@ extern "C" int pg_comm_destroy(void* comm) {
   Comm* c = reinterpret_cast<Comm*>(comm);
   if (c->c && rccl().destroy) rccl().destroy(c->c);
   delete c;
+  return 0;
+}
+
+// rank / size as RCCL reports them for this communicator (not the values pg_comm_init was called with)
+extern "C" int pg_comm_ranks(void* comm, int32_t* rank, int32_t* world) {
+  PG_REQUIRE(comm && rank && world, "pg_comm_ranks: bad arguments");
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  PG_REQUIRE(rccl().count && rccl().user_rank, "pg_comm_ranks: librccl lacks ncclCommCount / ncclCommUserRank");
+  int r = -1, w = -1;
+  PG_NCCL(rccl().count(c->c, &w), "ncclCommCount");
+  PG_NCCL(rccl().user_rank(c->c, &r), "ncclCommUserRank");
+  *rank = r; *world = w;
   return 0;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <tuple>
 #include <type_traits>
@@ -38,6 +39,31 @@ int& last_info();  // thread-local: tile config / loader modes / split-K of the 
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Ablation / debugging switches of the host-side launch code, read from the environment ONCE per process (round 3 called
+// getenv ~14 times per 256-row launch).  Every switch selects another CORRECT code path; the timing experiments that produce
+// wrong results exist only in builds with -DPG_TIMING_EXPERIMENTS (tools/conv_timeline.py).  Two switches stay dynamic because
+// the test-suite flips them inside one process: PG_FORCE_BF16_BIG (igemm_conv.hip) and PG_NO_OUT_DGRAD_MFMA (out_conv_dgrad.hip).
+struct Env {
+  bool no_vec_epilogue, splitk_debug, no_splitk_ws, no_dma, no_xcd_swizzle, conv_mask_generic, no_bf16_big, no_bf16_big64;
+  bool wg_generic, bias_grad_x4, nn_loss_v1;
+  unsigned debug_bits;      // PG_TIMING_EXPERIMENTS builds only: bits of ConvK::xcd_swizzle (igemm_bf16.hip)
+  Env() {
+    auto on = [](const char* n) { return getenv(n) != nullptr; };
+    no_vec_epilogue = on("PG_NO_VEC_EPILOGUE"); splitk_debug = on("PG_SPLITK_DEBUG"); no_splitk_ws = on("PG_NO_SPLITK_WS");
+    no_dma = on("PG_NO_DMA"); no_xcd_swizzle = on("PG_NO_XCD_SWIZZLE"); conv_mask_generic = on("PG_CONV_MASK_GENERIC");
+    no_bf16_big = on("PG_NO_BF16_BIG"); no_bf16_big64 = on("PG_NO_BF16_BIG64");
+    wg_generic = on("PG_WG_GENERIC"); bias_grad_x4 = on("PG_BIAS_GRAD_X4"); nn_loss_v1 = on("PG_NN_LOSS_V1");
+    debug_bits = 0;
+#ifdef PG_TIMING_EXPERIMENTS
+    const char* names[] = {"PG_DEBUG_OPERAND_A", "PG_DEBUG_OPERAND_B", "PG_DEBUG_ONE_KTILE", "PG_DEBUG_CONV_TIMELINE",
+                           "PG_DEBUG_EPI_NOFWD", "PG_DEBUG_EPI_NOSTORE", "PG_DEBUG_EPI_NOACC", "PG_DEBUG_NO_KBARRIER",
+                           "PG_DEBUG_NO_KDMA", "PG_DEBUG_A_EVERY_4TH"};
+    for (int i = 0; i < 10; ++i) if (on(names[i])) debug_bits |= 2u << i;
+#endif
+  }
+};
+inline const Env& env() { static const Env e; return e; }
 
 // ---- launch tape (round 3, api.hip: pg_tape_*).  Every kernel launch / memset / stream-ordering call of the library goes through
 // these macros: it is issued as usual and, while the calling thread records, also kept as a closure (kernel, geometry, stream

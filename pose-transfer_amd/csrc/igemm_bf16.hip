@@ -22,6 +22,14 @@
 
 namespace pg {
 
+// Timing experiments of round 3 (per-workgroup phase stamps; K loops without barrier / DMA / every 4th A tile — "results are
+// wrong, times are not"): compiled in only with -DPG_TIMING_EXPERIMENTS (tools/conv_timeline.py builds its own library).
+#ifdef PG_TIMING_EXPERIMENTS
+#define PG_DBG(p, bit) (((p).xcd_swizzle & (bit)) != 0)
+#else
+#define PG_DBG(p, bit) false
+#endif
+
 template <int OFF>
 __device__ __forceinline__ void lds_rd128(f32x4& v, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const bool tl_on = (p.xcd_swizzle & 16) != 0;
+  const bool tl_on = PG_DBG(p, 16);
   const int tl_id = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
   auto stamp = [&](int slot) {
     if (tl_on && tid == 0 && tl_id < TL_WGS) {
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   const int ktot = ntap * cpt;
   const int kper = (ktot + p.ksplit - 1) / p.ksplit;
   const int kt0 = split * kper;
-  const int kt1 = (p.xcd_swizzle & 8) ? min(ktot, kt0 + 1) : min(ktot, kt0 + kper);      // bit 3: PG_DEBUG_ONE_KTILE (fixed-cost experiment)
+  const int kt1 = PG_DBG(p, 8) ? min(ktot, kt0 + 1) : min(ktot, kt0 + kper);      // bit 3: PG_DEBUG_ONE_KTILE (fixed-cost experiment)
   if (kt0 >= kt1) return;
 
   f32x16 acc[TM][TN];
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       const bool ok = (rn[i] >= 0) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
       const long off = ((long)((rn[i] * p.Hi + iy) * p.Wi + ix) * sC + cl) * 2;
       pa[i] = ok ? sp + off : zero_pg + (tid & 7) * 16;
-      if (p.xcd_swizzle & 2) pa[i] = sp + (long)cl * 2;        // PG_DEBUG_OPERAND_A: every row reads pixel 0 (delivery experiment)
+      if (PG_DBG(p, 2)) pa[i] = sp + (long)cl * 2;        // PG_DEBUG_OPERAND_A: every row reads pixel 0 (delivery experiment)
     }
     const int base = (tp >> 16) * p.wCout;
 #pragma unroll
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       const int n = nb0 + (tid >> 3) + 64 * i;
       const long off = ((long)(base + p.n_off + n) * p.wCin + cc + chunk * 8) * 2;
       pb[i] = (n < p.n_cnt) ? wp + off : zero_pg + (tid & 7) * 16;
-      if (p.xcd_swizzle & 4) pb[i] = wp + ((long)(base + p.n_off) * p.wCin + cc + chunk * 8) * 2;      // PG_DEBUG_OPERAND_B
+      if (PG_DBG(p, 4)) pb[i] = wp + ((long)(base + p.n_off) * p.wCin + cc + chunk * 8) * 2;      // PG_DEBUG_OPERAND_B
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): no scalar (kernel-argument) load stays in flight past here
   };
@@ -520,11 +528,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    if (!(p.xcd_swizzle & 256)) __builtin_amdgcn_s_barrier();      // bit 8: PG_DEBUG_NO_KBARRIER (timing experiment, wrong results)
+    if (!PG_DBG(p, 256)) __builtin_amdgcn_s_barrier();      // bit 8: PG_DEBUG_NO_KBARRIER (timing experiment, wrong results)
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + NST < kt1 && !(p.xcd_swizzle & 512)) {        // tile kt + NST into the stage this tile just released (bit 9: PG_DEBUG_NO_KDMA)
+    if (kt + NST < kt1 && !PG_DBG(p, 512)) {        // tile kt + NST into the stage this tile just released (bit 9: PG_DEBUG_NO_KDMA)
       if constexpr (PG_BIG_SPLIT_DMA && NST == 2) {
-        if (!((p.xcd_swizzle & 1024) && (kt & 3))) issue_a(stage);      // bit 10: PG_DEBUG_A_EVERY_4TH (timing experiment: A rows on one K tile in four)
+        if (!(PG_DBG(p, 1024) && (kt & 3))) issue_a(stage);      // bit 10: PG_DEBUG_A_EVERY_4TH (timing experiment: A rows on one K tile in four)
         pend = true;
       }
       else { issue(stage); advance(); }
@@ -633,9 +641,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     ld.C = C; ld.c = ngs - cst;
     ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
     ld.accum = dacc != 0;
-    if (p.xcd_swizzle & 32) { ld.has_fwd = false; ld.fwdp = gradp; }      // PG_DEBUG_EPI_NOFWD / _NOSTORE / _NOACC: epilogue experiments
-    if (p.xcd_swizzle & 64) cval = false;
-    if (p.xcd_swizzle & 128) ld.accum = false;
+    if (PG_DBG(p, 32)) { ld.has_fwd = false; ld.fwdp = gradp; }      // PG_DEBUG_EPI_NOFWD / _NOSTORE / _NOACC: epilogue experiments
+    if (PG_DBG(p, 64)) cval = false;
+    if (PG_DBG(p, 128)) ld.accum = false;
     stamp(8);
     if (p.dst_io == 1) {          // host: every destination and forward tensor in bf16 STORAGE, >= 32 pixels per sample
       const bool plain = __builtin_amdgcn_ballot_w64(ld.has_mask || ld.accum) == 0;       // wave-uniform

@@ -1544,7 +1544,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     k.dst_uniform = 1;
     for (int j = 0; j < d->ndst; ++j)
       if (d->dst[j].C % 32 != 0 || (double)d->N * d->Ho * d->Wo * d->dst[j].C >= 4294967296.0) k.dst_uniform = 0;
-    k.vec_dst = (k.dst_uniform && getenv("PG_NO_VEC_EPILOGUE") == nullptr) ? 1 : 0;
+    k.vec_dst = (k.dst_uniform && !env().no_vec_epilogue) ? 1 : 0;
     for (int j = 0; j < d->ndst; ++j)
       if (((size_t)d->dst[j].grad & 15) != 0 || ((size_t)d->dst[j].fwd & 15) != 0 || ((size_t)d->dst[j].mask & 15) != 0 ||
           ((size_t)d->dst[j].aff & 7) != 0)
@@ -1613,7 +1613,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
       if (c > 1) t += 2.0 * c * out_bytes / (bw_tbs * 1e6) + t_launch;
       if (t < best * 0.98) { best = t; ks = c; }             // a further split must buy 2 %
     }
-    if (getenv("PG_SPLITK_DEBUG")) fprintf(stderr, "[splitk] M=%d N=%d ktot=%d blocks=%ld cfg=%d -> ks=%d (T=%.0f us)\n", k.M, k.n_cnt, ktot_min, blocks, cfg, ks, best);
+    if (env().splitk_debug) fprintf(stderr, "[splitk] M=%d N=%d ktot=%d blocks=%ld cfg=%d -> ks=%d (T=%.0f us)\n", k.M, k.n_cnt, ktot_min, blocks, cfg, ks, best);
   }
   if (d->out_act != PG_OUT_NONE) ks = 1;
   if (d->epilogue == 0) {   // split-K accumulates atomically into a zeroed, dense NHWC output only
@@ -1646,7 +1646,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   const double out_elems = (double)d->N * d->Ho * d->Wo * k.n_cnt;
   if (ks > 1 && d->workspace != nullptr && tb == nullptr && k.n_cnt % 4 == 0 && splits_nonempty(ks) &&
       ((size_t)d->workspace & 15) == 0 && out_elems < 2147483648.0 && (double)ks * out_elems * 4.0 <= (double)d->workspace_bytes &&
-      getenv("PG_NO_SPLITK_WS") == nullptr) {
+      !env().no_splitk_ws) {
     use_part = true;
     if (d->epilogue == 0) {
       if (((size_t)d->out & 15) != 0 || (d->bias && ((size_t)d->bias & 15) != 0)) use_part = false;
@@ -1661,7 +1661,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     const bool dense0 = d->epilogue == 0 && d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
                         d->oN == (long)d->Ho * d->Wo * k.n_cnt && ((size_t)d->out & 15) == 0 &&
                         (d->bias == nullptr || ((size_t)d->bias & 15) == 0) && tb == nullptr;
-    k.vec_out = (k.n_cnt % 4 == 0 && out_elems < 2147483648.0 && (use_part || dense0) && getenv("PG_NO_VEC_EPILOGUE") == nullptr) ? 1 : 0;
+    k.vec_out = (k.n_cnt % 4 == 0 && out_elems < 2147483648.0 && (use_part || dense0) && !env().no_vec_epilogue) ? 1 : 0;
   }
   k.part = use_part ? reinterpret_cast<float*>(d->workspace) : nullptr;
   k.part_stride = (long)out_elems;
@@ -1701,40 +1701,31 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   }
   // LDS-DMA loaders: the A operand must need no prologue (one source, no deferred affine / mask / activation)
   const bool dma = amode == A_VEC && bmode == B_NN && d->nsrc == 1 && d->src[0].aff == nullptr && d->src[0].mask == nullptr &&
-                   d->act == PG_ACT_NONE && d->precision == PG_PREC_F32 && cfg != 3 && getenv("PG_NO_DMA") == nullptr;
+                   d->act == PG_ACT_NONE && d->precision == PG_PREC_F32 && cfg != 3 && !env().no_dma;
   if (tb) {
     PG_REQUIRE(tb->gtaps >= 1 && tb->gtaps <= MAXTAP && k.nphase == 1 && d->precision == PG_PREC_BF16_DATA && d->epilogue == 0,
                "batched-tap GEMM: bf16 data path, one phase, plain epilogue");
     k.gtaps = tb->gtaps;
     for (int t = 0; t < tb->gtaps; ++t) { k.a_off[t] = tb->a_off[t]; k.w_off[t] = tb->w_off[t]; k.o_off[t] = tb->o_off[t]; }
   }
-  k.xcd_swizzle = (bf16_data && mt % 8 == 0 && nt > 1 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
-  bool nomask = getenv("PG_CONV_MASK_GENERIC") == nullptr;
+  k.xcd_swizzle = (bf16_data && mt % 8 == 0 && nt > 1 && !env().no_xcd_swizzle) ? 1 : 0;
+  bool nomask = !env().conv_mask_generic;
   for (int j = 0; j < d->nsrc; ++j) nomask = nomask && d->src[j].mask == nullptr;
   dim3 grid(mt, nt, (tb ? tb->gtaps : k.nphase) * ks);
   // 256-row bf16 kernel (igemm_bf16.hip) for launches with enough 256 x BN tiles to fill the chip (one workgroup per CU)
   if (bf16_data && tb == nullptr && ks == 1 && amode == A_VEC && bmode == B_NT && d->out_act == PG_OUT_NONE &&
-      ((d->epilogue == 0 && k.vec_out) || (d->epilogue == 1 && k.vec_dst)) && getenv("PG_NO_BF16_BIG") == nullptr) {
+      ((d->epilogue == 0 && k.vec_out) || (d->epilogue == 1 && k.vec_dst)) && !env().no_bf16_big) {
     // (n_cnt == 32: the output convolution's 27 -> 32 tap columns on the 512 x 64 tile, half of its columns masked: half the fp32
     //  bytes of the 64-column padding; plain epilogue without statistics only)
     const bool n32 = k.n_cnt == 32 && d->epilogue == 0 && d->stats == nullptr && k.nphase == 1;
-    const int bn = (k.n_cnt % 256 == 0) ? 256 : (k.n_cnt % 128 == 0 ? 128 : ((k.n_cnt == 64 || n32) && getenv("PG_NO_BF16_BIG64") == nullptr ? 64 : 0));
+    const int bn = (k.n_cnt % 256 == 0) ? 256 : (k.n_cnt % 128 == 0 ? 128 : ((k.n_cnt == 64 || n32) && !env().no_bf16_big64 ? 64 : 0));
     if (bn != 0) {
       const int mtb = cdiv(k.M, bn == 64 ? 512 : 256), ntb = cdiv(k.n_cnt, bn);
       const long wgs = (long)mtb * ntb * k.nphase;
       static const long big_min = getenv("PG_BF16_BIG_MIN") ? atol(getenv("PG_BF16_BIG_MIN")) : 192;   // swept (tools/sweep_bf16_big_min.sh): 448 -> 523 / 814, 192 -> 529 / 832 img/s (256^2 batch 4 / 224^2 batch 8)
       if (wgs >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr) {
-        k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
-        if (getenv("PG_DEBUG_OPERAND_A")) k.xcd_swizzle |= 2;
-        if (getenv("PG_DEBUG_OPERAND_B")) k.xcd_swizzle |= 4;
-        if (getenv("PG_DEBUG_ONE_KTILE")) k.xcd_swizzle |= 8;
-        if (getenv("PG_DEBUG_CONV_TIMELINE")) k.xcd_swizzle |= 16;
-        if (getenv("PG_DEBUG_EPI_NOFWD")) k.xcd_swizzle |= 32;
-        if (getenv("PG_DEBUG_EPI_NOSTORE")) k.xcd_swizzle |= 64;
-        if (getenv("PG_DEBUG_EPI_NOACC")) k.xcd_swizzle |= 128;
-        if (getenv("PG_DEBUG_NO_KBARRIER")) k.xcd_swizzle |= 256;
-        if (getenv("PG_DEBUG_NO_KDMA")) k.xcd_swizzle |= 512;
-        if (getenv("PG_DEBUG_A_EVERY_4TH")) k.xcd_swizzle |= 1024;
+        k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && !env().no_xcd_swizzle) ? 1 : 0;
+        k.xcd_swizzle |= (int)env().debug_bits;       // zero unless built with -DPG_TIMING_EXPERIMENTS
         if (k.dst_io == 1 && k.Gy * k.Gx < 32) k.dst_io = 2;      // the pipelined bf16 scatter assumes <= 2 samples per 32 rows
         launch_conv_bf16_big(k, bn, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
@@ -1743,6 +1734,10 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
       }
     }
   }
+  // the 128 x 32 tile has no bf16-data instantiation: its launcher would fall through to the fp32 kernel and read the bf16
+  // operands as floats.  32-column launches on this path must have been taken by the 512 x 64 kernel above.
+  PG_REQUIRE(!(bf16_data && cfg == 3), "pg_conv: bf16 data path: a launch with %d output columns was not eligible for the 512x64 "
+             "kernel (plain epilogue, no statistics, >= PG_BF16_BIG_MIN workgroups) and has no other bf16 kernel", k.n_cnt);
   switch (cfg) {
     case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
     case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;

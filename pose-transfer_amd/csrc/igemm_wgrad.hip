@@ -654,7 +654,7 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
   for (int j = 0; j < d->nsrc; ++j) any_mask |= d->src[j].mask != nullptr;
   // (workgroups with only a few K tiles keep the generic kernel: the table fill + barrier in front of the pipeline
   //  prologue costs them ~2 us each — measured +10-16 us on launches with 16 tiles per workgroup, -40 us with 32)
-  const bool spec = d->N <= WG_AFF_TAB && !xs && !ys && (d->stride == 1 || d->stride == 2) && nkt / ks >= 8 && getenv("PG_WG_GENERIC") == nullptr;
+  const bool spec = d->N <= WG_AFF_TAB && !xs && !ys && (d->stride == 1 || d->stride == 2) && nkt / ks >= 8 && !env().wg_generic;
 #define PG_WG_SPEC(BM, BN)                                                                                             \
   do {                                                                                                                 \
     if (d->x_is_large) {                                                                                               \
@@ -847,7 +847,7 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
 extern "C" int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, float* db, void* stream) {
   PG_REQUIRE(dY_bf16 && db && npix > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ((size_t)dY_bf16 & 7) == 0,
              "pg_bias_grad_bf16: dense NHWC bf16 tensor with C %% 4 == 0 and 256 %% (C / 4) == 0 required");
-  if (C % 8 == 0 && 256 % (C / 8) == 0 && ((size_t)dY_bf16 & 15) == 0 && getenv("PG_BIAS_GRAD_X4") == nullptr) {
+  if (C % 8 == 0 && 256 % (C / 8) == 0 && ((size_t)dY_bf16 & 15) == 0 && !env().bias_grad_x4) {
     const int ppb8 = 256 / (C / 8);
     long blocks8 = (npix + (long)ppb8 * 16 - 1) / ((long)ppb8 * 16);
     static const long bcap8 = getenv("PG_BIAS_GRAD_WGS") ? atol(getenv("PG_BIAS_GRAD_WGS")) : 384;

@@ -438,7 +438,7 @@ extern "C" int pg_nn_loss(const float* P, const float* G, int32_t N, int32_t H, 
     PG_KLAUNCH(nn_loss_kernel<LPP>, dim3((int)blocks), dim3(256), 0, st, P, G, N, H, W, area,  \
                        scale, relu_mask, loss, dP);                                                    \
   }
-  if (C == 64 && (area == 3 || area == 5 || area == 7) && getenv("PG_NN_LOSS_V1") == nullptr) {
+  if (C == 64 && (area == 3 || area == 5 || area == 7) && !env().nn_loss_v1) {
     int rc = area == 3 ? launch_nn_tile64<3>(P, G, N, H, W, scale, relu_mask, loss, dP, st)
            : area == 5 ? launch_nn_tile64<5>(P, G, N, H, W, scale, relu_mask, loss, dP, st)
                        : launch_nn_tile64<7>(P, G, N, H, W, scale, relu_mask, loss, dP, st);

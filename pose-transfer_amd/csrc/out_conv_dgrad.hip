@@ -569,6 +569,9 @@ extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const f
     PG_LAUNCH_OK("pg_out_conv_bwd_direct (fused MFMA pass)");
     PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, 16), dim3(256), 0, st, workspace, (int)fb, c, dW);
     PG_LAUNCH_OK("pg_out_conv_bwd_direct (reduce)");
+    // the fused pass wrote dW on `stream`; callers (and the data-parallel reducer: runtime/dp.py orders a gradient range
+    // against the weight-gradient stream only) treat dW as a product of `wg_stream` — make that true
+    if (wg_stream != nullptr && wst != st) return pg_stream_wait(wg_stream, stream);
     return 0;
   }
   if (g_is_dpre) PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, k);

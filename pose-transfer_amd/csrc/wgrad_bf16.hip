@@ -642,7 +642,7 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
       if (ks4 < 1) ks4 = 1;
       while (ks4 > 1 && (long)(ks4 - 1) * ((ktot + ks4 - 1) / ks4) >= ktot) --ks4;
       q.ksplit = ks4; q.atomic = ks4 > 1 ? 1 : 0;
-      q.xcd_remap = (((long)mt4 * nt4 * ks4) % 8 == 0 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
+      q.xcd_remap = (((long)mt4 * nt4 * ks4) % 8 == 0 && !env().no_xcd_swizzle) ? 1 : 0;
       dim3 grid4(mt4, nt4, 4 * ks4);
 #define PGW4_LAUNCH(M_, N_)                                                                                              \
   do {                                                                                                                   \
@@ -693,7 +693,7 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   if (ks >= 8 && ks % 8 != 0 && ktot / ((ks + 7) / 8 * 8) >= 8) ks = (ks + 7) / 8 * 8;       // whole XCD groups of taps
   while (ks > 1 && (long)(ks - 1) * ((ktot + ks - 1) / ks) >= ktot) --ks;
   k.ksplit = ks; k.atomic = ks > 1 ? 1 : 0;
-  k.xcd_remap = (((long)mt * nt * ks) % 8 == 0 && getenv("PG_NO_XCD_SWIZZLE") == nullptr) ? 1 : 0;
+  k.xcd_remap = (((long)mt * nt * ks) % 8 == 0 && !env().no_xcd_swizzle) ? 1 : 0;
   dim3 grid(mt, nt, 16 * ks);
 #define PGW_LAUNCH(M_, N_)                                                                                   \
   do {                                                                                                       \

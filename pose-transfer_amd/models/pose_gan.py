@@ -124,10 +124,13 @@ class DeformablePose_GAN(nn.Module):
 
     def _drop_setup(self, eng, drop_masks, stage, call):
         # (in a HIP-graph replay session the iteration number comes from the device counter, not from this string)
-        it = 0 if E.REPLAY_CTR is not None else self.iteration
+        replay = E.REPLAY_CTR is not None
+        it = 0 if replay else self.iteration
         # repeated calls within ONE iteration (--training_ratio > 1: several dis_update per gen_update, main.py:78-88)
         # draw fresh masks, as the reference's Dropout2d does: the k-th repeat of a (call, stage) gets its own stream
-        if getattr(self, "_drop_it", None) != it:
+        if getattr(self, "_drop_it", None) != it or replay:
+            # (a replay session pins `it` to 0 and records exactly one dis_update + gen_update: no repeats, so the stream
+            # names of its warm-up iterations and of the recorded one are the same)
             self._drop_it, self._drop_n = it, {}
         k = self._drop_n.get((call, stage), 0)
         self._drop_n[(call, stage)] = k + 1

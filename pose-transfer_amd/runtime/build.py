@@ -8,14 +8,18 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
-OBJDIR = os.path.join(LIBDIR, "obj")
+# PG_TIMING_EXPERIMENTS=1: a SEPARATE library (libposegan_hip_timing.so, objects in obj_timing/) built with
+# -DPG_TIMING_EXPERIMENTS — the per-workgroup phase stamps and the "wrong results, right times" K-loop experiments of
+# csrc/igemm_bf16.hip exist only there (tools/conv_timeline.py); the production library carries none of them.
+TIMING = os.environ.get("PG_TIMING_EXPERIMENTS") == "1"
+OBJDIR = os.path.join(LIBDIR, "obj_timing" if TIMING else "obj")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
-LIB = os.environ.get("PG_LIB") or os.path.join(LIBDIR, "libposegan_hip.so")
+LIB = os.environ.get("PG_LIB") or os.path.join(LIBDIR, "libposegan_hip_timing.so" if TIMING else "libposegan_hip.so")
 SOURCES = ["api.hip", "comm.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "pose_geom.hip", "edge.hip", "small_cin_wgrad.hip", "out_conv_dgrad.hip", "igemm_conv.hip", "igemm_bf16.hip", "wgrad_bf16.hip", "stem_bf16.hip", "igemm_wgrad.hip"]
 # -pragma-unroll-threshold: the epilogue loops over a wave's MFMA tiles MUST be fully unrolled (a rolled loop indexes the
 # accumulator array at run time and the compiler moves it to scratch memory); the 4x2-tile bf16 kernel exceeds the default
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1000000",
-         "-I" + INCLUDE, "-I" + CSRC]
+         "-I" + INCLUDE, "-I" + CSRC] + (["-DPG_TIMING_EXPERIMENTS"] if TIMING else [])
 
 
 def _hipcc():
@@ -63,7 +67,8 @@ def build_lib(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
-    build_example()
+    if not TIMING:
+        build_example()
     return LIB
 
 

@@ -118,8 +118,18 @@ class GradReducer:
         assert self.grad_dtype in ("f32", "bf16")
         self.bf16 = self.grad_dtype == "bf16"
         self.packed = torch.empty(arena.total, dtype=torch.bfloat16, device=arena.grads.device) if self.bf16 else None
+        # debugging hooks (test aids, see the module docstring): read ONCE here and announced when active
         self.debug_peer = os.environ.get("PG_DP_DEBUG_PEER") == "1" and self.on_device and dist_world() == 1
-        self.divisor = max(1, dist_world()) * (2 if self.debug_peer else 1)      # what the optimiser divides the sums by
+        self.debug_no_wait = os.environ.get("PG_DP_DEBUG_NO_WAIT") == "1"
+        self.wait_main = os.environ.get("PG_DP_WAIT_MAIN") == "1"
+        if self.debug_peer or self.debug_no_wait:
+            import sys
+            print("[pose_transfer_amd.dp] DEBUG hooks active: %s — gradients are NOT those of a normal run"
+                  % ", ".join(n for n, v in (("PG_DP_DEBUG_PEER", self.debug_peer), ("PG_DP_DEBUG_NO_WAIT", self.debug_no_wait)) if v),
+                  file=sys.stderr)
+        # what the optimiser divides the sums by: the size of the group this reducer spans (not the global world size)
+        gsize = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.divisor = max(1, gsize) * (2 if self.debug_peer else 1)
         self.comm_stream = torch.cuda.Stream(device=arena.grads.device) if self.on_device else None
         self.comm = None
         if self.backend == "rccl" and (world > 1 or os.environ.get("PG_FORCE_REDUCER") == "1"):
@@ -175,13 +185,13 @@ class GradReducer:
         of the iteration on one GPU: 170 -> 163 img/s)  The last launch (finish) and runs without a
         side stream wait for the main stream as well; PG_DP_WAIT_MAIN=1 restores the conservative form everywhere."""
         from . import engine as E
-        if os.environ.get("PG_DP_DEBUG_NO_WAIT") == "1":      # negative control of the ordering stress test: no producer events
+        if self.debug_no_wait:      # negative control of the ordering stress test: no producer events
             return
         dev = self.arena.grads.device
         cs = self.comm_stream
         side = E._SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
         side_on = E.SIDE_STREAM and side is not None
-        if final or not side_on or os.environ.get("PG_DP_WAIT_MAIN") == "1":
+        if final or not side_on or self.wait_main:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             cs.wait_event(ev)

@@ -442,12 +442,16 @@ def _bf16_sources(srcs, N, Hi, Wi, act, dev):
 
 
 def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, transposed=False, scalar_in=False,
-          out=None, out_strides=None, bias=None, out_act=L.OUT_NONE, dsts=None, n_off=0, n_cnt=0, ksplit=0, stats=None):
+          out=None, out_strides=None, bias=None, out_act=L.OUT_NONE, dsts=None, n_off=0, n_cnt=0, ksplit=0, stats=None,
+          allow_n32=False):
     prec = PRECISION
     if prec == 3:
         ncols = n_cnt if n_cnt > 0 else (wCin if transposed else wCout)
-        ok = (not scalar_in and n_off == 0 and n_cnt == 0 and ncols >= 32 and all(s.C % 64 == 0 for s in srcs)
-              and isinstance(W, torch.Tensor))
+        # 32 output columns have ONE bf16 kernel: the 512 x 64 tile with half its columns masked (plain epilogue, a launch large
+        # enough to be taken by it) — only the output convolution's tap launch asks for it (allow_n32); pg_conv refuses loudly
+        # if such a launch falls through to the 128 x 32 tile, which has no bf16 instantiation
+        ok = (not scalar_in and n_off == 0 and n_cnt == 0 and (ncols > 32 or (ncols == 32 and allow_n32))
+              and all(s.C % 64 == 0 for s in srcs) and isinstance(W, torch.Tensor))
         if ok:      # bf16 tensors in, K-contiguous bf16 weights (per-tap transposed copy for the data-gradient)
             srcs = _bf16_sources(srcs, N, Hi, Wi, act, W.device)
             W = _bf16_weight(W, K * K, wCout, wCin, transposed)
@@ -591,6 +595,10 @@ def dev_copy(dst, src):
             and dst.device == src.device):
         L.call("pg_copy", L.ptr(dst), L.ptr(src), dst.numel() * dst.element_size(), L.stream())
     else:
+        if REPLAY_CTR is not None and dst.is_cuda:
+            # a replay session (launch tape / HIP graph) records library enqueues only: a torch copy would silently drop out
+            raise RuntimeError("dev_copy: dtype / layout mismatch (%s %s -> %s %s) needs a torch copy, which a replay session cannot "
+                               "record" % (src.dtype, tuple(src.shape), dst.dtype, tuple(dst.shape)))
         dst.copy_(src.reshape(dst.shape) if src.numel() == dst.numel() else src)
 
 
@@ -943,7 +951,14 @@ class GeneratorEngine:
         # bf16 STORAGE (round 3): raw activations and their gradients as bf16 on the bf16 data path (first layers need the
         # bf16 stem kernels: <= 80 input channels, 64 outputs)
         cin_max = (3 + 2 * pose_dim) if not deformable else (3 + pose_dim)
-        self.bfs = bool(bf16_store() and bf16_ok and self.enc[0] == 64 and cin_max <= 80 and STEM_BF16 and torch.cuda.is_available())
+        cin_fin_ = (2 if deformable else 1) * self.enc[0] + self.dec[-2]
+        chans_ok = (all(c % 128 == 0 for c in self.enc[1:]) and all(c % 128 == 0 for c in self.dec[:-2])
+                    and (self.dec[-2] % 128 == 0 or self.dec[-2] == 64) and cin_fin_ <= 256 and cin_fin_ % 32 == 0)
+        # every layer must be eligible for the bf16 kernels (there is no fp32 fallback inside the storage mode): 64 first-layer
+        # outputs, multiples of 128 channels elsewhere (one 64-channel operand per weight gradient), an output convolution of
+        # <= 256 input channels (pg_out_conv_bwd_direct).  Models that are not fall back to fp32 STORAGE here, at build time.
+        self.bfs = bool(bf16_store() and bf16_ok and self.enc[0] == 64 and cin_max <= 80 and STEM_BF16 and chans_ok
+                        and torch.cuda.is_available())
         act = dict(dtype=torch.bfloat16 if self.bfs else torch.float32, device=device)
         A_ = lambda *shape: _reg_bf16(torch.empty(*shape, **act))
         hw = [(H >> l, W >> l) for l in range(self.nlev)]
@@ -1154,7 +1169,8 @@ class GeneratorEngine:
             # bf16 STORAGE: the three sources are bf16 operands already (normalised block output, relu'd warp, the stem's
             # ReLU copy); the 27 tap columns are padded to the 64-column tile of the bf16 kernels
             dev_copy(self.wt_fin[:27], A.p("decoder.net.%d.weight" % (i + 1)).view(27, cin))
-            _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W, self.wt_fin, self.fin_cols, cin, out=self.y_taps)
+            _conv([a.src() for _, _, a in srcs], N, H, W, L.ACT_RELU, 0, 1, 1, 0, H, W, self.wt_fin, self.fin_cols, cin, out=self.y_taps,
+                  allow_n32=True)
             L.call("pg_tap_gather_pitch", L.ptr(self.y_taps), self.fin_cols, N, H, W, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
                    L.OUT_TANH, L.ptr(self.out), 3 * H * W, H * W, W, 1, L.stream())
             return self.out

@@ -111,6 +111,7 @@ _PROTOS = {
     "pg_comm_init": [_vp, _i32, _i32, C.POINTER(_vp)],
     "pg_comm_allreduce_bucket": [_vp, _vp, _i64, _i32, _vp],
     "pg_comm_destroy": [_vp],
+    "pg_comm_ranks": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
     "pg_pack_bf16": [_vp, _vp, _i64, _vp],
     "pg_dropout_mask": [_vp, _i64, _u64, _f32, _vp],
     "pg_nchw_to_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -28,6 +28,19 @@ class TapedIteration:
         assert DP.world_size() == 1, "launch-tape replay is single-process only"
         assert E.REPLAY_CTR is None, "one replay session at a time"
         self.model, self.batches = model, batches
+        # the tape holds ADDRESSES: every input must be the static tensor the library reads directly — a dtype / layout that
+        # makes the iteration go through a torch temporary (warps.float(), a non-contiguous or 9-column warp tensor) would be
+        # recorded as a copy from a freed address
+        for bt in batches:
+            for x in bt:
+                assert x.is_cuda and x.is_contiguous(), "taped iteration: inputs must be contiguous device tensors"
+            assert bt[0].dtype == torch.float32 and bt[1].dtype == torch.float32 and bt[2].dtype == torch.float32, \
+                "taped iteration: images and warps must be fp32"
+            assert bt[2].shape[-1] == 8 and bt[3].dtype in (torch.float32, torch.float64), \
+                "taped iteration: warps need exactly 8 columns, masks fp32 / fp64"
+        for dm in (drop_masks or ()):
+            for x in (dm or ()):
+                assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(), "taped iteration: dropout masks fp32 on the device"
         self.drop = drop_masks or (None, None)          # explicit (dis_update, gen_update) dropout masks: parity tests
         self.od = dict(opt_dict, lazy_losses=True)
         self.dev = batches[0][0].device

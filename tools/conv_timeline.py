@@ -1,5 +1,8 @@
 """Per-workgroup phase timeline of the 256-row bf16 convolution kernel on a generator layer at batch N (bf16 STORAGE).
-    gpurun -- env PG_DEBUG_CONV_TIMELINE=1 python tools/conv_timeline.py 32 dec5 fwd
+    PG_TIMING_EXPERIMENTS=1 python -m pose_transfer_amd.runtime.build   # here: builds lib/libposegan_hip_timing.so (-DPG_TIMING_EXPERIMENTS)
+    gpurun -- env PG_TIMING_EXPERIMENTS=1 PG_DEBUG_CONV_TIMELINE=1 python tools/conv_timeline.py 32 dec5 fwd
+(the production library carries neither the stamps nor the K-loop experiments; with PG_TIMING_EXPERIMENTS=1 in the environment
+runtime/build.py and runtime/lib.py select the timing library)
 Prints, per phase, the median / mean microseconds a workgroup spends (shader clock calibrated against the 100 MHz wall
 clock), and the launch's duration."""
 import ctypes
