@@ -43,7 +43,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // Ablation / debugging switches of the host-side launch code, read from the environment ONCE per process (round 3 called
 // getenv ~14 times per 256-row launch).  Every switch selects another CORRECT code path; the timing experiments that produce
 // wrong results exist only in builds with -DPG_TIMING_EXPERIMENTS (tools/conv_timeline.py).  Two switches stay dynamic because
-// the test-suite flips them inside one process: PG_FORCE_BF16_BIG (igemm_conv.hip) and PG_NO_OUT_DGRAD_MFMA (out_conv_dgrad.hip).
+// the test-suite flips them inside one process: PG_FORCE_BF16_BIG, PG_BIG_128_VARIANT (igemm_conv.hip) and PG_NO_OUT_DGRAD_MFMA
+// (out_conv_dgrad.hip).
 struct Env {
   bool no_vec_epilogue, splitk_debug, no_splitk_ws, no_dma, no_xcd_swizzle, conv_mask_generic, no_bf16_big, no_bf16_big64;
   bool wg_generic, bias_grad_x4, nn_loss_v1;

@@ -265,17 +265,26 @@ static __device__ unsigned long long kTimeline[TL_WGS * TL_SLOTS];
 #ifndef PG_BIG_SPLIT_DMA
 #define PG_BIG_SPLIT_DMA 1
 #endif
-template <int BN>
+// BK (round 4): K elements per tile.  64 everywhere except the 512 x 128 tile of the N = 128 layers (the last decoder block's
+// forward, encoder level 1's forward, encoder level 2's data gradient): 256 x 128 x 64 gives a wave 64 x 64 — 16 ds_read_b128 and
+// 6 DMA instructions per 16 MFMAs, the worst ratios of the family (mfma_util 0.31) — and 512 x 128 x 64 does not fit two stages
+// into 160 KB.  512 x 128 x 32: rows of 32 bf16 (64 B, four 16-byte chunks, swizzle chunk ^ (row >> 2 & 3)), a wave owns 128 x 64
+// as in the 256-wide kernel (12 ds_read_b128 and 5 DMA instructions per 16 MFMAs), THREE stages of 40 KB (a DMA has two tiles of
+// MFMA time to land; one barrier per tile = per 16 MFMAs of a wave, as before).
+template <int BN, int BK>
 __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
-  constexpr int BM = (BN == 64) ? 512 : 256;                // BN = 64 (N = 64 layers at full resolution): 512 x 64, a wave owns 64 x 64
+  constexpr int BM = (BN == 64 || BK == 32) ? 512 : 256;    // BN = 64 (N = 64 layers at full resolution): 512 x 64, a wave owns 64 x 64
   constexpr int WGN = BN / 64, WGM = 8 / WGN;            // 256: 2 x 4 waves, 128: 4 x 2 waves, 64: 8 x 1 waves
   constexpr int TM = BM / WGM / 32, TN = 2;              // MFMA tiles per wave: 4 x 2 or 2 x 2
-  constexpr int A_PASS = BM / 64, B_PASS = BN / 64;      // global_load_lds per thread and tile (64 rows per pass)
-  constexpr int A_ST = BM * 128, B_ST = BN * 128;        // bytes per stage
+  constexpr int ROWB = BK * 2, KCH = BK / 8, KS = BK / 16;   // bytes per operand row, 16-byte chunks per row, k-steps per tile
+  constexpr int RPP = 512 / KCH;                         // rows one DMA pass of the workgroup covers (512 lanes x 16 B)
+  constexpr int A_PASS = BM / RPP, B_PASS = BN / RPP;    // global_load_lds per thread and tile
+  constexpr int A_ST = BM * ROWB, B_ST = BN * ROWB;      // bytes per stage
   constexpr int STAGE = A_ST + B_ST;
-  constexpr int NST = (BN == 128 && PG_BIG_3STAGE) ? 3 : 2;
+  constexpr int NST = (BK == 32 || (BN == 128 && PG_BIG_3STAGE)) ? 3 : 2;
   constexpr int ROWS_OFF = NST * STAGE, TAPS_OFF = ROWS_OFF + BM * (int)sizeof(RowB);
   constexpr int STAT_OFF = (TAPS_OFF + MAXTAP * 4 + 7) & ~7, STAT_N = 8;         // per-workgroup statistics: STAT_N samples x (sum, sum of squares)
+  static_assert(B_PASS >= 1 && 8 * (32 * (32 * TN + 4)) * 4 <= NST * STAGE, "tile / epilogue buffers");
   __shared__ __attribute__((aligned(1024))) char smem[STAT_OFF + STAT_N * 2 * 8];     // ONE LDS object (see header)
   RowB* rows = reinterpret_cast<RowB*>(smem + ROWS_OFF);
   int* taps_l = reinterpret_cast<int*>(smem + TAPS_OFF);
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   __syncthreads();
 
   stamp(1);
-  const int cpt = p.Ctot / 64;                      // K tiles per tap
+  const int cpt = p.Ctot / BK;                      // K tiles per tap
   const int ktot = ntap * cpt;
   const int kper = (ktot + p.ksplit - 1) / p.ksplit;
   const int kt0 = split * kper;
@@ -367,14 +376,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   // ---- DMA loader state: per-thread source pointers of this thread's A_PASS + B_PASS rows (chunk = slot ^ row swizzle)
   const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
   const char* const wp = uniform_ptr(reinterpret_cast<const char*>(p.W) + w_off_g);
-  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const int chunk = (BK == 64) ? ((tid & 7) ^ ((tid >> 4) & 7)) : ((tid & 3) ^ ((tid >> 4) & 3));      // source chunk of this lane's LDS slot
   const char* pa[A_PASS];
   const char* pb[B_PASS];
   int ld_kt = kt0, ld_tap = kt0 / cpt, ld_ci = kt0 - (kt0 / cpt) * cpt;
   auto rebuild = [&]() {
     const int tp = lds_rd32_now(lds0 + TAPS_OFF + ld_tap * 4);
     const int dyv = (int)(signed char)(tp & 0xff), dxv = (int)(signed char)((tp >> 8) & 0xff);
-    const int cc = ld_ci * 64;
+    const int cc = ld_ci * BK;
     const char* sp = reinterpret_cast<const char*>(p.src[0].ptr);
     int sC = p.src[0].C, cs = 0;
 #pragma unroll
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     int rn[A_PASS], ryx[A_PASS];
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      const unsigned ra = lds0 + ROWS_OFF + (unsigned)(((tid >> 3) + 64 * i) * (int)sizeof(RowB));
+      const unsigned ra = lds0 + ROWS_OFF + (unsigned)((tid / KCH + RPP * i) * (int)sizeof(RowB));
       asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:8" : "=&v"(rn[i]), "=&v"(ryx[i]) : "v"(ra));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -396,15 +405,15 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       const int iy = (int)(short)(ryx[i] & 0xffff) + dyv, ix = (ryx[i] >> 16) + dxv;
       const bool ok = (rn[i] >= 0) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
       const long off = ((long)((rn[i] * p.Hi + iy) * p.Wi + ix) * sC + cl) * 2;
-      pa[i] = ok ? sp + off : zero_pg + (tid & 7) * 16;
+      pa[i] = ok ? sp + off : zero_pg + (tid & (KCH - 1)) * 16;
       if (PG_DBG(p, 2)) pa[i] = sp + (long)cl * 2;        // PG_DEBUG_OPERAND_A: every row reads pixel 0 (delivery experiment)
     }
     const int base = (tp >> 16) * p.wCout;
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      const int n = nb0 + (tid >> 3) + 64 * i;
+      const int n = nb0 + tid / KCH + RPP * i;
       const long off = ((long)(base + p.n_off + n) * p.wCin + cc + chunk * 8) * 2;
-      pb[i] = (n < p.n_cnt) ? wp + off : zero_pg + (tid & 7) * 16;
+      pb[i] = (n < p.n_cnt) ? wp + off : zero_pg + (tid & (KCH - 1)) * 16;
       if (PG_DBG(p, 4)) pb[i] = wp + ((long)(base + p.n_off) * p.wCin + cc + chunk * 8) * 2;      // PG_DEBUG_OPERAND_B
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): no scalar (kernel-argument) load stays in flight past here
@@ -416,13 +425,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       else {
         bool src_edge = false;
 #pragma unroll
-        for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && ld_ci * 64 == p.cstart[q]) src_edge = true;
+        for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && ld_ci * BK == p.cstart[q]) src_edge = true;
         if (src_edge) rebuild();
         else {
 #pragma unroll
-          for (int i = 0; i < A_PASS; ++i) pa[i] += 128;
+          for (int i = 0; i < A_PASS; ++i) pa[i] += ROWB;
 #pragma unroll
-          for (int i = 0; i < B_PASS; ++i) pb[i] += 128;
+          for (int i = 0; i < B_PASS; ++i) pb[i] += ROWB;
         }
       }
     }
@@ -453,20 +462,20 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   };
 
   // ---- operand fetch: k-step ks (16 k's) of a stage -> one register set (TM + TN ds_read_b128)
-  const int swr = (l31 >> 1) & 7;
-  unsigned fa[4], fb[4];
+  const int swr = (BK == 64) ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+  unsigned fa[KS], fb[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    fa[ks] = lds0 + (unsigned)((wm0 + l31) * 128) + (unsigned)(((2 * ks + lhi) ^ swr) * 16);
-    fb[ks] = lds0 + A_ST + (unsigned)((wn0 + l31) * 128) + (unsigned)(((2 * ks + lhi) ^ swr) * 16);
+  for (int ks = 0; ks < KS; ++ks) {
+    fa[ks] = lds0 + (unsigned)((wm0 + l31) * ROWB) + (unsigned)(((2 * ks + lhi) ^ swr) * 16);
+    fb[ks] = lds0 + A_ST + (unsigned)((wn0 + l31) * ROWB) + (unsigned)(((2 * ks + lhi) ^ swr) * 16);
   }
   auto fetch = [&](int stage, int ks, f32x4 (&va)[TM], f32x4 (&vb)[TN]) {
     const unsigned aa = fa[ks] + (unsigned)(stage * STAGE), bb = fb[ks] + (unsigned)(stage * STAGE);
     lds_rd128<0>(va[0], aa);
-    lds_rd128<4096>(va[1], aa);
-    if constexpr (TM == 4) { lds_rd128<8192>(va[2], aa); lds_rd128<12288>(va[3], aa); }
+    lds_rd128<32 * ROWB>(va[1], aa);
+    if constexpr (TM == 4) { lds_rd128<64 * ROWB>(va[2], aa); lds_rd128<96 * ROWB>(va[3], aa); }
     lds_rd128<0>(vb[0], bb);
-    lds_rd128<4096>(vb[1], bb);
+    lds_rd128<32 * ROWB>(vb[1], bb);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto mfmas = [&](const f32x4 (&va)[TM], const f32x4 (&vb)[TN]) {
@@ -505,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
     __builtin_amdgcn_sched_barrier(0);
+    // k-steps 0 .. KS-2: fetch the next k-step's operands into the other register set, multiply the current one
     fetch(stage, 1, va1, vb1);
     PGB_LDS_WAIT(NRD);
     mfmas(va0, vb0);
@@ -512,13 +522,15 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
       if (pend) { issue_b(stage ^ 1); advance(); pend = false; }      // the B half behind the first k-step's MFMAs
       __builtin_amdgcn_sched_barrier(0);
     }
-    fetch(stage, 2, va0, vb0);
-    PGB_LDS_WAIT(NRD);
-    mfmas(va1, vb1);
+    if constexpr (KS == 4) {
+      fetch(stage, 2, va0, vb0);
+      PGB_LDS_WAIT(NRD);
+      mfmas(va1, vb1);
 
-    fetch(stage, 3, va1, vb1);
-    PGB_LDS_WAIT(NRD);
-    mfmas(va0, vb0);
+      fetch(stage, 3, va1, vb1);
+      PGB_LDS_WAIT(NRD);
+      mfmas(va0, vb0);
+    }
     // tile switch: this wave's last operand fetch of the stage has landed (lgkmcnt(0)), its share of the next tile has
     // landed (two stages: vmcnt(0); three: the DMA instructions of tile kt + 2, issued later, may stay in flight); after the
     // barrier both hold for every wave
@@ -673,9 +685,10 @@ extern "C" int pg_debug_conv_timeline(unsigned long long* host_out, int32_t n_wg
 namespace pg {
 // launch helper used by conv_impl (igemm_conv.hip)
 void launch_conv_bf16_big(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
-  if (bn == 256) PG_KLAUNCH((conv_bf16_big_kernel<256>), grid, dim3(512), 0, st, k);
-  else if (bn == 64) PG_KLAUNCH((conv_bf16_big_kernel<64>), grid, dim3(512), 0, st, k);
-  else PG_KLAUNCH((conv_bf16_big_kernel<128>), grid, dim3(512), 0, st, k);
+  if (bn == 256) PG_KLAUNCH((conv_bf16_big_kernel<256, 64>), grid, dim3(512), 0, st, k);
+  else if (bn == 64) PG_KLAUNCH((conv_bf16_big_kernel<64, 64>), grid, dim3(512), 0, st, k);
+  else if (bn == 129) PG_KLAUNCH((conv_bf16_big_kernel<128, 32>), grid, dim3(512), 0, st, k);      // 512 x 128 x 32
+  else PG_KLAUNCH((conv_bf16_big_kernel<128, 64>), grid, dim3(512), 0, st, k);
 }
 
 }  // namespace pg

@@ -1720,16 +1720,27 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     const bool n32 = k.n_cnt == 32 && d->epilogue == 0 && d->stats == nullptr && k.nphase == 1;
     const int bn = (k.n_cnt % 256 == 0) ? 256 : (k.n_cnt % 128 == 0 ? 128 : ((k.n_cnt == 64 || n32) && !env().no_bf16_big64 ? 64 : 0));
     if (bn != 0) {
-      const int mtb = cdiv(k.M, bn == 64 ? 512 : 256), ntb = cdiv(k.n_cnt, bn);
-      const long wgs = (long)mtb * ntb * k.nphase;
+      int mtb = cdiv(k.M, bn == 64 ? 512 : 256);
+      const int ntb = cdiv(k.n_cnt, bn);
+      long wgs = (long)mtb * ntb * k.nphase;
       static const long big_min = getenv("PG_BF16_BIG_MIN") ? atol(getenv("PG_BF16_BIG_MIN")) : 192;   // swept (tools/sweep_bf16_big_min.sh): 448 -> 523 / 814, 192 -> 529 / 832 img/s (256^2 batch 4 / 224^2 batch 8)
+      // (round 4) 128-column tiles: 512 x 128 x 32 in three stages instead of 256 x 128 x 64 when the launch still fills the
+      // chip with 512-row tiles (csrc/igemm_bf16.hip)
+      int code = bn;
+      if (bn == 128) {
+        // PG_BIG_128_VARIANT = 256 | 512 pins the tile (read per launch: the test-suite flips it inside one process)
+        const char* pin = getenv("PG_BIG_128_VARIANT");
+        const int mt5 = cdiv(k.M, 512);
+        const bool want = pin ? (pin[0] == '5' && k.M >= 512) : ((long)mt5 * ntb * k.nphase >= 2 * big_min);
+        if (want) { code = 129; mtb = mt5; wgs = (long)mt5 * ntb * k.nphase; }
+      }
       if (wgs >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr) {
         k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && !env().no_xcd_swizzle) ? 1 : 0;
         k.xcd_swizzle |= (int)env().debug_bits;       // zero unless built with -DPG_TIMING_EXPERIMENTS
         if (k.dst_io == 1 && k.Gy * k.Gx < 32) k.dst_io = 2;      // the pipelined bf16 scatter assumes <= 2 samples per 32 rows
-        launch_conv_bf16_big(k, bn, dim3(mtb, ntb, k.nphase), st);
+        launch_conv_bf16_big(k, code, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
-        last_info() = (bn == 256 ? 4 : (bn == 128 ? 5 : 6)) | (amode << 4) | (bmode << 8) | (1 << 16);
+        last_info() = (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6))) | (amode << 4) | (bmode << 8) | (1 << 16);
         return 0;
       }
     }

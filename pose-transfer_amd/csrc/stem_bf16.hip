@@ -223,6 +223,150 @@ __global__ __launch_bounds__(256) void stem_conv_bf16_kernel(const StemK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// forward, pipelined form (round 4) for ONE source, one channel group and k3 s1 — the generator's first layers.  The kernel above
+// spends a tile's life in dependent latencies: four batches of input loads before the patch is written, the 28 KB filter
+// re-read from L2 (its LDS doubles as the epilogue's transposition tiles), MFMAs, stores — 31 us per 16 x 16 tile and
+// workgroup, 2.6 TB/s.  Here the filter stays resident, the transposition tiles have their own LDS (79 KB per workgroup, two
+// per CU), a thread's patch elements (channel, row, column) are the same for every tile, so their offsets live in registers,
+// and the NEXT tile's input is loaded into registers before the current tile's MFMAs and stores.
+template <int CG, int TH>
+__global__ __launch_bounds__(256, 2) void stem_conv_bf16_pf_kernel(const StemK p) {
+  constexpr int K = 3, S = 1, TW = 16;
+  constexpr int PH = TH + 2, PW = TW + 2, ROWP = PW;
+  constexpr int PS = CG * 2;
+  constexpr int PATCH_B = (PH * ROWP * PS + 15) / 16 * 16;
+  constexpr int CPT = CG / 8, NCH = 9 * CPT, NKS = (NCH + 1) / 2;
+  constexpr int W_B = 2 * NKS * 1024;
+  constexpr int TMW = TH / 8;
+  constexpr int NU = (CG * PH * PW + 255) / 256;            // patch elements per thread (upper bound: CG channels)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const patch = smem;
+  char* const wl = smem + PATCH_B;
+  float* const T = reinterpret_cast<float*>(smem + PATCH_B + W_B) + (threadIdx.x >> 6) * (32 * 68);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int i = tid; i < PATCH_B / 16; i += 256) reinterpret_cast<float4*>(patch)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.Wp);
+    for (int e = tid; e < W_B / 16; e += 256) reinterpret_cast<float4*>(wl)[e] = src[e];
+  }
+  const int sC = (int)p.src[0].sC, sH = (int)p.src[0].sH, sW = (int)p.src[0].sW;
+  const int E = p.Ctot * PH * PW;
+  // per-thread element table: global offset relative to the tile origin, LDS byte offset, (row, column)
+  int rel[NU];
+  unsigned meta[NU];                                        // LDS byte offset | row << 16 | column << 24
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int e = tid + 256 * u;
+    const int col = e % PW, rr = (e / PW) % PH, c = e / (PW * PH);
+    rel[u] = c * sC + rr * sH + col * sW;
+    meta[u] = (unsigned)((rr * ROWP + col) * PS + c * 2) | ((unsigned)rr << 16) | ((unsigned)col << 24);
+  }
+  static_assert(PH * ROWP * PS < 65536, "stem conv: LDS offsets in 16 bits");
+  const int a_base = ((2 * TMW * wave + (l31 >> 4)) * ROWP + (l31 & 15)) * PS;
+  const int b_base = lhi * 1024 + l31 * 16;
+  const float bias0 = p.bias ? p.bias[l31] : 0.f, bias1 = p.bias ? p.bias[32 + l31] : 0.f;
+
+  float v[NU];
+  unsigned okm = 0;
+  auto prefetch = [&](int t) {
+    int b = t;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int iy0 = ty * TH - p.pad, ix0 = tx * TW - p.pad;
+    const char* ptr = uniform_ptr(reinterpret_cast<const char*>(p.src[0].ptr + (long)n * p.src[0].sN));
+    const int org = iy0 * sH + ix0 * sW;
+    okm = 0;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int iy = iy0 + (int)((meta[u] >> 16) & 0xffu), ix = ix0 + (int)(meta[u] >> 24);
+      const bool ok = (tid + 256 * u < E) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      v[u] = ldg32(ptr, (long)(ok ? org + rel[u] : 0) * 4);
+      okm |= (ok ? 1u : 0u) << u;
+    }
+  };
+  static_assert(NU <= 32, "stem conv: element mask");
+
+  int t = blockIdx.x;
+  if (t < p.ntiles) prefetch(t);
+  for (; t < p.ntiles; t += gridDim.x) {
+    int b = t;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    __syncthreads();                                        // every wave is done with the previous tile's patch
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (tid + 256 * u < E) *reinterpret_cast<unsigned short*>(patch + (meta[u] & 0xffffu)) = to_bf16(((okm >> u) & 1u) ? v[u] : 0.f);
+    __syncthreads();
+    if (t + (int)gridDim.x < p.ntiles) prefetch(t + gridDim.x);      // in flight behind the MFMAs and the stores below
+
+    f32x16 acc[TMW][2];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NKS; ++kk) {
+      int off[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * kk + h;
+        const int tp = (j < NCH) ? j / CPT : 0, c8 = (j < NCH) ? j % CPT : 0;
+        off[h] = ((tp / 3) * ROWP + tp % 3) * PS + c8 * 16;
+      }
+      const int ao = a_base + (lhi ? off[1] : off[0]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wl + b_base + kk * 2048);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wl + b_base + kk * 2048 + 512);
+#pragma unroll
+      for (int i = 0; i < TMW; ++i) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + ao + i * (2 * ROWP * PS));
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[i][1], 0, 0, 0);
+      }
+    }
+    // epilogue as in the kernel above, through this wave's own transposition tile
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float bj = j ? bias1 : bias0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 68 + j * 32 + l31] = acc[i][j][r] + bj;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float4 o4[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) o4[it] = *reinterpret_cast<const float4*>(&T[(it * 4 + (lane >> 4)) * 68 + (lane & 15) * 4]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = it * 4 + (lane >> 4);
+        const int oy = oy0 + 2 * (TMW * wave + i) + (m >> 4), ox = ox0 + (m & 15);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const long o = (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + (lane & 15) * 4;
+        if (p.out != nullptr) *reinterpret_cast<float4*>(p.out + o) = o4[it];
+#pragma unroll
+        for (int ob = 0; ob < 3; ++ob) {
+          unsigned short* const optr = ob == 0 ? p.out_bf16 : (ob == 1 ? p.obf2 : p.obf3);
+          const float oslope = ob == 0 ? p.slope : (ob == 1 ? p.slope2 : p.slope3);
+          if (optr == nullptr) continue;
+          *reinterpret_cast<uint2*>(optr + o) = make_uint2(pack_bf16(apply_act_s(o4[it].x, oslope), apply_act_s(o4[it].y, oslope)),
+                                                           pack_bf16(apply_act_s(o4[it].z, oslope), apply_act_s(o4[it].w, oslope)));
+        }
+      }
+    }
+  }
+}
+
 // W packed fp32 [tap][co 64][Cin]  ->  bf16 [group][stage][chunk][co][8]; chunk j of a stage = tap j / CPT, channels
 // group*CG + (j % CPT)*8 .. +7; zero where the channel / chunk does not exist.
 __global__ __launch_bounds__(256) void stem_pack_kernel(const float* W, int K, int Cin, int CG, int ngroups, unsigned short* Wp) {
@@ -437,6 +581,28 @@ static int launch_stem_conv(StemK& k, hipStream_t st) {
   return 0;
 }
 
+// pipelined forward kernel (one source, one channel group, k3 s1, CG = 24): 2 workgroups per CU
+template <int CG, int TH>
+static int launch_stem_conv_pf(StemK& k, hipStream_t st) {
+  constexpr int PH = TH + 2, PW = 18;
+  constexpr int PATCH_B = (PH * PW * CG * 2 + 15) / 16 * 16;
+  constexpr int NCH = 9 * (CG / 8), NKS = (NCH + 1) / 2;
+  constexpr int LDS = PATCH_B + 2 * NKS * 1024 + 4 * 32 * 68 * 4;
+  static_assert(2 * LDS <= 160 * 1024, "stem conv (pipelined): two workgroups per CU");
+  k.tiles_x = (k.Wo + 15) / 16; k.tiles_y = (k.Ho + TH - 1) / TH;
+  k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  auto kern = stem_conv_bf16_pf_kernel<CG, TH>;
+  static bool set = false;
+  if (!set) {
+    PG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    set = true;
+  }
+  int blocks = stem_cu_count() * 2;
+  if (blocks > k.ntiles) blocks = k.ntiles;
+  PG_KLAUNCH(kern, dim3((unsigned)blocks), dim3(256), LDS, st, k);
+  return 0;
+}
+
 template <int K, int S, int TH, int CP, int NW, int NTW>
 static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hipStream_t st) {
   constexpr int PH = (TH - 1) * S + K, PW = 15 * S + K, PWH = (PW + 1) / 2, ROWP = (S == 1) ? PW : 2 * PWH;
@@ -529,7 +695,10 @@ extern "C" int pg_stem_conv_bf16_v3(const pg_src_t* src, int32_t nsrc, int32_t N
   k.ngroups = (k.Ctot + CG - 1) / CG;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (K == 3) rc = (CG == 24) ? pg::launch_stem_conv<3, 1, 24, 16>(k, st) : pg::launch_stem_conv<3, 1, 40, 16>(k, st);
+  static const bool no_pf = getenv("PG_NO_STEM_PF") != nullptr;        // ablation switch: the round-3 kernel everywhere
+  if (K == 3 && CG == 24 && nsrc == 1 && k.ngroups == 1 && !no_pf &&
+      (double)Hi * Wi * k.Ctot * 4.0 < 2147483648.0) rc = pg::launch_stem_conv_pf<24, 16>(k, st);
+  else if (K == 3) rc = (CG == 24) ? pg::launch_stem_conv<3, 1, 24, 16>(k, st) : pg::launch_stem_conv<3, 1, 40, 16>(k, st);
   else rc = (CG == 24) ? pg::launch_stem_conv<4, 2, 24, 16>(k, st) : pg::launch_stem_conv<4, 2, 40, 8>(k, st);
   if (rc) return rc;
   PG_LAUNCH_OK("pg_stem_conv_bf16");

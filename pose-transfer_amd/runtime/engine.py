@@ -27,7 +27,7 @@ class KernelProfiler:
     """Per-launch timing of the contraction kernels with HIP events recorded on the launch stream
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
-    CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32", 4: "256x256", 5: "256x128", 6: "512x64"}
+    CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32", 4: "256x256", 5: "256x128", 6: "512x64", 7: "512x128"}
     WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin", 6: "bf16-tr-256", 7: "bf16-stem"}
 
     def __init__(self):
@@ -616,6 +616,48 @@ def _join_side():
         L.call("pg_stream_wait", L.stream(), _raw(_SIDE[torch.cuda.current_device()]))
 
 
+# Third stream (round 4): the deformable skips' kernels — mask pyramid, limb-mask boxes, warp forward, warp backward — are
+# instruction- / latency-bound passes over the four high-resolution levels that depend only on the SHALLOW encoder levels
+# (forward) / the shallow decoder blocks (backward).  The DEEP layers (16^2 ... 4^2 maps: ~25 short launches per pass that
+# leave most CUs idle) do not touch them, so the warp kernels run on an auxiliary stream next to that chain:
+#   forward :  app 0..3, pose 0..3 | fork: [aux: warp l = 0..3]  [main: app 4.., pose 4.., decoder blocks on unwarped levels] | join
+#   backward:  ... decoder block of level 3 | fork: [aux: warp backward l = 3..0]  [main: deep decoder blocks, encoder levels
+#              whose input gradient no warp writes] | join before the first data gradient that accumulates into a warped level
+AUX_STREAM = os.environ.get("PG_NO_AUX_STREAM") is None
+_AUX = {}
+
+
+def _aux_on():
+    return AUX_STREAM and SIDE_STREAM and torch.cuda.is_available()
+
+
+def _aux_stream():
+    dev = torch.cuda.current_device()
+    st = _AUX.get(dev)
+    if st is None:
+        st = _AUX[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+@contextlib.contextmanager
+def _on_aux(fork=True):
+    """run the body's launches on the auxiliary stream (fork: it first waits for everything on the main stream so far)"""
+    if not _aux_on():
+        yield
+        return
+    aux = _aux_stream()
+    if fork:
+        L.call("pg_stream_wait", _raw(aux), L.stream())
+    with torch.cuda.stream(aux):
+        yield
+
+
+def _join_aux():
+    """main stream waits for everything enqueued on the auxiliary stream so far"""
+    if _aux_on() and _AUX.get(torch.cuda.current_device()) is not None:
+        L.call("pg_stream_wait", L.stream(), _raw(_AUX[torch.cuda.current_device()]))
+
+
 OUT_CONV_STREAM = os.environ.get("PG_NO_OUT_CONV_STREAM") is None   # ablation switch: K=32 pg_conv launch instead
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
 SMALL_CIN_DGRAD = os.environ.get("PG_NO_SMALL_CIN_DGRAD") is None   # ablation switch: GEMM-N = 3 pg_conv launch instead
@@ -1085,26 +1127,38 @@ class GeneratorEngine:
             dev_copy(self.warps, w8 if w8.shape[-1] == 8 else w8[:, :, :8])
             if self.masked:
                 assert masks.is_contiguous() and tuple(masks.shape) == (N, T, H, W)
-                for l in range(self.nwarp):
-                    L.call("pg_mask_pyramid", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W,
-                           self.hw[l][0], self.hw[l][1], L.ptr(self.lvl_masks[l]), L.stream())
-                if WARP_BBOX:       # bounding boxes of the non-zero mask regions: the warp backward skips what cannot contribute
-                    L.call("pg_mask_bbox", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W, L.ptr(self.mask_bbox),
-                           L.stream())
+                with _on_aux():
+                    for l in range(self.nwarp):
+                        L.call("pg_mask_pyramid", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W,
+                               self.hw[l][0], self.hw[l][1], L.ptr(self.lvl_masks[l]), L.stream())
+                    if WARP_BBOX:       # bounding boxes of the non-zero mask regions: the warp backward skips what cannot contribute
+                        L.call("pg_mask_bbox", L.ptr(masks), 1 if masks.dtype == torch.float64 else 0, N, T, H, W, L.ptr(self.mask_bbox),
+                               L.stream())
         # ---- encoders (reference networks.py:193-202)
         bfs = self.bfs
         assert bfs == (bf16_store() and bfs), "the engine was built for another storage mode (PRECISION changed?)"
         npx = lambda l: self.hw[l][0] * self.hw[l][1]
         # (round 3, tried and dropped: the pose encoder's chain on the side stream next to the appearance encoder's — 22.28 ms
         # against 22.02 ms for the north-star pass, and the 224^2 data-parallel identity test failed under it)
+        # shallow levels of both encoders first: everything the warps need exists, then the warps go to the auxiliary stream
+        # while the deep levels and the deep decoder blocks run here
+        cut = self.nwarp if (self.nwarp > 0 and _aux_on()) else self.nlev
         for e in self.encs:
-            self._forward_encoder(e, inp, bfs, npx)
-        self._forward_rest(inp, bfs)
+            self._forward_encoder(e, inp, bfs, npx, 0, cut)
+        if cut < self.nlev:
+            with _on_aux():
+                self._forward_warps(bfs)
+            for e in self.encs:
+                self._forward_encoder(e, inp, bfs, npx, cut, self.nlev)
+        else:
+            self._forward_warps(bfs)
+        self._forward_rest(inp, bfs, joined=cut >= self.nlev)
         return self.out
 
-    def _forward_encoder(self, e, inp, bfs, npx):
+    def _forward_encoder(self, e, inp, bfs, npx, l0, l1):
+        """levels l0 .. l1-1 of encoder `e` (level 0 = the first convolution)"""
         A, N, H, W = self.A, self.N, self.H, self.W
-        if True:
+        if l0 == 0:
             s0 = self._enc_in_src(e, inp)
             if bfs:
                 # level 0 has no norm: the stem writes the raw tensor and the operand(s) of its readers in one pass — the next
@@ -1120,24 +1174,25 @@ class GeneratorEngine:
             else:
                 _conv([s0.src()], N, H, W, L.ACT_NONE, 0, 3, 1, 1, H, W, A.p(e + ".net.0.weight"), self.enc[0], s0.C,
                       scalar_in=True, out=self.e_raw[e][0], bias=A.p(e + ".net.0.bias"))
-            for l in range(1, self.nlev):
-                hi, wi = self.hw[l - 1]
-                ho, wo = self.hw[l]
-                has_norm = l < self.nlev - 1
-                xin = self._enc_act(e, l - 1)
-                if bfs and l - 1 >= 1 and not (self.deformable and e == "encoder_app" and l - 1 < self.nwarp):
-                    # skip l-1 is read twice with different activations: both operands in one pass over the raw tensor
-                    _BF_CTX.get2(L.ptr(xin.t), xin.C, L.ACT_LEAKY, L.ACT_RELU, L.ptr(xin.aff), None, N, npx(l - 1), xin.t.device)
-                _conv([xin.src()], N, hi, wi, L.ACT_LEAKY, 0, 4, 2, 1, ho, wo,
-                      A.p("%s.net.%d.net.1.weight" % (e, l)), self.enc[l], self.enc[l - 1], out=self.e_raw[e][l],
-                      stats=self.e_norm[e][l].stats_target() if has_norm else None)
-                if has_norm:
-                    self.e_norm[e][l].forward(self.e_raw[e][l], N, ho * wo * self.enc[l],
-                                              A.p("%s.net.%d.net.2.weight" % (e, l)), A.p("%s.net.%d.net.2.bias" % (e, l)),
-                                              have_stats=True)
-    def _forward_rest(self, inp, bfs):
-        A, N, H, W = self.A, self.N, self.H, self.W
-        # ---- deformable skips (reference networks.py:279-288, utils/pose_transform.py:69-92)
+        for l in range(max(1, l0), l1):
+            hi, wi = self.hw[l - 1]
+            ho, wo = self.hw[l]
+            has_norm = l < self.nlev - 1
+            xin = self._enc_act(e, l - 1)
+            if bfs and l - 1 >= 1 and not (self.deformable and e == "encoder_app" and l - 1 < self.nwarp):
+                # skip l-1 is read twice with different activations: both operands in one pass over the raw tensor
+                _BF_CTX.get2(L.ptr(xin.t), xin.C, L.ACT_LEAKY, L.ACT_RELU, L.ptr(xin.aff), None, N, npx(l - 1), xin.t.device)
+            _conv([xin.src()], N, hi, wi, L.ACT_LEAKY, 0, 4, 2, 1, ho, wo,
+                  A.p("%s.net.%d.net.1.weight" % (e, l)), self.enc[l], self.enc[l - 1], out=self.e_raw[e][l],
+                  stats=self.e_norm[e][l].stats_target() if has_norm else None)
+            if has_norm:
+                self.e_norm[e][l].forward(self.e_raw[e][l], N, ho * wo * self.enc[l],
+                                          A.p("%s.net.%d.net.2.weight" % (e, l)), A.p("%s.net.%d.net.2.bias" % (e, l)),
+                                          have_stats=True)
+
+    def _forward_warps(self, bfs):
+        """deformable skips (reference networks.py:279-288, utils/pose_transform.py:69-92)"""
+        N, H, W = self.N, self.H, self.W
         for l in range(self.nwarp):
             a = self._enc_act("encoder_app", l)
             if bfs:     # bf16 in, relu(out) bf16 out: the stored tensor IS the decoder's operand (and its ReLU-derivative input)
@@ -1149,9 +1204,15 @@ class GeneratorEngine:
             L.call("pg_warp_mask_max_fwd", L.ptr(a.t), L.ptr(a.aff), L.ptr(self.warps), L.ptr(self.lvl_masks[l]), N,
                    self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.w_out[l]),
                    L.ptr(self.w_arg[l]), L.stream())
+
+    def _forward_rest(self, inp, bfs, joined=True):
+        A, N, H, W = self.A, self.N, self.H, self.W
         # ---- decoder (reference networks.py:236-250)
         for i in range(self.ndec - 1):
             srcs = self._dec_sources(i)
+            if not joined and any(kind == "warp" for kind, _, _ in srcs):
+                _join_aux()              # the first block that reads a warped skip
+                joined = True
             hi, wi = self.hw[self.nlev - 1 - i]
             ho, wo = 2 * hi, 2 * wi
             cin = sum(a.C for _, _, a in srcs)
@@ -1160,6 +1221,8 @@ class GeneratorEngine:
                   stats=self.d_norm[i].stats_target())
             self.d_norm[i].forward(self.d_raw[i], N, ho * wo * self.dec[i], A.p("decoder.net.%d.net.3.weight" % i),
                                    A.p("decoder.net.%d.net.3.bias" % i), have_stats=True)
+        if not joined:
+            _join_aux()
         i = self.ndec - 1
         srcs = self._dec_sources(i)
         cin = sum(a.C for _, _, a in srcs)
@@ -1269,6 +1332,17 @@ class GeneratorEngine:
 
     def _backward_rest(self, image_grad=None):
         A, N, H, W = self.A, self.N, self.H, self.W
+
+        def warp_bwd(levels):
+            for l in levels:
+                L.call("pg_warp_mask_max_bwd_bbox", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
+                       L.ptr(self.lvl_masks[l]), L.ptr(self.mask_bbox) if (self.masked and WARP_BBOX) else None, N, self.T, self.enc[l],
+                       self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.e_dz["encoder_app"][l]), 3 if self.bfs else 0,
+                       L.stream())
+
+        # decoder block that writes the deepest warped skip's gradient (level nwarp-1); -1: no fork (few levels / no aux stream)
+        i_fork = (self.nlev - self.nwarp) if (self.nwarp > 0 and _aux_on() and 0 < self.nlev - self.nwarp <= self.ndec - 2) else -1
+        forked = False
         # ---- up blocks
         for i in range(self.ndec - 2, -1, -1):
             srcs = self._dec_sources(i)
@@ -1285,14 +1359,20 @@ class GeneratorEngine:
             self._ready("decoder.net.%d." % i)
             _conv_dgrad(Act(dy, self.dec[i]).src(), N, ho, wo, 0, 4, 2, 1, hi, wi, A.p(wkey), self.dec[i], cin,
                         self._dsts_for(srcs, True))
+            if i == i_fork:
+                # every warped skip's gradient w_g[0 .. nwarp-1] is complete (block i wrote the deepest one): the warp
+                # backward goes to the auxiliary stream, deepest level first (the first one the encoder chain needs)
+                with _on_aux():
+                    warp_bwd(range(self.nwarp - 1, -1, -1))
+                forked = True
         # ---- deformable skips
-        for l in range(self.nwarp):
-            L.call("pg_warp_mask_max_bwd_bbox", L.ptr(self.w_g[l]), L.ptr(self.w_arg[l]), L.ptr(self.warps),
-                   L.ptr(self.lvl_masks[l]), L.ptr(self.mask_bbox) if (self.masked and WARP_BBOX) else None, N, self.T, self.enc[l],
-                   self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.e_dz["encoder_app"][l]), 3 if self.bfs else 0,
-                   L.stream())
+        if not forked:
+            warp_bwd(range(self.nwarp))
         # ---- encoders
         for l in range(self.nlev - 1, 0, -1):
+            if forked and l - 1 < self.nwarp:
+                _join_aux()              # this level's data gradient accumulates into a gradient the warp backward wrote
+                forked = False
             for e in self.encs:
                 hi, wi = self.hw[l - 1]
                 ho, wo = self.hw[l]
@@ -1310,6 +1390,8 @@ class GeneratorEngine:
                             self.enc[l - 1],
                             [L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
                                         accumulate=True)])
+        if forked:
+            _join_aux()
         for e in self.encs:
             dz = self.e_dz[e][0]
             s0 = self._enc_in_src(e, self.input)

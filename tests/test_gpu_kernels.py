@@ -814,17 +814,27 @@ def big_cases():
         ConvCase("big_k3_bias", "conv", [(128, A, False)], 256, 2, 14, 18, 3, 1, 1, L.ACT_RELU, bias=True, seed=15),
         ConvCase("big_up_n64_512rows", "convT", [(128, A, False), (64, False, False)], 64, 3, 20, 18, 4, 2, 1, L.ACT_RELU, seed=16),
         ConvCase("big_down_n64", "conv", [(64, A, False)], 64, 2, 50, 44, 4, 2, 1, L.ACT_LEAKY, seed=17),
+        # (round 4) enough rows for the 512 x 128 x 32 tile in every direction: forward N = 128 over four phases / one phase with
+        # a partial last M tile, data gradient N = 128 (= input channels) over > 512 rows per phase
+        ConvCase("big_up_128_1080rows", "convT", [(128, A, M), (64, False, False), (64, A, False)], 128, 3, 20, 18, 4, 2, 1,
+                 L.ACT_RELU, seed=18),
+        ConvCase("big_down_dgrad_128_1920rows", "conv", [(128, A, False)], 256, 4, 48, 40, 4, 2, 1, L.ACT_LEAKY, seed=19),
     ]
 
 
+@pytest.mark.parametrize("variant", ["256", "512"])
 @pytest.mark.parametrize("case", big_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
-def test_conv_bf16_big_kernel(case, monkeypatch):
+def test_conv_bf16_big_kernel(case, variant, monkeypatch):
     """igemm_bf16.hip (256 x 256 / 256 x 128 tiles, 8 waves, DMA'd operands, one barrier per K tile), forced on small
     problems (PG_FORCE_BF16_BIG) so that partial M tiles, several N tiles, multi-source A, the four convT phases, bias,
     the fused statistics and the data-gradient scatter (fresh and accumulating) are all exercised.  Exact up to summation
     order against the fp32 contraction of the bf16-ROUNDED operands (1e-4 of the tensor max)."""
     monkeypatch.setattr(E, "PRECISION", 3)
     monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    # 128-column launches: the 256 x 128 x 64 tile or (round 4) the 512 x 128 x 32 three-stage tile
+    monkeypatch.setenv("PG_BIG_128_VARIANT", variant)
+    if variant == "512" and case.cout != 128 and case.cin != 128:
+        pytest.skip("no 128-column launch in this case")
     bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
     zs, xs = [], []
     for j in range(len(case.srcs)):
@@ -842,7 +852,11 @@ def test_conv_bf16_big_kernel(case, monkeypatch):
     ref = conv(xq)
     stats = torch.zeros(case.N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
     got = case.run_forward(1, stats=stats)
-    assert (L.load().pg_last_launch_info() & 0xF) in (4, 5, 6), "the 256-row kernel did not run"
+    code = L.load().pg_last_launch_info() & 0xF
+    assert code in (4, 5, 6, 7), "the 256-row kernel did not run"
+    rows_f = case.N * (case.Ho * case.Wo if case.kind == "conv" else case.H * case.W)
+    if case.cout == 128:
+        assert code == (7 if (variant == "512" and rows_f >= 512) else 5), (code, rows_f)
     assert rel(got, ref) < 1e-4, (case.name, float(rel(got, ref)))
     o64 = got.double().reshape(case.N, -1)          # statistics of the STORED values
     st = stats.cpu().sum(1)
@@ -854,7 +868,7 @@ def test_conv_bf16_big_kernel(case, monkeypatch):
     for acc in (False, True):
         dgot = case.run_dgrad(1, acc)
         if case.cin % 128 == 0:          # the 256-row kernel needs >= 128 output columns (= input channels here)
-            assert (L.load().pg_last_launch_info() & 0xF) in (4, 5)
+            assert (L.load().pg_last_launch_info() & 0xF) in (4, 5, 7)
         for g, r in zip(dgot, dref):
             assert rel(g, r) < 1e-4, (case.name, acc, float(rel(g, r)))
 
