@@ -55,7 +55,13 @@ typedef struct {
   int32_t act;        /* PG_ACT_* of the consumer that read `fwd`                            */
   int32_t accumulate; /* 1: grad += ...; 0: grad = ...                                       */
   int32_t flags;      /* PG_DST_*: bf16 STORAGE of `grad` / `fwd` (bf16 data path, round 3); 0 = fp32 */
+  double* bsums;      /* optional (round 4), [N][PG_STAT_SLOTS][2], zeroed by the caller: the epilogue that writes the FINAL value r of
+                       * this gradient also adds the two per-sample sums of the following norm backward — (sum r, sum r * fwd) —
+                       * so that pg_norm_bwd_reduce's pass over the tensor does not run (pg_norm_bwd_apply_v2 converts them).
+                       * Only the bf16 256-row kernel and pg_out_conv_bwd_direct's fused pass implement it; whether a launch
+                       * did is reported in pg_last_launch_info() bit 14 (PG_INFO_BSUMS) — otherwise the field is ignored   */
 } pg_dst_t;
+#define PG_INFO_BSUMS (1 << 14)
 #define PG_DST_GRAD_BF16 1
 #define PG_DST_FWD_BF16 2
 
@@ -422,6 +428,15 @@ int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float* mr, int32_
                           int32_t io_flags, void* stream);
 int pg_norm_bwd_apply_io(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma, int32_t N,
                          int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags, void* stream);
+/* (round 4) the same with the per-sample sums taken from a producer's epilogue (pg_dst_t.bsums, [N][PG_STAT_SLOTS][2]):
+ * sums_mode 1: (sum r, sum r * y_raw)  -> sum r * xhat = rstd * (S2 - mean * S1)        (data-gradient scatter: `fwd` = raw tensor)
+ * sums_mode 2: (sum r, sum r * x_act)  -> sum r * xhat = (S2 - beta * S1) / gamma       (pg_out_conv_bwd_direct: `fwd` = relu(norm(y)),
+ *              r = 0 wherever the ReLU is off; gamma == 0 makes dz = 0 and the gamma gradient 0 — the normalised value is not
+ *              recoverable from a constant)
+ * sums_mode 0 = pg_norm_bwd_apply_io (bsums [N][2] from pg_norm_bwd_reduce). */
+int pg_norm_bwd_apply_v2(void* dz, const void* y, const float* mr, const double* sums, const float* gamma, const float* beta,
+                         int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags,
+                         int32_t sums_mode, void* stream);
 /* io_flags: bit 0 = feat is bf16, bit 1 = out is bf16, bit 2 = store relu(out) (the decoder reads the warped skip only
  * through its ReLU; relu(x) > 0 <=> x > 0 keeps the backward's activation derivative) */
 int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const float* warps, const float* lvl_masks, int32_t N,

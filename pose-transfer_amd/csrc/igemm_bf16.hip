@@ -141,9 +141,14 @@ __device__ __forceinline__ void big_store_64x64(const f32x16 (&acc)[2][TN_], flo
 // wait per half, never behind a store.
 // SIMPLE (wave-uniform, decided by the caller): no lane's destination has a dropout mask or accumulates — the case of the large
 // decoder data gradients; drops the previous-gradient and mask loads and about half of the VALU work per element.
-template <int TM_, int TN_, bool SIMPLE>
+// BS (round 4): the destination carries `bsums` — while a half's results are in registers, add (sum r, sum r * f) of its valid
+// elements to the sums of the norm backward that will read this gradient next (f = the raw forward value the scatter loads
+// anyway), per sample: a lane-local pair for the half's first sample, flushed (DPP wave sum -> LDS double atomic on the
+// workgroup's table `stab`, indexed by sample - nbase) when the sample changes, and a second pair for rows of the next sample.
+template <int TM_, int TN_, bool SIMPLE, bool BS>
 __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], float* T, const RowB* rows, int wm0, int lane,
-                                                 const LaneDst& d, bool cval, int m_first, int gg, int M, int N) {
+                                                 const LaneDst& d, bool cval, int m_first, int gg, int M, int N,
+                                                 double* stab = nullptr, int nbase = 0, int stat_n = 0, int gslot = 0) {
   constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int rsel = lane / LPR, c4 = (lane % LPR) * 4;
@@ -177,8 +182,25 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
       L.mk[1] = *reinterpret_cast<const float4*>(d.maskp + (d.has_mask ? nhi * d.C + d.c : (d.c & 511)));
     }
   };
+  int run_n = -1;                    // BS: sample of the running pair
+  float run_s = 0.f, run_q = 0.f;
+  auto flush = [&](int n, float s_, float q_) {
+    const double ds = (double)wave_sum_dpp(s_), dq = (double)wave_sum_dpp(q_);
+    if (lane == 0 && n >= 0 && (ds != 0.0 || dq != 0.0)) {
+      const int sl = n - nbase;
+      if (sl >= 0 && sl < stat_n) { atomicAdd(&stab[sl * 2], ds); atomicAdd(&stab[sl * 2 + 1], dq); }
+      else {
+        atomicAdd(&d.bsums[((long)n * PG_STAT_SLOTS + gslot) * 2], ds);
+        atomicAdd(&d.bsums[((long)n * PG_STAT_SLOTS + gslot) * 2 + 1], dq);
+      }
+    }
+  };
   // one 32-row half: `cur` holds its loads; before its stores go out the loads of half `nh` are issued into `nx` (nh < 0: none)
   auto step = [&](int hh, Half& cur, Half& nx, int nh) {
+    float hi_s = 0.f, hi_q = 0.f;
+    if constexpr (BS) {
+      if (cur.nlo != run_n) { flush(run_n, run_s, run_q); run_n = cur.nlo; run_s = 0.f; run_q = 0.f; }
+    }
 #pragma unroll
     for (int j = 0; j < TN_; ++j)
 #pragma unroll
@@ -220,7 +242,17 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
         }
         res[it] = make_uint2(pack_bf16(r4[0], r4[1]), pack_bf16(r4[2], r4[3]));
         oidx[it] = (unsigned)ro[u].y * (unsigned)d.C + (unsigned)d.c;
+        if constexpr (BS) {
+          const float okf = ((cur.ok >> it) & 1u) ? 1.f : 0.f;
+          const float s4 = okf * ((r4[0] + r4[1]) + (r4[2] + r4[3]));
+          const float q4 = okf * fmaf(r4[0], f4[0], fmaf(r4[1], f4[1], fmaf(r4[2], f4[2], r4[3] * f4[3])));
+          run_s += hi ? 0.f : s4; run_q += hi ? 0.f : q4;
+          hi_s += hi ? s4 : 0.f; hi_q += hi ? q4 : 0.f;
+        }
       }
+    }
+    if constexpr (BS) {
+      if (__builtin_amdgcn_ballot_w64(hi_s != 0.f || hi_q != 0.f) != 0) flush(cur.nlo + 1, hi_s, hi_q);      // rows of the next sample (rare)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -245,6 +277,7 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
     if (TM_ > 2) step(2, ha, hb, 3);
     if (TM_ > 3) step(3, hb, ha, -1);
   }
+  if constexpr (BS) flush(run_n, run_s, run_q);
 }
 
 // PG_DEBUG_CONV_TIMELINE: per-workgroup time stamps (s_memtime) of the LAST launch: 0 start, 1 rows/taps set up, 2 first tile landed,
@@ -642,7 +675,12 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
         gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
         C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags;
       }
+    double* bs0 = p.dst[0].bsums;
+#pragma unroll
+    for (int q = 1; q < PG_MAX_SRC; ++q)
+      if (q < p.ndst && ngs >= p.dstart[q]) bs0 = p.dst[q].bsums;
     LaneDst ld;
+    ld.bsums = bs0;
     ld.grad_bf16 = (dfl & PG_DST_GRAD_BF16) != 0; ld.fwd_bf16 = (dfl & PG_DST_FWD_BF16) != 0;
     ld.has_fwd = fwd0 != nullptr;
     const bool fa_ = aff0 != nullptr && ld.has_fwd;
@@ -659,8 +697,22 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_big_kernel(const ConvK p) {
     stamp(8);
     if (p.dst_io == 1) {          // host: every destination and forward tensor in bf16 STORAGE, >= 32 pixels per sample
       const bool plain = __builtin_amdgcn_ballot_w64(ld.has_mask || ld.accum) == 0;       // wave-uniform
-      if (plain) big_scatter_tile<TM, TN, true>(acc, T, rows, wm0, lane, ld, cval, __builtin_amdgcn_readfirstlane(m0 + wm0), p.Gy * p.Gx, p.M, p.N);
-      else big_scatter_tile<TM, TN, false>(acc, T, rows, wm0, lane, ld, cval, __builtin_amdgcn_readfirstlane(m0 + wm0), p.Gy * p.Gx, p.M, p.N);
+      const int mfw = __builtin_amdgcn_readfirstlane(m0 + wm0);
+      // host (conv_impl): a workgroup's column tile lies inside ONE destination whenever a destination carries bsums, so
+      // the choice is workgroup-uniform and the table `stab` holds one destination's sums
+      const bool bs_on = __builtin_amdgcn_readfirstlane((int)(ld.bsums != nullptr && ld.has_fwd)) != 0;
+      double* const stab = reinterpret_cast<double*>(smem + STAT_OFF);
+      const int nbase = m0 / (p.Gy * p.Gx), gslot = (bx + by * 5 + bz * 3) % PG_STAT_SLOTS;
+      if (bs_on) {
+        if (plain) big_scatter_tile<TM, TN, true, true>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
+        else big_scatter_tile<TM, TN, false, true>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
+        __syncthreads();
+        if (tid < STAT_N * 2) {
+          const double v = stab[tid];
+          if (v != 0.0) atomicAdd(&ld.bsums[((long)(nbase + (tid >> 1)) * PG_STAT_SLOTS + gslot) * 2 + (tid & 1)], v);
+        }
+      } else if (plain) big_scatter_tile<TM, TN, true, false>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N);
+      else big_scatter_tile<TM, TN, false, false>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N);
     } else {
 #pragma unroll
       for (int h = 0; h < TM / 2; ++h) {

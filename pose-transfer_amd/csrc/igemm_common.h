@@ -178,6 +178,7 @@ struct LaneDst {
   float* gradp; const float* fwdp; const float* affp; const float* maskp;
   int C, c, affmul; float dslope; bool has_fwd, has_mask, accum;
   bool grad_bf16 = false, fwd_bf16 = false;      // bf16 STORAGE of the gradient / forward tensor (pg_dst_t.flags)
+  double* bsums = nullptr;                       // (round 4) fused sums of the following norm backward (pg_dst_t.bsums), or null
 };
 // IO: 0 = fp32 tensors, 1 = gradient AND forward tensor in bf16 STORAGE (compile-time: the batched loads stay straight-line
 // code), 2 = per-destination run-time flags (mixed launches; the loads sit under wave-uniform branches)

@@ -1738,9 +1738,21 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
         k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && !env().no_xcd_swizzle) ? 1 : 0;
         k.xcd_swizzle |= (int)env().debug_bits;       // zero unless built with -DPG_TIMING_EXPERIMENTS
         if (k.dst_io == 1 && k.Gy * k.Gx < 32) k.dst_io = 2;      // the pipelined bf16 scatter assumes <= 2 samples per 32 rows
+        // (round 4) fused norm-backward sums (pg_dst_t.bsums): the pipelined bf16 scatter implements them when a workgroup's
+        // column tile lies inside one destination; otherwise the field is dropped and PG_INFO_BSUMS stays clear
+        bool bs_any = false, bs_ok = d->epilogue == 1 && k.dst_io == 1 && k.n_cnt % bn == 0;
+        if (d->epilogue == 1)
+          for (int j = 0; j < d->ndst; ++j) {
+            if (d->dst[j].bsums == nullptr) continue;
+            bs_any = true;       // its column range must be tile-aligned: no workgroup mixes it with another destination
+            if (k.dstart[j] % bn != 0 || d->dst[j].C % bn != 0 || d->dst[j].fwd == nullptr) bs_ok = false;
+          }
+        if (!(bs_any && bs_ok))
+          for (int j = 0; j < PG_MAX_SRC; ++j) k.dst[j].bsums = nullptr;
         launch_conv_bf16_big(k, code, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
-        last_info() = (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6))) | (amode << 4) | (bmode << 8) | (1 << 16);
+        last_info() = (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6))) | (amode << 4) | (bmode << 8) | (1 << 16) |
+                      ((bs_any && bs_ok) ? PG_INFO_BSUMS : 0);
         return 0;
       }
     }

@@ -130,16 +130,32 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* dz, const
   }
 }
 
-template <typename T>
+// The two per-sample sums (sum dz, sum dz * xhat) of sample n.  MODE 0: bsums [N][2] from norm_bwd_reduce_kernel.  MODE 1 / 2
+// (round 4): [N][PG_STAT_SLOTS][2] accumulated by the epilogue that wrote dz — (sum r, sum r * y_raw) or (sum r, sum r * x_act);
+// see pg_norm_bwd_apply_v2 in include/posegan_hip.h.
+template <int MODE>
+__device__ __forceinline__ void bwd_sums(const double* bsums, int n, float mean, float rstd, float g, float b, double& s1, double& s2) {
+  if constexpr (MODE == 0) { s1 = bsums[2 * n]; s2 = bsums[2 * n + 1]; return; }
+  double a1 = 0.0, a2 = 0.0;
+  for (int k = 0; k < PG_STAT_SLOTS; ++k) { a1 += bsums[((long)n * PG_STAT_SLOTS + k) * 2]; a2 += bsums[((long)n * PG_STAT_SLOTS + k) * 2 + 1]; }
+  s1 = a1;
+  if constexpr (MODE == 1) s2 = (double)rstd * (a2 - (double)mean * a1);
+  else s2 = (g != 0.f) ? (a2 - (double)b * a1) / (double)g : 0.0;
+}
+
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(T* dz, const T* y, const float* mr,
-                                                             const double* bsums, const float* gamma, int N, long L,
+                                                             const double* bsums, const float* gamma, const float* beta, int N, long L,
                                                              float* dgamma, float* dbeta, unsigned short* dy_bf16) {
   constexpr int V = Chunk<T>::N;
   const int n = blockIdx.y;
   const float mean = mr[2 * n], rstd = mr[2 * n + 1];
   const float g = gamma[0];
-  const float m1 = (float)(bsums[2 * n] / (double)L);
-  const float m2 = (float)(bsums[2 * n + 1] / (double)L);
+  const float bta = (MODE == 2) ? beta[0] : 0.f;
+  double s1d, s2d;
+  bwd_sums<MODE>(bsums, n, mean, rstd, g, bta, s1d, s2d);
+  const float m1 = (float)(s1d / (double)L);
+  const float m2 = (float)(s2d / (double)L);
   const float k = g * rstd;
   T* bd = dz + (long)n * L;
   const T* by = y + (long)n * L;
@@ -167,7 +183,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(T* dz, const T* y, 
     }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     double sg = 0.0, sb = 0.0;
-    for (int i = 0; i < N; ++i) { sb += bsums[2 * i]; sg += bsums[2 * i + 1]; }
+    for (int i = 0; i < N; ++i) {
+      double a1, a2;
+      bwd_sums<MODE>(bsums, i, mr[2 * i], mr[2 * i + 1], g, bta, a1, a2);
+      sb += a1; sg += a2;
+    }
     if (dgamma) atomicAdd(dgamma, (float)sg);
     if (dbeta) atomicAdd(dbeta, (float)sb);
   }
@@ -235,20 +255,30 @@ extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* 
 }
 
 // io_flags as in pg_norm_bwd_reduce_ex; with bf16 storage the in-place result IS the bf16 operand of the layer's gradient
-// contractions (dy_bf16 must be NULL then)
+// contractions (dy_bf16 must be NULL then).  sums_mode: where the two per-sample sums come from (include/posegan_hip.h).
+extern "C" int pg_norm_bwd_apply_v2(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma,
+                                    const float* beta, int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16,
+                                    int32_t io_flags, int32_t sums_mode, void* stream) {
+  PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0 && (io_flags == 0 || (io_flags == 3 && L % 8 == 0 && !dy_bf16)) &&
+             sums_mode >= 0 && sums_mode <= 2 && (sums_mode != 2 || beta != nullptr), "pg_norm_bwd_apply: bad arguments");
+  typedef unsigned short bf;
+  hipStream_t st = (hipStream_t)stream;
+#define PG_NBA(TT, VEC, MODE)                                                                                                 \
+  PG_KLAUNCH((norm_bwd_apply_kernel<TT, MODE>), dim3(norm_blocks(L, VEC), N), dim3(256), 0, st, (TT*)dz, (const TT*)y, mr, bsums, \
+             gamma, beta, N, (long)L, dgamma, dbeta, dy_bf16)
+  if (io_flags == 0) {
+    if (sums_mode == 0) PG_NBA(float, 4, 0); else if (sums_mode == 1) PG_NBA(float, 4, 1); else PG_NBA(float, 4, 2);
+  } else {
+    if (sums_mode == 0) PG_NBA(bf, 8, 0); else if (sums_mode == 1) PG_NBA(bf, 8, 1); else PG_NBA(bf, 8, 2);
+  }
+#undef PG_NBA
+  PG_LAUNCH_OK("pg_norm_bwd_apply");
+  return 0;
+}
 extern "C" int pg_norm_bwd_apply_io(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma,
                                     int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags,
                                     void* stream) {
-  PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0 && (io_flags == 0 || (io_flags == 3 && L % 8 == 0 && !dy_bf16)),
-             "pg_norm_bwd_apply: bad arguments");
-  typedef unsigned short bf;
-  hipStream_t st = (hipStream_t)stream;
-  if (io_flags == 0)
-    PG_KLAUNCH((norm_bwd_apply_kernel<float>), dim3(norm_blocks(L, 4), N), dim3(256), 0, st, (float*)dz, (const float*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
-  else
-    PG_KLAUNCH((norm_bwd_apply_kernel<bf>), dim3(norm_blocks(L, 8), N), dim3(256), 0, st, (bf*)dz, (const bf*)y, mr, bsums, gamma, N, (long)L, dgamma, dbeta, dy_bf16);
-  PG_LAUNCH_OK("pg_norm_bwd_apply");
-  return 0;
+  return pg_norm_bwd_apply_v2(dz, y, mr, bsums, gamma, nullptr, N, L, dgamma, dbeta, dy_bf16, io_flags, 0, stream);
 }
 extern "C" int pg_norm_bwd_apply_ex(float* dz, const float* y, const float* mr, const double* bsums, const float* gamma,
                                     int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, void* stream) {

@@ -235,6 +235,11 @@ __device__ __forceinline__ unsigned opack_bf16(float lo, float hi) {
   return r;
 }
 constexpr int OPATCH = 336;        // 3 channels x 3 rows x pitch 36 (34 used) = 324 floats + spare
+__device__ __forceinline__ float owave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgradK p) {
   __shared__ __attribute__((aligned(16))) uint4 a_lds[8 * 2 * 64];          // [channel tile][k step][lane]: 16 KB
@@ -279,16 +284,35 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
   const bool act0 = ct0 < nct, act1 = ct0 + 1 < nct;
   // destinations of this wave's two channel tiles (wave-uniform, fixed for the launch; constant-index picks)
   unsigned short* g16[2]; const unsigned short* f16[2]; int Cd[2], c0d[2]; float dsl[2];
+  double* bsd[2];                  // (round 4) pg_dst_t.bsums of the tile's destination: fused sums of the following norm backward
 #pragma unroll
   for (int cq = 0; cq < 2; ++cq) {
     const int ct = min(ct0 + cq, nct - 1);
     float* gp = p.dst[0].grad; const float* fp = p.dst[0].fwd; int C = p.dst[0].C, st = p.dstart[0], ac = p.dst[0].act;
+    double* bq = p.dst[0].bsums;
 #pragma unroll
     for (int q = 1; q < PG_MAX_SRC; ++q)
-      if (q < p.ndst && ct * 32 >= p.dstart[q]) { gp = p.dst[q].grad; fp = p.dst[q].fwd; C = p.dst[q].C; st = p.dstart[q]; ac = p.dst[q].act; }
+      if (q < p.ndst && ct * 32 >= p.dstart[q]) { gp = p.dst[q].grad; fp = p.dst[q].fwd; C = p.dst[q].C; st = p.dstart[q]; ac = p.dst[q].act; bq = p.dst[q].bsums; }
     g16[cq] = reinterpret_cast<unsigned short*>(gp); f16[cq] = reinterpret_cast<const unsigned short*>(fp);
     Cd[cq] = C; c0d[cq] = ct * 32 - st; dsl[cq] = act_slope(ac);
+    bsd[cq] = ((cq == 0 ? act0 : act1) ? bq : nullptr);
   }
+  const bool bs_on = bsd[0] != nullptr || bsd[1] != nullptr;       // wave-uniform
+  int run_n = -1;
+  float bs_s[2] = {0.f, 0.f}, bs_q[2] = {0.f, 0.f};
+  const int bslot = (int)(blockIdx.x % PG_STAT_SLOTS);
+  auto bs_flush = [&]() {
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq) {
+      if (bsd[cq] == nullptr || run_n < 0) continue;
+      const double ds = (double)owave_sum(bs_s[cq]), dq = (double)owave_sum(bs_q[cq]);
+      if (lane == 0 && (ds != 0.0 || dq != 0.0)) {
+        atomicAdd(&bsd[cq][((long)run_n * PG_STAT_SLOTS + bslot) * 2], ds);
+        atomicAdd(&bsd[cq][((long)run_n * PG_STAT_SLOTS + bslot) * 2 + 1], dq);
+      }
+      bs_s[cq] = 0.f; bs_q[cq] = 0.f;
+    }
+  };
   char* const xt_ = x_lds + wave * 32 * 128;
   const unsigned xb = (unsigned)(size_t)xt_;
   const int r4 = (lane >> 2) & 3, cql = lane & 3, mb = (lane >> 4) & 1;
@@ -351,6 +375,10 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
   int buf = 0;
   while (true) {
     const int cpix0 = pix0;
+    if (bs_on) {                   // a tile = 32 pixels of one image row: one sample
+      const int cn = cpix0 / HW;
+      if (cn != run_n) { bs_flush(); run_n = cn; }
+    }
     // ---- forward values -> the wave's LDS tile; both gradient operands from the patch
     *reinterpret_cast<uint4*>(xr) = xin00;
     *reinterpret_cast<uint4*>(xr + 16 * 128) = xin01;
@@ -399,6 +427,10 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
 #pragma unroll
         for (int e = 0; e < 4; ++e) r4v[e] = acc[4 * g + e] * act_grad_s(f4[e], dsl[cq]);
         res[cq * 4 + g] = make_uint2(opack_bf16(r4v[0], r4v[1]), opack_bf16(r4v[2], r4v[3]));
+        if (bsd[cq] != nullptr) {      // (sum r, sum r * x_act): sums_mode 2 of pg_norm_bwd_apply_v2
+          bs_s[cq] += (r4v[0] + r4v[1]) + (r4v[2] + r4v[3]);
+          bs_q[cq] += fmaf(r4v[0], f4[0], fmaf(r4v[1], f4[1], fmaf(r4v[2], f4[2], r4v[3] * f4[3])));
+        }
       }
     }
     // ---- weight gradient (k = the tile's 32 pixels)
@@ -451,6 +483,7 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     buf ^= 1;
   }
+  if (bs_on) bs_flush();
   // ---- this workgroup's weight-gradient partial: accw[cq][r] = dW[t = l31][ci = (ct0 + cq) * 32 + 8 (r >> 2) + 4 lhi + (r & 3)]
   if (l31 < ODG_T) {
     float* const dstp = p.wpart + (long)blockIdx.x * p.Ctot * 28;
@@ -569,11 +602,17 @@ extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const f
     PG_LAUNCH_OK("pg_out_conv_bwd_direct (fused MFMA pass)");
     PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, 16), dim3(256), 0, st, workspace, (int)fb, c, dW);
     PG_LAUNCH_OK("pg_out_conv_bwd_direct (reduce)");
+    {
+      bool bs = false;
+      for (int j = 0; j < ndst; ++j) bs = bs || dst[j].bsums != nullptr;
+      pg::last_info() = bs ? PG_INFO_BSUMS : 0;       // the fused pass filled pg_dst_t.bsums (sums_mode 2)
+    }
     // the fused pass wrote dW on `stream`; callers (and the data-parallel reducer: runtime/dp.py orders a gradient range
     // against the weight-gradient stream only) treat dW as a product of `wg_stream` — make that true
     if (wg_stream != nullptr && wst != st) return pg_stream_wait(wg_stream, stream);
     return 0;
   }
+  pg::last_info() = 0;             // streaming passes: pg_dst_t.bsums is not filled
   if (g_is_dpre) PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, k);
   else PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (data gradient)");

@@ -502,22 +502,24 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
         kdim = wCout if transposed else wCin
         PROFILER.launch("conv", 2.0 * N * sp * K * K * kdim * ncnt_,
                         lambda: L.check(L.load().pg_conv(d, L.stream()), "pg_conv"))
-        return
+        return L.load().pg_last_launch_info()
     L.check(L.load().pg_conv(d, L.stream()), "pg_conv")
+    return L.load().pg_last_launch_info()      # tile code, split-K, PG_INFO_BSUMS (thread-local, set by the call above)
 
 
 def _conv_dgrad(gy_src, N, Hi, Wi, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, dsts, ksplit=0):
     """Data-gradient of a layer whose packed weight is W [K][K][Cout][Cin]: contraction over (taps, Cout) of the
     upstream gradient (N,Hi,Wi,Cout) into the layer input's (N,Ho,Wo,Cin), scattered to `dsts` with act'/mask applied.
     (A per-tap pre-transposed weight copy was measured: no gain over reading the [k][n] operand directly.)"""
-    _conv([gy_src], N, Hi, Wi, L.ACT_NONE, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, transposed=True, dsts=dsts,
-          ksplit=ksplit)
+    return _conv([gy_src], N, Hi, Wi, L.ACT_NONE, mode, K, stride, pad, Ho, Wo, W, Cout, Cin, transposed=True, dsts=dsts,
+                 ksplit=ksplit)
 
 
 REPLAY_CTR = None         # device uint64 counter of a HIP-graph replay session (runtime/graph.py); None = host-side scalars
 
 
 NORM_BWD_BF16 = os.environ.get("PG_NO_NORM_BWD_BF16") is None    # ablation switch: separate materialisation of dy
+FUSE_NORM_SUMS = os.environ.get("PG_NO_FUSED_NORM_SUMS") is None   # ablation switch: norm backward's reduce pass always runs
 STEM_EMIT_BF16 = os.environ.get("PG_NO_STEM_EMIT_BF16") is None  # ablation switch: separate materialisation of the level-0 output
 STEM_BF16 = os.environ.get("PG_NO_STEM_BF16") is None     # ablation switch: fp32 first-layer kernels on the bf16 data path
 
@@ -884,12 +886,14 @@ class NormScratch:
     def __init__(self, count, N, device):
         self.sums = torch.zeros(count, N, L.STAT_SLOTS, 2, dtype=torch.float64, device=device)
         self.bsums = torch.zeros(count, N, 2, dtype=torch.float64, device=device)
+        # (round 4) backward sums written by the PRODUCER of a gradient (pg_dst_t.bsums): [N][STAT_SLOTS][2] per norm layer
+        self.fsums = torch.zeros(count, N, L.STAT_SLOTS, 2, dtype=torch.float64, device=device)
         self.used = 0
 
     def take(self):
         i = self.used
         self.used += 1
-        return self.sums[i], self.bsums[i]
+        return self.sums[i], self.bsums[i], self.fsums[i]
 
 
 class NormState:
@@ -897,11 +901,12 @@ class NormState:
 
     def __init__(self, N, device, scratch=None):
         if scratch is not None:
-            self.sums, self.bsums = scratch.take()
+            self.sums, self.bsums, self.fsums = scratch.take()
             self.shared = True
         else:
             self.sums = torch.zeros(N, L.STAT_SLOTS, 2, dtype=torch.float64, device=device)
             self.bsums = torch.zeros(N, 2, dtype=torch.float64, device=device)
+            self.fsums = None
             self.shared = False
         self.mr = torch.zeros(N, 2, dtype=torch.float32, device=device)
         self.aff = torch.zeros(N, 2, dtype=torch.float32, device=device)
@@ -920,22 +925,25 @@ class NormState:
         L.call("pg_norm_finalize", L.ptr(self.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(self.mr),
                L.ptr(self.aff), L.stream())
 
-    def backward(self, dz, y, N, Lr, gamma, dgamma, dbeta, C=0):
+    def backward(self, dz, y, N, Lr, gamma, dgamma, dbeta, C=0, fused=0, beta=None):
         """dz <- dy in place.  On the bf16 data path (C = channels of the tensor, a multiple of 64) the apply kernel also
         writes dy as the bf16 operand the data- / weight-gradient contractions of this layer will ask the pass's operand
-        cache for, so their materialisation pass (4 B read + 2 B write per element) does not run."""
+        cache for, so their materialisation pass (4 B read + 2 B write per element) does not run.
+        fused (round 4): 1 / 2 = the kernel that wrote dz already accumulated the two per-sample sums into `fsums`
+        (pg_dst_t.bsums; sums_mode of pg_norm_bwd_apply_v2) — the reduce pass over (dz, y) does not run."""
         if not self.shared:
             dev_zero(self.bsums)
         _debug_delay()
         io = (1 if dz.dtype == torch.bfloat16 else 0) | (2 if y.dtype == torch.bfloat16 else 0)
         if io:
             # bf16 STORAGE: dz <- dy in place in bf16; the result is the operand of the layer's gradient contractions
-            L.call("pg_norm_bwd_reduce_ex", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), io, L.stream())
+            if not fused:
+                L.call("pg_norm_bwd_reduce_ex", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), io, L.stream())
             bf = None
             if not (io & 1) and PRECISION == 3 and NORM_BWD_BF16 and _BF_CTX is not None and C > 0 and C % 64 == 0:
                 bf = _BF_CTX.reserve(L.ptr(dz), C, L.ACT_NONE, None, None, N * Lr, dz.device)
-            L.call("pg_norm_bwd_apply_io", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
-                   L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), io, L.stream())
+            L.call("pg_norm_bwd_apply_v2", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.fsums if fused else self.bsums), L.ptr(gamma),
+                   L.ptr(beta), N, Lr, L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), io, int(fused), L.stream())
             if (io & 1) and _BF_CTX is not None and C > 0:
                 _BF_CTX.adopt(L.ptr(dz), C, L.ACT_NONE, None, None, dz)
             return
@@ -1046,6 +1054,7 @@ class GeneratorEngine:
         self.drop_stream = "drop"      # mixed into the dropout key (the trainer sets seed / rank / global iteration)
         self.grad_ready_cb = None      # DP hook: called with the parameter keys whose gradients are complete
         self._bf_fwd, self._bf_bwd = BfCache(), BfCache()      # bf16 data path: operand tensors of the last forward / backward
+        self._fsum = {}                # (kind, index) -> sums_mode: norm layers whose backward sums a producer's epilogue wrote
 
     # -------------------------------------------------------------------------------- helpers
     def _ready(self, *prefixes):
@@ -1249,7 +1258,9 @@ class GeneratorEngine:
         dsts = []
         for kind, idx, a in srcs:
             if kind == "dec":
-                dsts.append(L.make_dst(self.d_dz[idx], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=L.ACT_RELU))
+                # the decoder block's output gradient has ONE writer (this launch): it may carry the norm backward's sums
+                bs = self.d_norm[idx].fsums if (self.bfs and FUSE_NORM_SUMS) else None
+                dsts.append(L.make_dst(self.d_dz[idx], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=L.ACT_RELU, bsums=bs))
             elif kind == "warp":
                 dsts.append(L.make_dst(self.w_g[idx], a.C, fwd=a.t, act=L.ACT_RELU))
             else:
@@ -1276,6 +1287,9 @@ class GeneratorEngine:
         assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
         ystr = (3 * H * W, H * W, W, 1)
         dev_zero(self.nscr.bsums)
+        self._fsum = {}
+        if self.bfs and FUSE_NORM_SUMS:
+            dev_zero(self.nscr.fsums)
         # ---- final conv k3s1p1 (+bias, tanh handled by the caller)
         i = self.ndec - 1
         srcs = self._dec_sources(i)
@@ -1300,8 +1314,11 @@ class GeneratorEngine:
                 assert xop is not None, "forward operand of the output convolution is not in the pass cache"
                 gt = {"dec": lambda: self.d_dz[idx], "warp": lambda: self.w_g[idx]}.get(
                     kind, lambda: self.e_dz[{"app": "encoder_app", "pose": "encoder_pose", "enc": "encoder"}[kind]][idx])()
+                # the last block's output gradient is written here and nowhere else: the fused pass may add the norm
+                # backward's sums in their activated-operand form (sums_mode 2; no dropout mask on this source)
+                bs = self.d_norm[idx].fsums if (kind == "dec" and FUSE_NORM_SUMS and a.mask is None) else None
                 dsts.append(L.make_dst(gt, a.C, fwd=xop.reshape(-1)[:gt.numel()].view(gt.shape), act=L.ACT_RELU,
-                                       accumulate=bool(d0.accumulate)))
+                                       accumulate=bool(d0.accumulate), bsums=bs))
             arr = (L.Dst * len(dsts))(*dsts)
             # no im2col'd copy of the gradient: the kernels gather each pixel's 27 values from dpre; the weight-gradient pass
             # goes to the side stream like every other weight gradient
@@ -1310,6 +1327,10 @@ class GeneratorEngine:
                 L.call("pg_stream_wait", _raw(side), L.stream())
             L.call("pg_out_conv_bwd_direct", L.ptr(dpre), 1, L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.ptr(A.g(wkey)),
                    L.ptr(self.fin_ws), self.fin_ws.numel(), ctypes.c_void_p(side.cuda_stream) if side is not None else None, L.stream())
+            if L.load().pg_last_launch_info() & L.INFO_BSUMS:
+                for (kind, idx, a), dd in zip(srcs, dsts):
+                    if dd.bsums:
+                        self._fsum[("d", idx)] = 2
             self._ready("decoder.net.%d." % (i + 1))
         else:
             self._backward_final_fp32(srcs, cin, wkey, i)
@@ -1352,13 +1373,16 @@ class GeneratorEngine:
             wkey = "decoder.net.%d.net.1.weight" % i
             self.d_norm[i].backward(self.d_dz[i], self.d_raw[i], N, ho * wo * self.dec[i],
                                     A.p("decoder.net.%d.net.3.weight" % i), A.g("decoder.net.%d.net.3.weight" % i),
-                                    A.g("decoder.net.%d.net.3.bias" % i), C=self.dec[i])
+                                    A.g("decoder.net.%d.net.3.bias" % i), C=self.dec[i], fused=self._fsum.pop(("d", i), 0),
+                                    beta=A.p("decoder.net.%d.net.3.bias" % i))
             dy = self.d_dz[i]
             _wgrad([a.src() for _, _, a in srcs], N, L.ACT_RELU, dy, self.dec[i], cin, False, hi, wi, ho, wo, 4, 2, 1,
                    A.g(wkey))
             self._ready("decoder.net.%d." % i)
-            _conv_dgrad(Act(dy, self.dec[i]).src(), N, ho, wo, 0, 4, 2, 1, hi, wi, A.p(wkey), self.dec[i], cin,
-                        self._dsts_for(srcs, True))
+            info = _conv_dgrad(Act(dy, self.dec[i]).src(), N, ho, wo, 0, 4, 2, 1, hi, wi, A.p(wkey), self.dec[i], cin,
+                               self._dsts_for(srcs, True))
+            if i > 0 and (info or 0) & L.INFO_BSUMS:
+                self._fsum[("d", i - 1)] = 1
             if i == i_fork:
                 # every warped skip's gradient w_g[0 .. nwarp-1] is complete (block i wrote the deepest one): the warp
                 # backward goes to the auxiliary stream, deepest level first (the first one the encoder chain needs)
@@ -1381,15 +1405,21 @@ class GeneratorEngine:
                 if l < self.nlev - 1:
                     self.e_norm[e][l].backward(dz, self.e_raw[e][l], N, ho * wo * self.enc[l],
                                                A.p("%s.net.%d.net.2.weight" % (e, l)), A.g("%s.net.%d.net.2.weight" % (e, l)),
-                                               A.g("%s.net.%d.net.2.bias" % (e, l)), C=self.enc[l])
+                                               A.g("%s.net.%d.net.2.bias" % (e, l)), C=self.enc[l], fused=self._fsum.pop((e, l), 0))
                 xin = self._enc_act(e, l - 1)
                 _wgrad([xin.src()], N, L.ACT_LEAKY, dz, self.enc[l], self.enc[l - 1], True, ho, wo, hi, wi, 4, 2, 1,
                        A.g(wkey))
                 self._ready("%s.net.%d." % (e, l))
-                _conv_dgrad(Act(dz, self.enc[l]).src(), N, ho, wo, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
-                            self.enc[l - 1],
-                            [L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
-                                        accumulate=True)])
+                # this launch is the LAST writer of level l-1's gradient (skip / warp contributions were written before): it may
+                # carry the sums of that level's norm backward
+                nst = self.e_norm[e][l - 1]
+                bs = nst.fsums if (nst is not None and self.bfs and FUSE_NORM_SUMS) else None
+                info = _conv_dgrad(Act(dz, self.enc[l]).src(), N, ho, wo, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
+                                   self.enc[l - 1],
+                                   [L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
+                                               accumulate=True, bsums=bs)])
+                if bs is not None and (info or 0) & L.INFO_BSUMS:
+                    self._fsum[(e, l - 1)] = 1
         if forked:
             _join_aux()
         for e in self.encs:

@@ -26,7 +26,8 @@ class Src(C.Structure):
 
 class Dst(C.Structure):
     _fields_ = [("grad", C.c_void_p), ("fwd", C.c_void_p), ("aff", C.c_void_p), ("mask", C.c_void_p),
-                ("C", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("flags", C.c_int32)]
+                ("C", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("flags", C.c_int32),
+                ("bsums", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):
@@ -134,6 +135,7 @@ _PROTOS = {
     "pg_materialise_bf16_ex": [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp],
     "pg_norm_bwd_reduce_ex": [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp],
     "pg_norm_bwd_apply_io": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
+    "pg_norm_bwd_apply_v2": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp],
     "pg_warp_mask_max_fwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "pg_warp_mask_max_bwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "pg_debug_conv_timeline": [_vp, _i32],
@@ -230,9 +232,14 @@ def make_src(t, C_, aff=None, mask=None, strides=None):
 DST_GRAD_BF16, DST_FWD_BF16 = 1, 2
 
 
-def make_dst(grad, C_, fwd=None, aff=None, mask=None, act=ACT_NONE, accumulate=False):
-    """grad / fwd may be fp32 or bf16 tensors (bf16 STORAGE on the bf16 data path): the dtype travels in Dst.flags."""
+INFO_BSUMS = 1 << 14     # include/posegan_hip.h PG_INFO_BSUMS
+
+
+def make_dst(grad, C_, fwd=None, aff=None, mask=None, act=ACT_NONE, accumulate=False, bsums=None):
+    """grad / fwd may be fp32 or bf16 tensors (bf16 STORAGE on the bf16 data path): the dtype travels in Dst.flags.
+    bsums: [N][STAT_SLOTS][2] double tensor (zeroed) that the epilogue may fill with the following norm backward's sums."""
     d = Dst()
+    d.bsums = ptr(bsums)
     if grad is not None and torch.is_tensor(grad) and grad.dtype == torch.bfloat16:
         d.flags |= DST_GRAD_BF16
     if fwd is not None and torch.is_tensor(fwd) and fwd.dtype == torch.bfloat16:
