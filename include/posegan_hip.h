@@ -423,6 +423,12 @@ int pg_debug_warp_gather_overflows(int32_t* count);
  * decoder (networks.py:152). */
 int pg_materialise_bf16_ex(const void* x, int32_t x_is_bf16, const float* aff, const float* mask, int32_t act, int32_t N,
                            int64_t HW, int32_t C, void* out_bf16, void* out2_bf16, int32_t act2, void* stream);
+/* (round 4) pg_materialise_bf16_ex with pg_norm_finalize folded in (InstanceNorm3d(1) statistics -> per-sample affine,
+ * networks.py:159,166-169): `sums` [N][PG_STAT_SLOTS][2] are the complete statistics the producing pg_conv accumulated; the kernel
+ * evaluates the affine per workgroup and publishes (mean, rstd) to `mr` and (a, b) to `aff` for the readers in later launches. */
+int pg_materialise_bf16_norm(const void* x, int32_t x_is_bf16, const double* sums, const float* gamma, const float* beta,
+                             int64_t L, float eps, float* mr, float* aff, const float* mask, int32_t act, int32_t N, int64_t HW,
+                             int32_t C, void* out_bf16, void* out2_bf16, int32_t act2, void* stream);
 /* io_flags: bit 0 = dz is bf16, bit 1 = y is bf16 */
 int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float* mr, int32_t N, int64_t L, double* bsums,
                           int32_t io_flags, void* stream);

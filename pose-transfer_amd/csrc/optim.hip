@@ -217,11 +217,36 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
 // IN_BF16: the raw tensor is stored as bf16 (bf16 STORAGE, round 3): 16 bytes in -> 16 bytes out per 8 elements.  out2 (optional):
 // a SECOND activated copy of the same normalised tensor (act2) — an encoder skip is read through LeakyReLU by the next
 // encoder level and through ReLU by the decoder; one pass over the raw tensor writes both operands.
+// (round 4) the per-sample affine of a norm layer whose statistics have just been completed by the producing convolution:
+// norm_finalize_kernel's arithmetic, evaluated by every workgroup for its own sample (32 doubles) — the separate 5 us launch per
+// norm layer goes away; the first workgroup of a sample publishes (mean, rstd) and (a, b) for the later readers (data-gradient
+// epilogues, warp kernels, norm backward: all in later launches).
+struct NormFold {
+  const double* sums;       // [N][PG_STAT_SLOTS][2] or null
+  const float* gamma; const float* beta;
+  long L; float eps;
+  float* mr; float* aff;
+};
+
 template <bool IN_BF16>
 __global__ __launch_bounds__(256) void materialise_bf16_kernel(const void* x, const float* aff, const float* mask, int act,
-                                                               long HW, int C, uint4* out, uint4* out2, int act2) {
+                                                               long HW, int C, uint4* out, uint4* out2, int act2, NormFold nf) {
   const int n = blockIdx.y;
-  const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
+  float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
+  if (nf.sums != nullptr) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < PG_STAT_SLOTS; ++k) { s1 += nf.sums[((long)n * PG_STAT_SLOTS + k) * 2]; s2 += nf.sums[((long)n * PG_STAT_SLOTS + k) * 2 + 1]; }
+    const double mean = s1 / (double)nf.L;
+    double var = s2 / (double)nf.L - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)nf.eps);
+    const double g = (double)nf.gamma[0], bt = (double)nf.beta[0];
+    a = (float)(g * rstd); b = (float)(bt - g * mean * rstd);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      nf.mr[2 * n] = (float)mean; nf.mr[2 * n + 1] = (float)rstd;
+      nf.aff[2 * n] = a; nf.aff[2 * n + 1] = b;
+    }
+  }
   const float slope = act_slope(act), slope2 = act_slope(act2);
   const long per = HW * C / 8;                       // 8 elements (one 16-byte bf16 chunk) per thread-iteration
   uint4* ob = out + (long)n * per;
@@ -332,13 +357,37 @@ extern "C" int pg_materialise_bf16_ex(const void* x, int32_t x_is_bf16, const fl
   PG_REQUIRE(x && out_bf16 && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "pg_materialise_bf16: bad arguments (C %% 8 == 0)");
   long blocks = (HW * C / 8 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  pg::NormFold nf;
+  memset(&nf, 0, sizeof(nf));
   if (x_is_bf16)
     PG_KLAUNCH(pg::materialise_bf16_kernel<true>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
-                       (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2);
+                       (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2, nf);
   else
     PG_KLAUNCH(pg::materialise_bf16_kernel<false>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, aff, mask, act,
-                       (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2);
+                       (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2, nf);
   PG_LAUNCH_OK("pg_materialise_bf16");
+  return 0;
+}
+
+// pg_materialise_bf16_ex with pg_norm_finalize folded in: the deferred affine is computed from the statistics `sums` (complete:
+// the producing convolution has finished) and published to `mr` / `aff` for later readers.
+extern "C" int pg_materialise_bf16_norm(const void* x, int32_t x_is_bf16, const double* sums, const float* gamma, const float* beta,
+                                        int64_t L, float eps, float* mr, float* aff, const float* mask, int32_t act, int32_t N,
+                                        int64_t HW, int32_t C, void* out_bf16, void* out2_bf16, int32_t act2, void* stream) {
+  PG_REQUIRE(x && sums && gamma && beta && mr && aff && out_bf16 && N > 0 && HW > 0 && C > 0 && C % 8 == 0 && L > 0 &&
+             ((size_t)x & 15) == 0 && ((size_t)out_bf16 & 15) == 0 && ((size_t)out2_bf16 & 15) == 0 && ((size_t)mask & 15) == 0,
+             "pg_materialise_bf16_norm: C %% 8 == 0, 16-byte aligned pointers and the statistics of the norm layer required");
+  long blocks = (HW * C / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  pg::NormFold nf;
+  nf.sums = sums; nf.gamma = gamma; nf.beta = beta; nf.L = (long)L; nf.eps = eps; nf.mr = mr; nf.aff = aff;
+  if (x_is_bf16)
+    PG_KLAUNCH(pg::materialise_bf16_kernel<true>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, mask,
+                       act, (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2, nf);
+  else
+    PG_KLAUNCH(pg::materialise_bf16_kernel<false>, dim3((int)blocks, N), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, mask,
+                       act, (long)HW, C, reinterpret_cast<uint4*>(out_bf16), reinterpret_cast<uint4*>(out2_bf16), act2, nf);
+  PG_LAUNCH_OK("pg_materialise_bf16_norm");
   return 0;
 }
 

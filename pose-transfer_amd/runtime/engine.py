@@ -353,6 +353,38 @@ _BF_CTX = None              # bf16 operand cache of the pass that is running (se
 _BF_CTX_X = None            # during a backward pass: the forward pass's cache (activated inputs = weight-gradient operands)
 
 
+# (round 4) pg_norm_finalize folded into the materialisation pass that reads the normalised tensor first: NormState.forward
+# registers the layer here instead of launching the 5 us finalize kernel; the first BfCache.get / get2 that asks for an operand
+# with this affine passes the statistics to pg_materialise_bf16_norm, which computes the affine itself and publishes it.  Every
+# other reader of an affine (warp kernels, fp32 prologues, backward) must call _flush_norm first — or find it already published.
+FOLD_FINALIZE = os.environ.get("PG_NO_FOLD_FINALIZE") is None
+_PENDING_NORM = {}          # data_ptr of the `aff` tensor -> (NormState, gamma, beta, N, Lr)
+
+
+def _flush_norm(aff_ptr):
+    """launch the stand-alone finalize of a norm layer whose affine is still pending (a consumer needs it NOW)"""
+    pend = _PENDING_NORM.pop(int(aff_ptr or 0), None) if _PENDING_NORM else None
+    if pend is not None:
+        st, gamma, beta, N, Lr = pend
+        L.call("pg_norm_finalize", L.ptr(st.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(st.mr), L.ptr(st.aff), L.stream())
+
+
+def _flush_all_norms():
+    for k in list(_PENDING_NORM):
+        _flush_norm(k)
+
+
+def _materialise(ptr, x_bf16, aff, mask, act, N, HW, C, out, out2=None, act2=0):
+    """pg_materialise_bf16_ex, or its form with the pending finalize of `aff`'s norm layer folded in"""
+    pend = _PENDING_NORM.pop(int(aff or 0), None) if (_PENDING_NORM and aff) else None
+    if pend is not None:
+        st, gamma, beta, n_, Lr = pend
+        L.call("pg_materialise_bf16_norm", ptr, x_bf16, L.ptr(st.sums), L.ptr(gamma), L.ptr(beta), Lr, NORM_EPS, L.ptr(st.mr),
+               L.ptr(st.aff), mask, act, N, HW, C, out, out2, act2, L.stream())
+    else:
+        L.call("pg_materialise_bf16_ex", ptr, x_bf16, aff, mask, act, N, HW, C, out, out2, act2, L.stream())
+
+
 class BfCache:
     """bf16 operand tensors of ONE engine pass, keyed by (tensor, channels, activation, deferred affine, mask): a tensor
     that feeds several contractions (forward + weight gradient, data gradient + weight gradient) is converted ONCE per
@@ -403,7 +435,7 @@ class BfCache:
         if src is not None and act == L.ACT_NONE and not aff and not mask:
             return self.adopt(ptr, C, act, aff, mask, src)
         b = self._buffer(k, N * HW * C, dev)
-        L.call("pg_materialise_bf16_ex", ptr, 1 if src is not None else 0, aff, mask, act, N, HW, C, L.ptr(b), None, 0, L.stream())
+        _materialise(ptr, 1 if src is not None else 0, aff, mask, act, N, HW, C, L.ptr(b))
         self.valid.add(k)
         return b
 
@@ -414,8 +446,7 @@ class BfCache:
         if k1 in self.valid and k2 in self.valid:
             return
         b1, b2 = self._buffer(k1, N * HW * C, dev), self._buffer(k2, N * HW * C, dev)
-        L.call("pg_materialise_bf16_ex", ptr, 1 if _is_bf16_ptr(ptr) else 0, aff, mask, act, N, HW, C, L.ptr(b1), L.ptr(b2), act2,
-               L.stream())
+        _materialise(ptr, 1 if _is_bf16_ptr(ptr) else 0, aff, mask, act, N, HW, C, L.ptr(b1), L.ptr(b2), act2)
         self.valid.add(k1)
         self.valid.add(k2)
 
@@ -431,8 +462,7 @@ def _bf16_sources(srcs, N, Hi, Wi, act, dev):
             need = N * Hi * Wi * s.C
             if pool[j] is None or pool[j].numel() < need:
                 pool[j] = torch.empty(need, dtype=torch.bfloat16, device=dev)
-            L.call("pg_materialise_bf16_ex", s.ptr, 1 if _is_bf16_ptr(s.ptr) else 0, s.aff, s.mask, act, N, Hi * Wi, s.C,
-                   L.ptr(pool[j]), None, 0, L.stream())
+            _materialise(s.ptr, 1 if _is_bf16_ptr(s.ptr) else 0, s.aff, s.mask, act, N, Hi * Wi, s.C, L.ptr(pool[j]))
             t = pool[j]
         q = L.Src()
         q.ptr, q.C = L.ptr(t), s.C
@@ -462,6 +492,8 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
             if any(_is_bf16_ptr(s.ptr) for s in srcs) or (isinstance(out, torch.Tensor) and out.dtype == torch.bfloat16):
                 raise RuntimeError("bf16 storage: this convolution is not eligible for the bf16 data path (channels %s -> %d)"
                                    % ([s.C for s in srcs], ncols))
+            for s_ in srcs:          # the fp32 prologue reads the deferred affine itself
+                _flush_norm(s_.aff)
             prec = 0
     d = L.ConvDesc()
     for i, s in enumerate(srcs):
@@ -922,6 +954,10 @@ class NormState:
             if not self.shared:
                 dev_zero(self.sums)
             L.call("pg_norm_stats", L.ptr(y), N, Lr, L.ptr(self.sums), L.stream())
+        if FOLD_FINALIZE and PRECISION == 3 and _BF_CTX is not None and y.is_cuda:
+            # bf16 data path: the first reader of the normalised tensor is a materialisation pass — it finalizes (see _PENDING_NORM)
+            _PENDING_NORM[self.aff.data_ptr()] = (self, gamma, beta, N, Lr)
+            return
         L.call("pg_norm_finalize", L.ptr(self.sums), L.ptr(gamma), L.ptr(beta), N, Lr, NORM_EPS, L.ptr(self.mr),
                L.ptr(self.aff), L.stream())
 
@@ -1155,6 +1191,8 @@ class GeneratorEngine:
         for e in self.encs:
             self._forward_encoder(e, inp, bfs, npx, 0, cut)
         if cut < self.nlev:
+            for l in range(self.nwarp):      # the deepest warped level's affine is still pending: publish it on THIS stream, before the fork
+                _flush_norm(L.ptr(self._enc_act("encoder_app", l).aff))
             with _on_aux():
                 self._forward_warps(bfs)
             for e in self.encs:
@@ -1162,6 +1200,7 @@ class GeneratorEngine:
         else:
             self._forward_warps(bfs)
         self._forward_rest(inp, bfs, joined=cut >= self.nlev)
+        _flush_all_norms()
         return self.out
 
     def _forward_encoder(self, e, inp, bfs, npx, l0, l1):
@@ -1204,6 +1243,7 @@ class GeneratorEngine:
         N, H, W = self.N, self.H, self.W
         for l in range(self.nwarp):
             a = self._enc_act("encoder_app", l)
+            _flush_norm(L.ptr(a.aff))        # (the warp may run before the level's materialisation pass: auxiliary stream)
             if bfs:     # bf16 in, relu(out) bf16 out: the stored tensor IS the decoder's operand (and its ReLU-derivative input)
                 L.call("pg_warp_mask_max_fwd_io", L.ptr(a.t), L.ptr(a.aff), L.ptr(self.warps), L.ptr(self.lvl_masks[l]), N,
                        self.T, self.enc[l], self.hw[l][0], self.hw[l][1], H, W, self.align, L.ptr(self.w_out[l]),
@@ -1548,6 +1588,7 @@ class DiscriminatorEngine:
             if j < self.nblk - 1:
                 self.norm[j].forward(self.raw[j], self.M, self.hs[j] * self.ws[j] * self.chans[j],
                                      A.p("net.%d.net.2.weight" % j), A.p("net.%d.net.2.bias" % j), have_stats=True)
+        _flush_all_norms()
         return self.raw[-1].view(self.M, self.K)
 
     def backward(self, dlogits, need_wgrad=True, image_grad=None):

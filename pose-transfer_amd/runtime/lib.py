@@ -134,6 +134,7 @@ _PROTOS = {
     "pg_transpose_f32": [_vp, _i32, _i32, _vp, _i32, _vp],
     "pg_materialise_bf16_ex": [_vp, _i32, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp],
     "pg_norm_bwd_reduce_ex": [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp],
+    "pg_materialise_bf16_norm": [_vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp],
     "pg_norm_bwd_apply_io": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
     "pg_norm_bwd_apply_v2": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp],
     "pg_warp_mask_max_fwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],

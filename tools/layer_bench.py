@@ -50,12 +50,14 @@ def main():
         kind, h, w, srcC, cout = LAYERS[name]
         cin = sum(srcC)
         ho, wo = (h // 2, w // 2) if kind == "conv" else (2 * h, 2 * w)
-        srcs = [E._reg_bf16(torch.randn(N, h, w, c, device=DEV).to(bf)) for c in srcC]
+        zero = os.environ.get("PG_LB_ZERO") == "1"       # all-zero operands: same instruction stream, far less switching power
+        rnd = (lambda *sh: torch.zeros(*sh, device=DEV)) if zero else (lambda *sh: torch.randn(*sh, device=DEV))
+        srcs = [E._reg_bf16(rnd(N, h, w, c).to(bf)) for c in srcC]
         acts = [E.Act(s, c) for s, c in zip(srcs, srcC)]
-        W = torch.randn(K, K, cout, cin, device=DEV) * 0.05
+        W = rnd(K, K, cout, cin) * 0.05
         dW = torch.zeros_like(W)
         out = E._reg_bf16(torch.empty(N, ho, wo, cout, device=DEV, dtype=bf))
-        gy = E._reg_bf16(torch.randn(N, ho, wo, cout, device=DEV).to(bf))
+        gy = E._reg_bf16(rnd(N, ho, wo, cout).to(bf))
         dz = [E._reg_bf16(torch.empty_like(s)) for s in srcs]
         stats = torch.zeros(N * 64, dtype=torch.float64, device=DEV)
         act = L.ACT_NONE       # the operands ARE the activated bf16 tensors: no materialisation pass inside the timed call
