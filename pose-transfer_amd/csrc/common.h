@@ -59,8 +59,8 @@ struct Env {
 #ifdef PG_TIMING_EXPERIMENTS
     const char* names[] = {"PG_DEBUG_OPERAND_A", "PG_DEBUG_OPERAND_B", "PG_DEBUG_ONE_KTILE", "PG_DEBUG_CONV_TIMELINE",
                            "PG_DEBUG_EPI_NOFWD", "PG_DEBUG_EPI_NOSTORE", "PG_DEBUG_EPI_NOACC", "PG_DEBUG_NO_KBARRIER",
-                           "PG_DEBUG_NO_KDMA", "PG_DEBUG_A_EVERY_4TH"};
-    for (int i = 0; i < 10; ++i) if (on(names[i])) debug_bits |= 2u << i;
+                           "PG_DEBUG_NO_KDMA", "PG_DEBUG_A_EVERY_4TH", "PG_DEBUG_HALF_A_FETCH", "PG_DEBUG_NO_FETCH", "PG_DEBUG_A_EVERY_2ND"};
+    for (int i = 0; i < 13; ++i) if (on(names[i])) debug_bits |= 2u << i;
 #endif
   }
 };

@@ -1,0 +1,375 @@
+// 256-row bf16 implicit-GEMM convolution with TAP-PAIR SHARING of the A operand (round 4).
+//
+// conv_bf16_big_kernel (igemm_bf16.hip) moves one A tile (256 rows x 64 channels) and one B tile global -> LDS per K tile.  Timing
+// experiments on that kernel (the same instruction stream with pieces removed, random and all-zero operands)
+// say where a launch's time goes on this chip: the matrix pipe is POWER-limited (a K loop of nothing but MFMAs reaches 1340 TFLOP/s
+// on random data, 1640 on zeros), LDS operand reads cost 1 - 3 %, the per-tile barrier 1 - 5 %, and the global -> LDS DMA 21 - 23 %,
+// in proportion to the number of DMA instructions.  So the lever is DMA volume per FLOP.
+//
+// Two taps of a k4 s2 convolution / transposed convolution that differ only by ONE STEP ALONG X read almost the same pixels: tap
+// (dy, dx + si) of output-grid position (qy, qx) is tap (dy, dx) of position (qy, qx + 1).  This kernel orders the K loop
+// (tap pair, channel chunk, tap of the pair) and DMAs ONE A tile per (pair, chunk): LDS row rho holds the pixel of "slot" k of an
+// image row of the tile for the pair's first tap, with Gx + 1 slots per image row (slot Gx = what the last position's second tap
+// reads), so the second tap of tile row r is simply LDS row rho(r) + 1.  rho(r) = r + (number of image-row starts in the tile
+// before r): at most 16 (8) extra rows on a 256 (512) row tile.  A-tile DMA instructions per tap: 32 -> 17; all DMA instructions of
+// a 256 x 256 launch - 23 %, of a 256 x 128 launch - 31 %, of a 512 x 64 launch - 43 %.  The operand stages become two rings: A
+// (2 x 34 KB, switched every second K tile) and B (2 x 32 KB, every tile).
+//
+// Everything else is conv_bf16_big_kernel: 8 waves, wave tile 128 x 64 (64 x 64), v_mfma_f32_32x32x16_bf16, chunk-swizzled unpadded
+// LDS images, one barrier per K tile in front of the last k-step's MFMAs, the shared epilogues (igemm_bf16_epi.h).  Because an
+// LDS row of A is not a tile row's private copy any more (the swizzle is a function of the LDS row), an A fragment address is
+// per (lane, tap of the pair, M tile): two VALU instructions per ds_read_b128 instead of an immediate offset.
+// Host conditions (conv_impl): every phase's taps pair up, ksplit = 1, Gx large enough for the extra rows.
+#include "igemm_bf16_epi.h"
+
+namespace pg {
+
+struct ARow {      // LDS row of the A ring -> the input pixel it holds, before the tap offset
+  int n;           // sample, -1 = beyond the problem
+  short iy, ix;    // qy * si, slot * si
+};
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
+  constexpr int BM = (BN == 64) ? 512 : 256;
+  constexpr int WGN = BN / 64, WGM = 8 / WGN;
+  constexpr int TM = BM / WGM / 32, TN = 2;
+  constexpr int ROWB = 128;
+  constexpr int AXR = (BM == 512) ? 8 : 16;              // extra LDS rows of an A tile: one per image row that starts inside the tile (+1)
+  constexpr int AROWS = BM + AXR;
+  constexpr int A_NI = AROWS / 8;                        // wave DMA instructions per A tile (8 rows of 128 B each)
+  constexpr int A_PASS = (A_NI + 7) / 8, B_PASS = BN / 64;
+  constexpr int A_ST = AROWS * ROWB, B_ST = BN * ROWB;
+  constexpr int B_OFF = 2 * A_ST;                        // [A ring: 2 stages][B ring: 2 stages]
+  constexpr int OPS = 2 * (A_ST + B_ST);
+  constexpr int ROWS_OFF = OPS, AROW_OFF = ROWS_OFF + BM * (int)sizeof(RowB), TAPS_OFF = AROW_OFF + AROWS * (int)sizeof(ARow);
+  constexpr int STAT_OFF = (TAPS_OFF + MAXTAP * 4 + 7) & ~7, STAT_N = 8;
+  static_assert(8 * (32 * (32 * TN + 4)) * 4 <= OPS && AROWS % 8 == 0, "epilogue tiles / DMA rows");
+  static_assert(STAT_OFF + STAT_N * 16 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) char smem[STAT_OFF + STAT_N * 2 * 8];
+  RowB* rows = reinterpret_cast<RowB*>(smem + ROWS_OFF);
+  int* taps_l = reinterpret_cast<int*>(smem + TAPS_OFF);
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_swizzle & 1) {          // as conv_bf16_big_kernel: (phase, N tile, M tile) order per XCD
+    const int mt = (int)gridDim.x, nt = (int)gridDim.y, P = (int)gridDim.z;
+    const int L = bx + mt * (by + nt * bz);
+    const int xcd = L & 7, j = L >> 3;
+    bz = j % P;
+    const int r = j / P;
+    by = r % nt;
+    bx = (r / nt) * 8 + xcd;
+  }
+  const int phase = bz;             // host: ksplit == 1, no tap batch
+  float* const out_g = p.out;
+  const int m0 = bx * BM, nb0 = by * BN;
+  const int ntap = p.ntap[phase];
+  const int gx = p.Gx;
+  const int qx0 = m0 % gx, R0 = m0 / gx;
+
+  if (tid >= 64 && tid < 64 + STAT_N * 2) reinterpret_cast<double*>(smem + STAT_OFF)[tid - 64] = 0.0;
+  if (tid < MAXTAP)
+    taps_l[tid] = (p.dy[phase][tid] & 0xff) | ((p.dx[phase][tid] & 0xff) << 8) | ((int)p.wtap[phase][tid] << 16);
+  if (tid < BM) {
+    RowB ri;
+    const int m = m0 + tid;
+    ri.n = -1; ri.opix = 0; ri.iy = 0; ri.ix = 0; ri.oy = 0; ri.ox = 0;
+    if (m < p.M) {
+      const int gg = p.Gy * p.Gx;
+      const int n = m / gg;
+      const int rem = m - n * gg;
+      const int qy = rem / p.Gx;
+      const int qx = rem - qy * p.Gx;
+      const int oy = qy * p.so + p.phy[phase];
+      const int ox = qx * p.so + p.phx[phase];
+      if (oy < p.Ho && ox < p.Wo) {
+        ri.n = n; ri.iy = (short)(qy * p.si); ri.ix = (short)(qx * p.si); ri.oy = (short)oy; ri.ox = (short)ox;
+        ri.opix = (n * p.Ho + oy) * p.Wo + ox;
+      }
+    }
+    rows[tid] = ri;
+  }
+  for (int rho = tid; rho < AROWS; rho += 512) {          // LDS row -> (local image row j, slot k): rho + qx0 = j (Gx + 1) + k
+    const int t = rho + qx0;
+    const int j = t / (gx + 1), k = t - j * (gx + 1);
+    const int Rg = R0 + j;
+    const int n = Rg / p.Gy, qy = Rg - n * p.Gy;
+    ARow a;
+    a.n = n < p.N ? n : -1; a.iy = (short)(qy * p.si); a.ix = (short)(k * p.si);
+    reinterpret_cast<ARow*>(smem + AROW_OFF)[rho] = a;
+  }
+  __syncthreads();
+
+  const int cpt = p.Ctot / 64;                      // channel chunks = K tiles per tap
+  const int npc = (ntap >> 1) * cpt;                // (tap pair, chunk) steps; two K tiles each
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm0 = (wave / WGN) * (TM * 32);
+  const int wn0 = (wave % WGN) * (TN * 32);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // ---- DMA loader state
+  const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
+  const char* const wp = uniform_ptr(reinterpret_cast<const char*>(p.W));
+  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);   // source chunk of this lane's LDS slot (swizzle by LDS row, rows 64 i + (tid >> 3))
+  // per-row source: 32-bit byte offset against a wave-uniform base (the source tensor of the chunk / the weights) + a validity bit
+  // (invalid rows read the zero page) — 64-bit pointers per row cost the 256 x 256 variant its registers (host: tensors < 4 GiB)
+  unsigned pa[A_PASS], pb[B_PASS];
+  unsigned pa_ok = 0, pb_ok = 0;
+  const char* a_src = zero_pg;                       // uniform: source tensor of the A cursor's chunk
+  long wdelta = 0;                                   // uniform: byte offset from the pair's first to its second tap in W
+  int a_g = 0, a_ci = 0, a_left = npc;               // A cursor: next (pair, chunk) to load; steps not yet loaded
+  int b_g = 0, b_ci = 0, b_left = npc;               // B cursor: next (pair, chunk); its two tiles are issued one by one
+  auto rebuild_a = [&]() __attribute__((always_inline)) {
+    const int tp = lds_rd32_now(lds0 + TAPS_OFF + (2 * a_g) * 4);
+    const int dyv = (int)(signed char)(tp & 0xff), dxv = (int)(signed char)((tp >> 8) & 0xff);
+    const int cc = a_ci * 64;
+    const char* sp = reinterpret_cast<const char*>(p.src[0].ptr);
+    int sC = p.src[0].C, cs = 0;
+#pragma unroll
+    for (int q = 1; q < PG_MAX_SRC; ++q)
+      if (q < p.nsrc && cc >= p.cstart[q]) { sp = reinterpret_cast<const char*>(p.src[q].ptr); sC = p.src[q].C; cs = p.cstart[q]; }
+    a_src = uniform_ptr(sp);
+    const int cl = cc - cs + chunk * 8;
+    pa_ok = 0;
+    int rn[A_PASS], ryx[A_PASS];
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const int rho = min((tid >> 3) + 64 * i, AROWS - 1);
+      const unsigned ra = lds0 + AROW_OFF + (unsigned)(rho * (int)sizeof(ARow));
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4" : "=&v"(rn[i]), "=&v"(ryx[i]) : "v"(ra));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const int iy = (int)(short)(ryx[i] & 0xffff) + dyv, ix = (ryx[i] >> 16) + dxv;
+      const bool ok = (rn[i] >= 0) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+      pa[i] = ok ? ((unsigned)((rn[i] * p.Hi + iy) * p.Wi + ix) * (unsigned)sC + (unsigned)cl) * 2u : 0u;
+      pa_ok |= (ok ? 1u : 0u) << i;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  };
+  auto advance_a = [&]() __attribute__((always_inline)) {            // after a step's A tile was issued
+    if (--a_left <= 0) return;
+    if (++a_ci == cpt) { a_ci = 0; ++a_g; rebuild_a(); return; }
+    bool src_edge = false;
+#pragma unroll
+    for (int q = 1; q < PG_MAX_SRC; ++q) if (q < p.nsrc && a_ci * 64 == p.cstart[q]) src_edge = true;
+    if (src_edge) { rebuild_a(); return; }
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) pa[i] += ROWB;       // (invalid rows: the offset is not used)
+  };
+  auto rebuild_b = [&]() __attribute__((always_inline)) {
+    const int tp0 = lds_rd32_now(lds0 + TAPS_OFF + (2 * b_g) * 4), tp1 = lds_rd32_now(lds0 + TAPS_OFF + (2 * b_g + 1) * 4);
+    const int base = __builtin_amdgcn_readfirstlane((tp0 >> 16) * p.wCout);
+    wdelta = (long)__builtin_amdgcn_readfirstlane((tp1 >> 16) - (tp0 >> 16)) * p.wCout * p.wCin * 2;
+    pb_ok = 0;
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      const int n = nb0 + (tid >> 3) + 64 * i;
+      const bool ok = n < p.n_cnt;
+      pb[i] = ok ? ((unsigned)(base + p.n_off + n) * (unsigned)p.wCin + (unsigned)(b_ci * 64 + chunk * 8)) * 2u : 0u;
+      pb_ok |= (ok ? 1u : 0u) << i;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  };
+  auto advance_b = [&]() __attribute__((always_inline)) {            // after BOTH tiles of a step were issued
+    if (--b_left <= 0) return;
+    if (++b_ci == cpt) { b_ci = 0; ++b_g; rebuild_b(); return; }
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) pb[i] += ROWB;
+  };
+  auto issue_a = [&](int stage) __attribute__((always_inline)) {
+    float* const As = reinterpret_cast<float*>(smem + stage * A_ST);
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i)
+      if (i * 8 + wave < A_NI) {      // wave-uniform: the last pass covers only the first extra rows
+        const char* src = ((pa_ok >> i) & 1u) ? a_src + pa[i] : zero_pg + (tid & 7) * 16;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), As + (i * 8 + wave) * 256, 16, 0, 0);
+      }
+  };
+  auto issue_b = [&](int stage, int second) __attribute__((always_inline)) {
+    float* const Bs = reinterpret_cast<float*>(smem + B_OFF + stage * B_ST);
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      const char* src = ((pb_ok >> i) & 1u) ? wp + (second ? wdelta : 0) + pb[i] : zero_pg + (tid & 7) * 16;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), Bs + (i * 8 + wave) * 256, 16, 0, 0);
+    }
+  };
+
+  // ---- operand fetch.  A: LDS row of tile row r: rho(r) = r + (qx0 + r) / Gx (+ 1 for the pair's second tap).  The 16-byte slot
+  // of k-step ks and lane half lhi is (2 ks + lhi) ^ swizzle(LDS row) = slot(ks = 0) ^ (2 ks): ONE address per (tap of the pair, M
+  // tile) for ks = 0, and address(ks) = address(0) ^ (ks << 5).  The xor sits in the asm statement of its read (as a separate
+  // expression the compiler hoists all 24 loop-invariant results out of the K loop: 260 spilled registers); ring stages and the B
+  // tile's second 32 rows are instruction offsets.
+  constexpr bool BIGA = A_ST > 60000;                 // 512-row tiles: the second A stage is beyond the 16-bit instruction offset
+  unsigned abase[BIGA ? 2 : 1][2][TM];                // [ring stage (512-row tiles only)][tap of the pair][M tile]
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm0 + 32 * i + l31;
+    const int rho = r + (qx0 + r) / gx;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = rho + j, s = (row >> 1) & 7;
+      abase[0][j][i] = lds0 + (unsigned)(row * ROWB) + (unsigned)((lhi ^ s) << 4);
+      if constexpr (BIGA) abase[1][j][i] = abase[0][j][i] + (unsigned)A_ST;
+    }
+  }
+  const int swr = (l31 >> 1) & 7;
+  const unsigned fb0 = lds0 + B_OFF + (unsigned)((wn0 + l31) * ROWB) + (unsigned)((lhi ^ swr) * 16);
+  // AS / BSG: ring stages, JT: tap of the pair, KS: k-step — all compile-time
+  auto fetch = [&](auto asg, auto jt, auto bsg, auto ksc, f32x4 (&va)[TM], f32x4 (&vb)[TN]) __attribute__((always_inline)) {
+    constexpr int AS = decltype(asg)::value, JT = decltype(jt)::value, BSG = decltype(bsg)::value, KS = decltype(ksc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      unsigned t;
+#ifdef PG_PAIR_NOXOR
+      asm volatile("ds_read_b128 %0, %2 offset:%4" : "=v"(va[i]), "=&v"(t) : "v"(abase[BIGA ? AS : 0][JT][i]), "n"(KS * 32), "n"(BIGA ? 0 : AS * A_ST));
+#else
+      asm volatile("v_xor_b32 %1, %3, %2\n\tds_read_b128 %0, %1 offset:%4"
+                   : "=v"(va[i]), "=&v"(t) : "v"(abase[BIGA ? AS : 0][JT][i]), "n"(KS * 32), "n"(BIGA ? 0 : AS * A_ST));
+#endif
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      unsigned t;
+#ifdef PG_PAIR_NOXOR
+      asm volatile("ds_read_b128 %0, %2 offset:%4" : "=v"(vb[j]), "=&v"(t) : "v"(fb0), "n"(KS * 32), "n"(BSG * B_ST + j * 32 * ROWB));
+#else
+      asm volatile("v_xor_b32 %1, %3, %2\n\tds_read_b128 %0, %1 offset:%4"
+                   : "=v"(vb[j]), "=&v"(t) : "v"(fb0), "n"(KS * 32), "n"(BSG * B_ST + j * 32 * ROWB));
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfmas = [&](const f32x4 (&va)[TM], const f32x4 (&vb)[TN]) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va[i]), __builtin_bit_cast(bf16x8, vb[j]),
+                                                             acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr int NRD = TM + TN;
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 3> I3;
+
+  // ---- prologue: step 0's A tile -> A stage 0, its first B tile -> B stage 0
+  rebuild_a();
+  issue_a(0);
+  advance_a();
+  rebuild_b();
+  issue_b(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  // in flight before the loop: step 0's second B tile, step 1's A tile
+  issue_b(1, 1);
+  advance_b();
+  if (npc > 1) { issue_a(1); advance_a(); }
+  f32x4 va0[TM], vb0[TN], va1[TM], vb1[TN];
+  fetch(I0{}, I0{}, I0{}, I0{}, va0, vb0);
+  bool pend_a = false;               // an A tile whose ring stage was released at the last switch is still to be issued
+  int pend_stage = 0;
+  // one (pair, chunk) step = two K tiles; AS = its A ring stage (compile-time: the loop below alternates the two instantiations)
+  // DMA placement (measured: the position right behind the tile-switch barrier, where all eight waves issue at once and the next
+  // tile's first operand fetch follows, is the expensive one): a released ring stage is refilled behind the FIRST k-step of the next
+  // tile (B) and behind its SECOND k-step (A, every other tile) — PG_PAIR_DMA_AT_BARRIER=1 builds the earlier placement.
+#ifndef PG_PAIR_DMA_AT_BARRIER
+#define PG_PAIR_DMA_AT_BARRIER 0
+#endif
+#ifndef PG_PAIR_A_AT_BARRIER
+#define PG_PAIR_A_AT_BARRIER 1     // the A tile (every other switch) right behind the barrier, B tiles behind the first k-step
+#endif
+  int pend_b = -1;                   // B ring stage to refill behind the next first k-step (-1: none); its tile is `pend_b`'s tap of the B cursor
+  auto step = [&](auto asg, int pc) __attribute__((always_inline)) {
+    constexpr int AS = decltype(asg)::value;
+    typedef std::integral_constant<int, AS> IA;
+    typedef std::integral_constant<int, AS ^ 1> IN;
+    const bool more = pc + 1 < npc;
+    // ================= first tile of the step: tap 2g, B stage 0
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IA{}, I0{}, I0{}, I1{}, va1, vb1);
+    PGB_LDS_WAIT(NRD);
+    mfmas(va0, vb0);
+    if (pend_b == 1) { issue_b(1, 1); advance_b(); pend_b = -1; }          // B stage 1 was released at the last switch
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IA{}, I0{}, I0{}, I2{}, va0, vb0);
+    PGB_LDS_WAIT(NRD);
+    mfmas(va1, vb1);
+    if (!PG_PAIR_A_AT_BARRIER && pend_a) { issue_a(pend_stage); advance_a(); pend_a = false; }      // the A stage released at the last switch
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IA{}, I0{}, I0{}, I3{}, va1, vb1);
+    PGB_LDS_WAIT(NRD);
+    mfmas(va0, vb0);
+    // tile switch: this wave's reads of B stage 0 have landed, its share of the next tile's operands has landed; after the
+    // barrier both hold for every wave, and B stage 0 is free: the next step's first B tile goes there
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      if (PG_PAIR_DMA_AT_BARRIER) issue_b(0, 0); else pend_b = 0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IA{}, I1{}, I1{}, I0{}, va0, vb0);
+    mfmas(va1, vb1);
+    // ================= second tile: tap 2g + 1 = the same A stage one LDS row further, B stage 1
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IA{}, I1{}, I1{}, I1{}, va1, vb1);
+    PGB_LDS_WAIT(NRD);
+    mfmas(va0, vb0);
+    if (pend_b == 0) { issue_b(0, 0); pend_b = -1; }                       // B stage 0 was released at the last switch
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IA{}, I1{}, I1{}, I2{}, va0, vb0);
+    PGB_LDS_WAIT(NRD);
+    mfmas(va1, vb1);
+    fetch(IA{}, I1{}, I1{}, I3{}, va1, vb1);
+    PGB_LDS_WAIT(NRD);
+    mfmas(va0, vb0);
+    // tile switch: B stage 1 and A stage AS are free
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      if (PG_PAIR_DMA_AT_BARRIER) { issue_b(1, 1); advance_b(); } else pend_b = 1;
+    }
+    if (pc + 2 < npc) {
+      if (PG_PAIR_A_AT_BARRIER) { issue_a(AS); advance_a(); }
+      else { pend_a = true; pend_stage = AS; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch(IN{}, I0{}, I0{}, I0{}, va0, vb0);
+    mfmas(va1, vb1);
+  };
+  for (int pc = 0; pc < npc; pc += 2) {
+    step(I0{}, pc);
+    if (pc + 1 < npc) step(I1{}, pc + 1);
+  }
+
+  // ------------------------------------------------------------------ epilogue (shared; rows outside the problem are NOT zero here)
+  big_epilogue<TM, TN, STAT_OFF, STAT_N>(p, acc, smem, rows, tid, m0, nb0, wm0, wn0, bx, by, bz, 0, out_g, true, false, [](int) {});
+}
+
+void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
+  if (bn == 256) PG_KLAUNCH((conv_bf16_pair_kernel<256>), grid, dim3(512), 0, st, k);
+  else if (bn == 64) PG_KLAUNCH((conv_bf16_pair_kernel<64>), grid, dim3(512), 0, st, k);
+  else PG_KLAUNCH((conv_bf16_pair_kernel<128>), grid, dim3(512), 0, st, k);
+}
+
+}  // namespace pg

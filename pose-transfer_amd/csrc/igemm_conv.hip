@@ -1460,6 +1460,7 @@ static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma,
 }  // namespace pg
 
 namespace pg { void launch_conv_bf16_big(const ConvK& k, int bn, dim3 grid, hipStream_t st); }   // igemm_bf16.hip
+namespace pg { void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st); }  // igemm_bf16_pair.hip
 
 using namespace pg;
 
@@ -1735,6 +1736,45 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
         if (want) { code = 129; mtb = mt5; wgs = (long)mt5 * ntb * k.nphase; }
       }
       if (wgs >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr) {
+        // (round 4) tap-pair sharing of the A tile (igemm_bf16_pair.hip): every phase's taps must pair up as (dy, dx), (dy, dx + si)
+        // — reordered here so that taps 2g, 2g + 1 are pair g — and the tile's extra LDS rows (one per image row) must suffice
+        bool pair = false;
+        {
+          const char* pe = getenv("PG_BIG_PAIR");          // "0" / "1": read per launch (the test-suite flips it inside one process)
+          const int bm_p = bn == 64 ? 512 : 256, axr = bn == 64 ? 8 : 16;
+          bool want = pe ? pe[0] != '0' : true;
+          want = want && k.Gx >= 2 && (bm_p + k.Gx - 2) / k.Gx + 1 <= axr && k.Wi * 1 < 32000 && k.Hi < 32000;
+          if (want) {
+            ConvK kk = k;
+            bool ok = true;
+            for (int ph = 0; ph < k.nphase && ok; ++ph) {
+              const int nt_ = k.ntap[ph];
+              if (nt_ < 2 || (nt_ & 1)) { ok = false; break; }
+              int o[MAXTAP], used[MAXTAP];
+              for (int a = 0; a < nt_; ++a) { o[a] = a; used[a] = 0; }
+              for (int a = 1; a < nt_; ++a)           // insertion sort by (dy, dx)
+                for (int b = a; b > 0; --b) {
+                  const int x = o[b - 1], y = o[b];
+                  if (k.dy[ph][x] > k.dy[ph][y] || (k.dy[ph][x] == k.dy[ph][y] && k.dx[ph][x] > k.dx[ph][y])) { o[b - 1] = y; o[b] = x; }
+                }
+              int w = 0;
+              for (int a = 0; a < nt_ && ok; ++a) {
+                if (used[a]) continue;
+                int b = a + 1;
+                while (b < nt_ && (used[b] || k.dy[ph][o[b]] != k.dy[ph][o[a]] || k.dx[ph][o[b]] != k.dx[ph][o[a]] + k.si)) ++b;
+                if (b >= nt_) { ok = false; break; }
+                used[a] = used[b] = 1;
+                const int pr[2] = {o[a], o[b]};
+                for (int e = 0; e < 2; ++e) {
+                  kk.dy[ph][w] = k.dy[ph][pr[e]]; kk.dx[ph][w] = k.dx[ph][pr[e]]; kk.wtap[ph][w] = k.wtap[ph][pr[e]];
+                  ++w;
+                }
+              }
+            }
+            if (ok) { k = kk; pair = true; }
+          }
+        }
+        if (pair && code == 129) { code = 128; mtb = cdiv(k.M, 256); }          // 128 columns: the paired 256 x 128 tile instead of 512 x 128 x 32
         k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && !env().no_xcd_swizzle) ? 1 : 0;
         k.xcd_swizzle |= (int)env().debug_bits;       // zero unless built with -DPG_TIMING_EXPERIMENTS
         if (k.dst_io == 1 && k.Gy * k.Gx < 32) k.dst_io = 2;      // the pipelined bf16 scatter assumes <= 2 samples per 32 rows
@@ -1749,10 +1789,11 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
           }
         if (!(bs_any && bs_ok))
           for (int j = 0; j < PG_MAX_SRC; ++j) k.dst[j].bsums = nullptr;
-        launch_conv_bf16_big(k, code, dim3(mtb, ntb, k.nphase), st);
+        if (pair) launch_conv_bf16_pair(k, bn, dim3(mtb, ntb, k.nphase), st);
+        else launch_conv_bf16_big(k, code, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
-        last_info() = (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6))) | (amode << 4) | (bmode << 8) | (1 << 16) |
-                      ((bs_any && bs_ok) ? PG_INFO_BSUMS : 0);
+        last_info() = (pair ? (bn == 256 ? 8 : (bn == 128 ? 9 : 10)) : (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6)))) |
+                      (amode << 4) | (bmode << 8) | (1 << 16) | ((bs_any && bs_ok) ? PG_INFO_BSUMS : 0);
         return 0;
       }
     }

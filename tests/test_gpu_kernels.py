@@ -819,10 +819,15 @@ def big_cases():
         ConvCase("big_up_128_1080rows", "convT", [(128, A, M), (64, False, False), (64, A, False)], 128, 3, 20, 18, 4, 2, 1,
                  L.ACT_RELU, seed=18),
         ConvCase("big_down_dgrad_128_1920rows", "conv", [(128, A, False)], 256, 4, 48, 40, 4, 2, 1, L.ACT_LEAKY, seed=19),
+        # tap-pair kernels: 512 x 64 tile (forward N = 64 on a 96-wide grid; its data gradient is the 64-column up-mode launch on
+        # a 96-wide grid), tiles that straddle image rows AND samples (grid 24 x 20, 3 samples: 1440 rows), two sources
+        ConvCase("pair_up_n64_wide", "convT", [(64, A, False), (64, False, False)], 64, 2, 40, 96, 4, 2, 1, L.ACT_RELU, seed=31),
+        ConvCase("pair_down_x64_wide", "conv", [(64, A, False)], 128, 2, 80, 192, 4, 2, 1, L.ACT_LEAKY, seed=32),
+        ConvCase("pair_up_256_samples", "convT", [(128, A, M), (128, False, False)], 256, 3, 24, 20, 4, 2, 1, L.ACT_RELU, seed=33),
     ]
 
 
-@pytest.mark.parametrize("variant", ["256", "512"])
+@pytest.mark.parametrize("variant", ["256", "512", "pair"])
 @pytest.mark.parametrize("case", big_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
 def test_conv_bf16_big_kernel(case, variant, monkeypatch):
     """igemm_bf16.hip (256 x 256 / 256 x 128 tiles, 8 waves, DMA'd operands, one barrier per K tile), forced on small
@@ -832,7 +837,10 @@ def test_conv_bf16_big_kernel(case, variant, monkeypatch):
     monkeypatch.setattr(E, "PRECISION", 3)
     monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
     # 128-column launches: the 256 x 128 x 64 tile or (round 4) the 512 x 128 x 32 three-stage tile
-    monkeypatch.setenv("PG_BIG_128_VARIANT", variant)
+    # ... or (variant "pair", round 4) the tap-pair kernels of igemm_bf16_pair.hip: one A tile per pair of taps that differ by one
+    # step along x (every k4 s2 launch; k3 and 1x1 launches cannot pair and take the plain kernel)
+    monkeypatch.setenv("PG_BIG_PAIR", "1" if variant == "pair" else "0")
+    monkeypatch.setenv("PG_BIG_128_VARIANT", "256" if variant == "pair" else variant)
     if variant == "512" and case.cout != 128 and case.cin != 128:
         pytest.skip("no 128-column launch in this case")
     bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
@@ -853,9 +861,14 @@ def test_conv_bf16_big_kernel(case, variant, monkeypatch):
     stats = torch.zeros(case.N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
     got = case.run_forward(1, stats=stats)
     code = L.load().pg_last_launch_info() & 0xF
-    assert code in (4, 5, 6, 7), "the 256-row kernel did not run"
+    assert code in (4, 5, 6, 7, 8, 9, 10), "the 256-row kernel did not run"
     rows_f = case.N * (case.Ho * case.Wo if case.kind == "conv" else case.H * case.W)
-    if case.cout == 128:
+    gx_f = case.Wo if case.kind == "conv" else case.W          # output-grid width of the forward launch
+    bm_f, axr_f = (512, 8) if case.cout == 64 else (256, 16)       # conv_impl: the tile's extra LDS rows (one per image row) must suffice
+    pairs_f = variant == "pair" and case.K == 4 and (bm_f + gx_f - 2) // gx_f + 1 <= axr_f
+    if pairs_f:
+        assert code in (8, 9, 10), (code, "the tap-pair kernel did not run")
+    elif case.cout == 128:
         assert code == (7 if (variant == "512" and rows_f >= 512) else 5), (code, rows_f)
     assert rel(got, ref) < 1e-4, (case.name, float(rel(got, ref)))
     o64 = got.double().reshape(case.N, -1)          # statistics of the STORED values
@@ -868,7 +881,7 @@ def test_conv_bf16_big_kernel(case, variant, monkeypatch):
     for acc in (False, True):
         dgot = case.run_dgrad(1, acc)
         if case.cin % 128 == 0:          # the 256-row kernel needs >= 128 output columns (= input channels here)
-            assert (L.load().pg_last_launch_info() & 0xF) in (4, 5, 7)
+            assert (L.load().pg_last_launch_info() & 0xF) in (4, 5, 7, 8, 9)
         for g, r in zip(dgot, dref):
             assert rel(g, r) < 1e-4, (case.name, acc, float(rel(g, r)))
 
