@@ -373,7 +373,7 @@ def pmc_traffic(kernel):
     made by tools/pmc_bench.sh on the default workload — counters cannot be collected from inside this process):
     2*FETCH_SIZE + WRITE_SIZE, in bytes (MI355X_MICROARCH.md: FETCH_SIZE reads half of a wide coalesced stream on
     gfx950).  (None, None) when no PMC summary is available."""
-    for name in ("round3_pmc.json", "round2_pmc.json", "round1_pmc.json"):
+    for name in ("round4_pmc.json", "round3_pmc.json", "round2_pmc.json", "round1_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             k = d["kernels"].get(kernel)

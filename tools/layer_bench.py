@@ -43,9 +43,10 @@ def timed(fn, reps=5):
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     names = sys.argv[2:] or list(LAYERS)
-    E.PRECISION = 3
+    F32 = os.environ.get("PG_LB_F32") == "1"      # the fp32 path (v_mfma_f32_32x32x2_f32 kernels, deferred-norm prologues)
+    E.PRECISION = 0 if F32 else 3
     K, stride, pad = 4, 2, 1
-    bf = torch.bfloat16
+    bf = torch.float32 if F32 else torch.bfloat16
     for name in names:
         kind, h, w, srcC, cout = LAYERS[name]
         cin = sum(srcC)
@@ -64,8 +65,8 @@ def main():
         mode_f = 0 if kind == "conv" else 1
         flops = 2.0 * N * min(h * w, ho * wo) * K * K * cin * cout
         cache = E.BfCache()
-        E._BF_CTX = cache
-        E._BF_CTX_X = cache
+        E._BF_CTX = None if F32 else cache
+        E._BF_CTX_X = None if F32 else cache
 
         def fwd():
             E._conv([a.src() for a in acts], N, h, w, act, mode_f, K, stride, pad, ho, wo, W, cout, cin, out=out, stats=stats)
