@@ -180,11 +180,15 @@ struct LaneDst {
   bool grad_bf16 = false, fwd_bf16 = false;      // bf16 STORAGE of the gradient / forward tensor (pg_dst_t.flags)
   double* bsums = nullptr;                       // (round 4) fused sums of the following norm backward (pg_dst_t.bsums), or null
 };
+// (round 4) per-lane partial sums (sum r, sum r * f) of the values a scatter stores, for the two samples n0 / n0 + 1 of a wave's
+// 64 rows (pg_dst_t.bsums: the norm backward that reads this gradient next); rows of later samples add straight to memory
+struct BsAcc { int n0; float s[2], q[2]; };
 // IO: 0 = fp32 tensors, 1 = gradient AND forward tensor in bf16 STORAGE (compile-time: the batched loads stay straight-line
 // code), 2 = per-destination run-time flags (mixed launches; the loads sit under wave-uniform branches)
-template <int TN_, int IO = 0, typename RowT = RowInfo, bool PIPE = true>
+template <int TN_, int IO = 0, typename RowT = RowInfo, bool PIPE = true, bool BS = false>
 __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowT* rows, int wm0, int lane,
-                                                  const LaneDst& d, bool cval, int Ho, int Wo) {
+                                                  const LaneDst& d, bool cval, int Ho, int Wo, BsAcc* bs = nullptr) {
+  static_assert(!BS || PIPE, "fused sums: pipelined order only");
   const bool gbf = IO == 1 ? true : (IO == 0 ? false : d.grad_bf16);
   const bool fbf = IO == 1 ? true : (IO == 0 ? false : d.fwd_bf16);
   constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR;     // lanes per row, rows per pass
@@ -246,6 +250,7 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
     float2 ab[4];
     unsigned idx[4];
     unsigned ok;
+    int n[BS ? 4 : 1];
   };
   auto issue = [&](int i, int h, Batch& L) {
     L.ok = 0;
@@ -256,6 +261,7 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
       const bool ok = (ri.n >= 0) & cval;
       const int nn = ok ? ri.n : 0;
       L.ok |= (ok ? 1u : 0u) << u;
+      if constexpr (BS) L.n[u] = nn;
       L.idx[u] = ok ? (unsigned)((nn * Ho + ri.oy) * Wo + ri.ox) * (unsigned)d.C + (unsigned)d.c : (unsigned)d.c;
       L.f[u] = ld4_any(d.fwdp, d.has_fwd ? L.idx[u] : (unsigned)d.c, IO == 2 ? (d.has_fwd ? fbf : gbf) : fbf);
       L.ab[u] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nn);
@@ -292,6 +298,18 @@ __device__ __forceinline__ void vec_scatter_64x64(const f32x16 (&acc)[2][TN_], f
         }
         res[u] = make_float4(r4[0], r4[1], r4[2], r4[3]);
         sidx[u] = cur.idx[u];
+        if constexpr (BS) {
+          const bool okb = ((cur.ok >> u) & 1u) != 0;
+          const float s4 = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+          const float q4 = fmaf(r4[0], f4[0], fmaf(r4[1], f4[1], fmaf(r4[2], f4[2], r4[3] * f4[3])));
+          const int dn = cur.n[u] - bs->n0;
+          bs->s[0] += (okb && dn == 0) ? s4 : 0.f; bs->q[0] += (okb && dn == 0) ? q4 : 0.f;
+          bs->s[1] += (okb && dn == 1) ? s4 : 0.f; bs->q[1] += (okb && dn == 1) ? q4 : 0.f;
+          if (okb && dn > 1) {       // host: >= 64 positions per sample, so a wave's 64 rows hold at most two samples — never taken
+            atomicAdd(&d.bsums[(long)cur.n[u] * PG_STAT_SLOTS * 2], (double)s4);
+            atomicAdd(&d.bsums[(long)cur.n[u] * PG_STAT_SLOTS * 2 + 1], (double)q4);
+          }
+        }
       }
       const unsigned sok = cur.ok;
       if (h + 1 < NB) issue(i, h + 1, cur);

@@ -1155,12 +1155,70 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       ld.C = C; ld.c = ngs - cst;
       ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
       ld.accum = dacc != 0;
+      // (round 4) fused norm-backward sums: host (conv_impl) keeps pg_dst_t.bsums only when the workgroup's column tile lies
+      // in ONE destination (workgroup-uniform pointer) and a sample has >= 64 rows
+      double* bsq = p.dst[0].bsums;
+#pragma unroll
+      for (int q = 1; q < PG_MAX_SRC; ++q)
+        if (q < p.ndst && ngs >= p.dstart[q]) bsq = p.dst[q].bsums;
+      ld.bsums = bsq;
+      const bool bs_on = __builtin_amdgcn_readfirstlane((int)(bsq != nullptr)) != 0;
+      BsAcc ba;
+      ba.s[0] = ba.s[1] = ba.q[0] = ba.q[1] = 0.f;
+      ba.n0 = 0;
+      if (bs_on) {                                             // first valid sample of this wave's rows
+        const int nn = rows[wm0 + (lane & (TM * 32 - 1))].n;
+        int nf = nn >= 0 ? nn : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nf = min(nf, __shfl_xor(nf, o));
+        ba.n0 = nf;
+      }
+      float* const Tw = smem + wave * (32 * (32 * TN + 4));
       if constexpr (PREC == 3) {
-        if (p.dst_io == 0) vec_scatter_64x64<TN, 0>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
-        else if (p.dst_io == 1) vec_scatter_64x64<TN, 1>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
-        else vec_scatter_64x64<TN, 2>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+        if (p.dst_io == 0) {
+          if (bs_on) vec_scatter_64x64<TN, 0, RowInfo, true, true>(acc, Tw, rows, wm0, lane, ld, cval, p.Ho, p.Wo, &ba);
+          else vec_scatter_64x64<TN, 0>(acc, Tw, rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+        } else if (p.dst_io == 1) {
+          if (bs_on) vec_scatter_64x64<TN, 1, RowInfo, true, true>(acc, Tw, rows, wm0, lane, ld, cval, p.Ho, p.Wo, &ba);
+          else vec_scatter_64x64<TN, 1>(acc, Tw, rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+        } else vec_scatter_64x64<TN, 2>(acc, Tw, rows, wm0, lane, ld, cval, p.Ho, p.Wo);
       } else {
-        vec_scatter_64x64<TN, 0>(acc, smem + wave * (32 * (32 * TN + 4)), rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+        if (bs_on) vec_scatter_64x64<TN, 0, RowInfo, true, true>(acc, Tw, rows, wm0, lane, ld, cval, p.Ho, p.Wo, &ba);
+        else vec_scatter_64x64<TN, 0>(acc, Tw, rows, wm0, lane, ld, cval, p.Ho, p.Wo);
+      }
+      if (bs_on) {
+        // workgroup-level merge as for the forward statistics: (wave, k) pairs, equal samples merged, one pair of double atomics
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);           // [wave][2 samples][sum r, sum r * f]
+        int* redn = reinterpret_cast<int*>(smem + 64);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double ds = wave_sum_d((double)ba.s[k]), dq = wave_sum_d((double)ba.q[k]);
+          if (lane == 0) { red[(wave * 2 + k) * 2] = ds; red[(wave * 2 + k) * 2 + 1] = dq; }
+        }
+        if (lane == 0) redn[wave] = ba.n0;
+        __syncthreads();
+        if (tid < 8) {
+          const int w = tid >> 1, k = tid & 1;
+          const int n = redn[w] == 0x7fffffff ? -1 : redn[w] + k;
+          double ds = red[tid * 2], dq = red[tid * 2 + 1];
+          bool first = true;
+          for (int o = 0; o < tid; ++o) {
+            const int no = redn[o >> 1] == 0x7fffffff ? -1 : redn[o >> 1] + (o & 1);
+            if (no == n) first = false;
+          }
+          if (first && n >= 0) {
+            for (int o = tid + 1; o < 8; ++o) {
+              const int no = redn[o >> 1] == 0x7fffffff ? -1 : redn[o >> 1] + (o & 1);
+              if (no == n) { ds += red[o * 2]; dq += red[o * 2 + 1]; }
+            }
+            if (ds != 0.0 || dq != 0.0) {
+              const int slot = (blockIdx.x + blockIdx.y * 5 + blockIdx.z * 3) % PG_STAT_SLOTS;
+              atomicAdd(&bsq[((long)n * PG_STAT_SLOTS + slot) * 2], ds);
+              atomicAdd(&bsq[((long)n * PG_STAT_SLOTS + slot) * 2 + 1], dq);
+            }
+          }
+        }
       }
       vec_done = true;
     }
@@ -1332,6 +1390,7 @@ struct FixupK {
   int ndst;
   int dstart[PG_MAX_SRC + 1];
   int out_bf16;             // epilogue 0: `out` is bf16 (bf16 STORAGE); the destinations of epilogue 1 carry their own flags
+  int has_bs;               // epilogue 1: a destination carries pg_dst_t.bsums (fused sums of the following norm backward)
 };
 
 // grid (workgroups per sample, N): every lane owns 4 consecutive columns of one pixel, sums the ks partial tiles and
@@ -1342,6 +1401,9 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
   const int q4 = p.n_cnt >> 2;
   const int items = p.ppix * q4;
   float st_s = 0.f, st_q = 0.f;
+  float bs_s[PG_MAX_SRC], bs_q[PG_MAX_SRC];       // (round 4) per destination: sum r, sum r * f of this lane's final values
+#pragma unroll
+  for (int q = 0; q < PG_MAX_SRC; ++q) { bs_s[q] = 0.f; bs_q[q] = 0.f; }
   for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
     const int pl = it / q4, col = (it - pl * q4) * 4;
     const long pixel = (long)n * p.ppix + pl;
@@ -1378,22 +1440,23 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
     } else {
       float* gradp = p.dst[0].grad;
       const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
-      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0, dfl = p.dst[0].flags;
+      int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0, dfl = p.dst[0].flags, qsel = 0;
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q)
         if (q < p.ndst && col >= p.dstart[q]) {
           gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
-          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags;
+          C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags; qsel = q;
         }
       const int c = col - cst;
       const long idx = pixel * C + c;
       float g4[4] = {v.x, v.y, v.z, v.w};
       float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      float f4[4] = {0.f, 0.f, 0.f, 0.f};
       if (mask0) { const float4 m = *reinterpret_cast<const float4*>(mask0 + (long)n * C + c); m4[0] = m.x; m4[1] = m.y; m4[2] = m.z; m4[3] = m.w; }
       if (fwd0) {
         const float4 f = ld4_any(fwd0, (unsigned)idx, (dfl & PG_DST_FWD_BF16) != 0);
         const float a = aff0 ? aff0[2 * n] : 1.f, b = aff0 ? aff0[2 * n + 1] : 0.f;
-        const float f4[4] = {f.x, f.y, f.z, f.w};
+        f4[0] = f.x; f4[1] = f.y; f4[2] = f.z; f4[3] = f.w;
         const float slope = act_slope(dact);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g4[e] = (g4[e] * m4[e]) * act_grad_s(fmaf(f4[e], a, b) * m4[e], slope);
@@ -1404,6 +1467,36 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const FixupK p) {
       const bool gbf = (dfl & PG_DST_GRAD_BF16) != 0;
       if (dacc) { const float4 old = ld4_any(gradp, (unsigned)idx, gbf); g4[0] += old.x; g4[1] += old.y; g4[2] += old.z; g4[3] += old.w; }
       st4_any(gradp, (unsigned long)idx, gbf, make_float4(g4[0], g4[1], g4[2], g4[3]));
+      if (p.has_bs) {            // the value just stored is FINAL (host: this launch is the tensor's last writer): sums_mode 1
+        const float s4 = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+        const float q4s = fmaf(g4[0], f4[0], fmaf(g4[1], f4[1], fmaf(g4[2], f4[2], g4[3] * f4[3])));
+#pragma unroll
+        for (int q = 0; q < PG_MAX_SRC; ++q)
+          if (qsel == q) { bs_s[q] += s4; bs_q[q] += q4s; }
+      }
+    }
+  }
+  if (p.epilogue == 1 && p.has_bs) {
+    __shared__ double redb[4][PG_MAX_SRC][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < PG_MAX_SRC; ++q) {
+      const double ds = wave_sum_d((double)bs_s[q]), dq = wave_sum_d((double)bs_q[q]);
+      if (lane == 0) { redb[w][q][0] = ds; redb[w][q][1] = dq; }
+    }
+    __syncthreads();
+    if (threadIdx.x < PG_MAX_SRC) {
+      const int q = threadIdx.x;
+      double* b = p.dst[0].bsums;
+#pragma unroll
+      for (int k = 1; k < PG_MAX_SRC; ++k)
+        if (q == k) b = p.dst[k].bsums;
+      if (q < p.ndst && b != nullptr) {
+        const double ds = (redb[0][q][0] + redb[1][q][0]) + (redb[2][q][0] + redb[3][q][0]);
+        const double dq = (redb[0][q][1] + redb[1][q][1]) + (redb[2][q][1] + redb[3][q][1]);
+        double* slot = b + ((long)n * PG_STAT_SLOTS + (blockIdx.x % PG_STAT_SLOTS)) * 2;
+        if (ds != 0.0 || dq != 0.0) { atomicAdd(&slot[0], ds); atomicAdd(&slot[1], dq); }
+      }
     }
   }
   if (p.stats != nullptr) {
@@ -1802,6 +1895,26 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   // operands as floats.  32-column launches on this path must have been taken by the 512 x 64 kernel above.
   PG_REQUIRE(!(bf16_data && cfg == 3), "pg_conv: bf16 data path: a launch with %d output columns was not eligible for the 512x64 "
              "kernel (plain epilogue, no statistics, >= PG_BF16_BIG_MIN workgroups) and has no other bf16 kernel", k.n_cnt);
+  // (round 4) fused norm-backward sums (pg_dst_t.bsums) on this path: the split-K fix-up pass implements them for any layout; the
+  // in-kernel row-major scatter when a workgroup's column tile lies inside one destination, a sample has >= 64 rows per phase
+  // (a wave's 64 rows then hold at most two samples) and the tensors are all fp32 or all bf16.  Otherwise the field is dropped
+  // and PG_INFO_BSUMS stays clear: the caller runs pg_norm_bwd_reduce.
+  bool gbs = false;
+  if (d->epilogue == 1) {
+    const int bn_g = cfg == 0 ? 128 : 64;
+    bool any = false;
+    bool ok = use_part || (ks == 1 && k.vec_dst && (cfg == 0 || cfg == 1) && bmode != B_SCALAR && k.dst_io != 2 &&
+                           k.Gy * k.Gx >= 64 && k.n_cnt % bn_g == 0);
+    for (int j = 0; j < d->ndst; ++j) {
+      if (d->dst[j].bsums == nullptr) continue;
+      any = true;
+      if (d->dst[j].fwd == nullptr) ok = false;
+      if (!use_part && (k.dstart[j] % bn_g != 0 || d->dst[j].C % bn_g != 0)) ok = false;
+    }
+    gbs = any && ok;
+    if (!gbs)
+      for (int j = 0; j < PG_MAX_SRC; ++j) k.dst[j].bsums = nullptr;
+  }
   switch (cfg) {
     case 0: launch_cfg<128, 128, 2, 2>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
     case 1: launch_cfg<128, 64, 2, 2>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
@@ -1809,7 +1922,8 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     default: launch_cfg<128, 32, 4, 1>(k, amode, bmode, d->precision, dma, nomask, grid, st); break;
   }
   PG_LAUNCH_OK("pg_conv");
-  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16) | (dma ? (1 << 12) : 0) | (use_part ? (1 << 13) : 0);
+  last_info() = cfg | (amode << 4) | (bmode << 8) | (ks << 16) | (dma ? (1 << 12) : 0) | (use_part ? (1 << 13) : 0) |
+                (gbs ? PG_INFO_BSUMS : 0);
   if (use_part) {
     FixupK f;
     memset(&f, 0, sizeof(f));
@@ -1819,6 +1933,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
     f.out_bf16 = k.out_bf16;
     for (int j = 0; j < PG_MAX_SRC; ++j) f.dst[j] = k.dst[j];
     f.ndst = k.ndst;
+    f.has_bs = gbs ? 1 : 0;
     for (int j = 0; j <= PG_MAX_SRC; ++j) f.dstart[j] = k.dstart[j];
     const long items = (long)f.ppix * (k.n_cnt / 4);
     long bx = (items + 511) / 512;

@@ -53,9 +53,13 @@ __device__ __forceinline__ float4 ld4_dt(const float* base, long idx) {
 // the batched loads stay straight-line code).  Instantiated as <DG, !WG, fp32> (the fp32 paths), <DG, !WG, bf16> and
 // <!DG, WG, bf16>: two lean passes beat one fused pass (256 VGPRs, one wave per SIMD: 3.07 ms at batch 32 against
 // 0.4 + 0.4 ms).
-template <bool DG, bool WG, bool BF, bool DIRECT = false>
+// BS (round 4): a destination carries pg_dst_t.bsums.  The grid is (workgroups per sample, N) then — a wave stays inside ONE
+// sample, keeps (sum r, sum r * f) of the values it stores per lane (a lane = 4 channels of one destination) and the workgroup
+// adds them once at the end, per destination (sums_mode 1 of pg_norm_bwd_apply_v2: f is the raw forward value).
+template <bool DG, bool WG, bool BF, bool DIRECT = false, bool BS = false>
 __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float bs_s = 0.f, bs_q = 0.f;
   // DIRECT: lane t < 27 = (tap, channel) = (t / 3, t % 3) reads dpre[n][c][y - (r - 1)][x - (s - 1)] (pg_im2col_taps' formula)
   const int d_c = (lane % 27) % 3, d_tap = (lane % 27) / 3;
   const int d_dy = 1 - d_tap / 3, d_dx = 1 - d_tap % 3;
@@ -90,6 +94,10 @@ __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) 
       C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags;
     }
   (void)dfl;
+  int qsel = 0;
+#pragma unroll
+  for (int q = 1; q < PG_MAX_SRC; ++q)
+    if (q < p.ndst && cgc >= p.dstart[q]) qsel = q;
   constexpr bool gbf = BF;
   const int c = cgc - cst;
   const float slope = act_slope(dact);
@@ -107,7 +115,10 @@ __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) 
 
   constexpr int U = 4;                                         // consecutive pixels per wave and step (loads in flight)
   const int stride = gridDim.x * 4 * U;
-  for (int base0 = (blockIdx.x * 4 + wave) * U; base0 < p.npix; base0 += stride) {
+  // BS: pixels [pix_lo, pix_hi) of sample blockIdx.y; otherwise every pixel of the launch
+  const int pix_lo = BS ? (int)blockIdx.y * p.ppix : 0;
+  const int pix_hi = BS ? pix_lo + p.ppix : p.npix;
+  for (int base0 = pix_lo + (blockIdx.x * 4 + wave) * U; base0 < pix_hi; base0 += stride) {
     const int base = __builtin_amdgcn_readfirstlane(base0);
     float gl[U];
     float4 f[U], m[U], old[U];
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) 
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      ok[u] = base + u < p.npix;                               // wave-uniform
+      ok[u] = base + u < pix_hi;                               // wave-uniform
       const int pix = ok[u] ? base + u : base;
       const int n = pix / p.ppix;
       idx[u] = (long)pix * C + c;
@@ -183,6 +194,33 @@ __global__ __launch_bounds__(256) void out_conv_dgrad_kernel(const OutDgradK p) 
         } else {
           *reinterpret_cast<float4*>(gradp + idx[u]) = make_float4(r[0], r[1], r[2], r[3]);
         }
+        if constexpr (BS) {
+          bs_s += (r[0] + r[1]) + (r[2] + r[3]);
+          bs_q += fmaf(r[0], f4[0], fmaf(r[1], f4[1], fmaf(r[2], f4[2], r[3] * f4[3])));
+        }
+      }
+    }
+  }
+  if constexpr (BS) {
+    __shared__ double redb[4][PG_MAX_SRC][2];
+#pragma unroll
+    for (int q = 0; q < PG_MAX_SRC; ++q) {
+      const bool mine = live && qsel == q;
+      const double ds = wave_sum_d(mine ? (double)bs_s : 0.0), dq = wave_sum_d(mine ? (double)bs_q : 0.0);
+      if (lane == 0) { redb[wave][q][0] = ds; redb[wave][q][1] = dq; }
+    }
+    __syncthreads();
+    if (threadIdx.x < PG_MAX_SRC) {
+      const int q = threadIdx.x;
+      double* b = p.dst[0].bsums;
+#pragma unroll
+      for (int k = 1; k < PG_MAX_SRC; ++k)
+        if (q == k) b = p.dst[k].bsums;
+      if (q < p.ndst && b != nullptr) {
+        const double ds = (redb[0][q][0] + redb[1][q][0]) + (redb[2][q][0] + redb[3][q][0]);
+        const double dq = (redb[0][q][1] + redb[1][q][1]) + (redb[2][q][1] + redb[3][q][1]);
+        double* slot = b + ((long)blockIdx.y * PG_STAT_SLOTS + (blockIdx.x % PG_STAT_SLOTS)) * 2;
+        if (ds != 0.0 || dq != 0.0) { atomicAdd(&slot[0], ds); atomicAdd(&slot[1], dq); }
       }
     }
   }
@@ -542,7 +580,21 @@ extern "C" int pg_out_conv_dgrad(const float* G, const float* Wt, int32_t N, int
     if (dst[j].flags != 0) { PG_REQUIRE((dst[j].flags & want) == want, "pg_out_conv_dgrad: a destination mixes fp32 and bf16 tensors"); ++nbf; }
   }
   PG_REQUIRE(nbf == 0 || nbf == ndst, "pg_out_conv_dgrad: destinations must be all fp32 or all bf16");
-  if (nbf) PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  // (round 4) fused norm-backward sums: the fp32 form of the pass, every carrying destination with a forward tensor
+  bool bs = nbf == 0;
+  int nbs = 0;
+  for (int j = 0; j < ndst; ++j)
+    if (dst[j].bsums != nullptr) { ++nbs; bs = bs && dst[j].fwd != nullptr; }
+  bs = bs && nbs > 0;
+  if (!bs)
+    for (int j = 0; j < PG_MAX_SRC; ++j) k.dst[j].bsums = nullptr;
+  pg::last_info() = bs ? PG_INFO_BSUMS : 0;
+  if (bs) {
+    long bx = (k.ppix + 15) / 16;
+    const long cap = (256 * 12 + N - 1) / N;
+    if (bx > cap) bx = cap;
+    PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, false, false, true>), dim3((unsigned)bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, k);
+  } else if (nbf) PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   else PG_KLAUNCH((pg::out_conv_dgrad_kernel<true, false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad");
   return 0;

@@ -44,7 +44,9 @@ class DeformablePose_GAN(nn.Module):
         # adding extra layers for larger image size — reference pose_gan.py:17-18
         nfilters_encoder, nfilters_decoder = synth.nfilters(opt.image_size)
         if not opt.use_input_pose:
-            raise Exception("use_input_pose=0 is not supported by the MI355X build")
+            # the reference's Deformable_Generator.forward concatenates `inp_pose = None` in this mode (networks.py:270-271:
+            # torch.cat([inp_app, None]) raises TypeError) — the path does not run there either
+            raise Exception("use_input_pose=0 is not supported (the reference's deformable generator raises in this mode too)")
         input_nc = 3 + 2 * opt.pose_dim
         self.batch_size = opt.batch_size
         self.pose_dim = opt.pose_dim

@@ -918,9 +918,12 @@ class NormScratch:
 
     def __init__(self, count, N, device):
         self.sums = torch.zeros(count, N, L.STAT_SLOTS, 2, dtype=torch.float64, device=device)
-        self.bsums = torch.zeros(count, N, 2, dtype=torch.float64, device=device)
-        # (round 4) backward sums written by the PRODUCER of a gradient (pg_dst_t.bsums): [N][STAT_SLOTS][2] per norm layer
-        self.fsums = torch.zeros(count, N, L.STAT_SLOTS, 2, dtype=torch.float64, device=device)
+        # backward: the reduce pass's sums [N][2] and (round 4) the sums written by the PRODUCER of a gradient (pg_dst_t.bsums,
+        # [N][STAT_SLOTS][2]) per norm layer — one allocation (`bwd`), one memset per backward pass
+        nb, nf = count * N * 2, count * N * L.STAT_SLOTS * 2
+        self.bwd = torch.zeros(nb + nf, dtype=torch.float64, device=device)
+        self.bsums = self.bwd[:nb].view(count, N, 2)
+        self.fsums = self.bwd[nb:].view(count, N, L.STAT_SLOTS, 2)
         self.used = 0
 
     def take(self):
@@ -984,10 +987,14 @@ class NormState:
             if (io & 1) and _BF_CTX is not None and C > 0:
                 _BF_CTX.adopt(L.ptr(dz), C, L.ACT_NONE, None, None, dz)
             return
-        L.call("pg_norm_bwd_reduce", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), L.stream())
         bf = None
         if PRECISION == 3 and NORM_BWD_BF16 and _BF_CTX is not None and C > 0 and C % 64 == 0:
             bf = _BF_CTX.reserve(L.ptr(dz), C, L.ACT_NONE, None, None, N * Lr, dz.device)
+        if fused:
+            L.call("pg_norm_bwd_apply_v2", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.fsums), L.ptr(gamma), L.ptr(beta), N, Lr,
+                   L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), 0, int(fused), L.stream())
+            return
+        L.call("pg_norm_bwd_reduce", L.ptr(dz), L.ptr(y), L.ptr(self.mr), N, Lr, L.ptr(self.bsums), L.stream())
         if bf is not None:
             L.call("pg_norm_bwd_apply_ex", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
                    L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), L.stream())
@@ -1300,7 +1307,7 @@ class GeneratorEngine:
         for kind, idx, a in srcs:
             if kind == "dec":
                 # the decoder block's output gradient has ONE writer (this launch): it may carry the norm backward's sums
-                bs = self.d_norm[idx].fsums if (self.bfs and FUSE_NORM_SUMS) else None
+                bs = self.d_norm[idx].fsums if FUSE_NORM_SUMS else None
                 dsts.append(L.make_dst(self.d_dz[idx], a.C, fwd=a.t, aff=a.aff, mask=a.mask, act=L.ACT_RELU, bsums=bs))
             elif kind == "warp":
                 dsts.append(L.make_dst(self.w_g[idx], a.C, fwd=a.t, act=L.ACT_RELU))
@@ -1327,10 +1334,8 @@ class GeneratorEngine:
         A, N, H, W = self.A, self.N, self.H, self.W
         assert dpre.is_contiguous() and tuple(dpre.shape) == (N, 3, H, W)
         ystr = (3 * H * W, H * W, W, 1)
-        dev_zero(self.nscr.bsums)
+        dev_zero(self.nscr.bwd if FUSE_NORM_SUMS else self.nscr.bsums)
         self._fsum = {}
-        if self.bfs and FUSE_NORM_SUMS:
-            dev_zero(self.nscr.fsums)
         # ---- final conv k3s1p1 (+bias, tanh handled by the caller)
         i = self.ndec - 1
         srcs = self._dec_sources(i)
@@ -1389,8 +1394,13 @@ class GeneratorEngine:
         if cin <= 256 and all(t.C % 4 == 0 for t in dsts) and OUT_CONV_STREAM:
             arr = (L.Dst * len(dsts))(*dsts)          # K = 27: no GEMM — the streaming kernel (one wave per pixel)
             L.call("pg_out_conv_dgrad", L.ptr(self.g_taps), L.ptr(self.wt_out), N, H, W, arr, len(dsts), L.stream())
+            info = L.load().pg_last_launch_info()
         else:
-            _conv([Act(self.g_taps, 32).src()], N, H, W, L.ACT_NONE, 0, 1, 1, 0, H, W, self.wt_out, cin, 32, dsts=dsts)
+            info = _conv([Act(self.g_taps, 32).src()], N, H, W, L.ACT_NONE, 0, 1, 1, 0, H, W, self.wt_out, cin, 32, dsts=dsts)
+        if (info or 0) & L.INFO_BSUMS:          # the last block's output gradient has this one writer: sums_mode 1 (raw forward values)
+            for (kind, idx, a), dd in zip(srcs, dsts):
+                if kind == "dec" and dd.bsums:
+                    self._fsum[("d", idx)] = 1
 
     def _backward_rest(self, image_grad=None):
         A, N, H, W = self.A, self.N, self.H, self.W
@@ -1454,7 +1464,7 @@ class GeneratorEngine:
                 # this launch is the LAST writer of level l-1's gradient (skip / warp contributions were written before): it may
                 # carry the sums of that level's norm backward
                 nst = self.e_norm[e][l - 1]
-                bs = nst.fsums if (nst is not None and self.bfs and FUSE_NORM_SUMS) else None
+                bs = nst.fsums if (nst is not None and FUSE_NORM_SUMS) else None
                 info = _conv_dgrad(Act(dz, self.enc[l]).src(), N, ho, wo, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
                                    self.enc[l - 1],
                                    [L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
@@ -1606,7 +1616,8 @@ class DiscriminatorEngine:
         """dlogits (M,K).  need_wgrad: accumulate weight grads (dis_update).  image_grad: list of NCHW (n,3,H,W)
         buffers (one per forward pair, or None) receiving d/d(judged image) (gen_update)."""
         A, M, H, W = self.A, self.M, self.H, self.W
-        dev_zero(self.nscr.bsums)
+        dev_zero(self.nscr.bwd if FUSE_NORM_SUMS else self.nscr.bsums)
+        fsum = {}                   # block -> sums_mode: norm layers whose backward sums the producer of their gradient wrote
         j = self.nblk - 1
         ystr = (self.K, 1, self.ws[j], 1)
         wkey = "net.%d.net.1.weight" % j
@@ -1615,7 +1626,7 @@ class DiscriminatorEngine:
             _wgrad([xin.src()], M, L.ACT_LEAKY, dlogits, 1, self.chans[j - 1], True, self.hs[j], self.ws[j],
                    self.hs[j - 1], self.ws[j - 1], 4, 2, 1, A.g(wkey), y_strides=ystr)
             self._ready("net.%d." % j)
-        dst = L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)
+        dst = L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)      # (1 output channel: no fused sums)
         if self.chans[j - 1] % 4 == 0 and 16 * self.chans[j - 1] * 4 <= 160 * 1024:
             # 1 output channel: K = 16 taps, no GEMM — the streaming small-Cout kernel (6 us; 73 us as a pg_conv launch)
             L.call("pg_small_cout_dgrad", L.ptr(dlogits), ystr[0], ystr[1], ystr[2], ystr[3], M, self.hs[j - 1],
@@ -1629,15 +1640,19 @@ class DiscriminatorEngine:
             self.norm[j].backward(dz, self.raw[j], M, self.hs[j] * self.ws[j] * self.chans[j],
                                   A.p("net.%d.net.2.weight" % j),
                                   A.g("net.%d.net.2.weight" % j) if need_wgrad else None,
-                                  A.g("net.%d.net.2.bias" % j) if need_wgrad else None, C=self.chans[j])
+                                  A.g("net.%d.net.2.bias" % j) if need_wgrad else None, C=self.chans[j], fused=fsum.pop(j, 0))
             xin = self._act(j - 1)
             if need_wgrad:
                 _wgrad([xin.src()], M, L.ACT_LEAKY, dz, self.chans[j], self.chans[j - 1], True, self.hs[j], self.ws[j],
                        self.hs[j - 1], self.ws[j - 1], 4, 2, 1, A.g(wkey))
                 self._ready("net.%d." % j)
-            _conv_dgrad(Act(dz, self.chans[j]).src(), M, self.hs[j], self.ws[j], 1, 4, 2, 1, self.hs[j - 1],
-                        self.ws[j - 1], A.p(wkey), self.chans[j], self.chans[j - 1],
-                        [L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY)])
+            nst = self.norm[j - 1]          # this launch is the only writer of block j-1's gradient
+            bs = nst.fsums if (nst is not None and FUSE_NORM_SUMS) else None
+            info = _conv_dgrad(Act(dz, self.chans[j]).src(), M, self.hs[j], self.ws[j], 1, 4, 2, 1, self.hs[j - 1],
+                               self.ws[j - 1], A.p(wkey), self.chans[j], self.chans[j - 1],
+                               [L.make_dst(self.dz[j - 1], self.chans[j - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY, bsums=bs)])
+            if bs is not None and (info or 0) & L.INFO_BSUMS:
+                fsum[j - 1] = 1
         # stem
         dz0 = self.dz[0]
         cin = 3 + 2 * self.P + 3
