@@ -272,6 +272,8 @@ __device__ __forceinline__ unsigned opack_bf16(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+constexpr int OXP = 144;           // row pitch (bytes) of a wave's forward-value tile in LDS
+static_assert(4 * OXP == 576 && 16 * OXP == 2304 && 20 * OXP == 2880, "ds_read_b64_tr_b16 offsets in out_conv_bwd_mfma_kernel");
 constexpr int OPATCH = 336;        // 3 channels x 3 rows x pitch 36 (34 used) = 324 floats + spare
 __device__ __forceinline__ float owave_sum(float v) {
 #pragma unroll
@@ -281,7 +283,10 @@ __device__ __forceinline__ float owave_sum(float v) {
 
 __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgradK p) {
   __shared__ __attribute__((aligned(16))) uint4 a_lds[8 * 2 * 64];          // [channel tile][k step][lane]: 16 KB
-  __shared__ __attribute__((aligned(16))) char x_lds[4 * 32 * 128];         // per wave: [32 pixels][64 channels] bf16
+  // per wave: [32 pixels][64 channels] bf16, row pitch OXP = 144 bytes: with the natural 128-byte pitch the accumulator-layout
+  // accesses (lane = pixel row, 8 bytes) put 32 lanes on 4 banks — 16-way conflicts on 16 of the tile's LDS instructions
+  // (round-4 counters: SQ_LDS_BANK_CONFLICT 0.8 of SQ_LDS_IDX_ACTIVE, SQ_WAIT_INST_LDS a third of the wave cycles); 36 words: 2-way
+  __shared__ __attribute__((aligned(16))) char x_lds[4 * 32 * OXP];
   __shared__ float patch[2][OPATCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -351,14 +356,14 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
       bs_s[cq] = 0.f; bs_q[cq] = 0.f;
     }
   };
-  char* const xt_ = x_lds + wave * 32 * 128;
+  char* const xt_ = x_lds + wave * 32 * OXP;
   const unsigned xb = (unsigned)(size_t)xt_;
   const int r4 = (lane >> 2) & 3, cql = lane & 3, mb = (lane >> 4) & 1;
   unsigned fa[2];
 #pragma unroll
-  for (int cq = 0; cq < 2; ++cq) fa[cq] = xb + (unsigned)((8 * lhi + r4) * 128) + (unsigned)((((cq * 32) >> 3) + 2 * mb + (cql >> 1)) << 4) + ((cql & 1) << 3);
-  char* const xq = xt_ + l31 * 128 + 8 * lhi;            // accumulator layout: this lane's pixel row, + (cq*32 + 8 g) * 2
-  char* const xr = xt_ + (lane >> 2) * 128 + (lane & 3) * 16;      // row-major layout: + i * 16 * 128 + cq * 64
+  for (int cq = 0; cq < 2; ++cq) fa[cq] = xb + (unsigned)((8 * lhi + r4) * OXP) + (unsigned)((((cq * 32) >> 3) + 2 * mb + (cql >> 1)) << 4) + ((cql & 1) << 3);
+  char* const xq = xt_ + l31 * OXP + 8 * lhi;            // accumulator layout: this lane's pixel row, + (cq*32 + 8 g) * 2
+  char* const xr = xt_ + (lane >> 2) * OXP + (lane & 3) * 16;      // row-major layout: + i * 16 * OXP + cq * 64
 
   f32x16 accw[2];
 #pragma unroll
@@ -419,9 +424,9 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
     }
     // ---- forward values -> the wave's LDS tile; both gradient operands from the patch
     *reinterpret_cast<uint4*>(xr) = xin00;
-    *reinterpret_cast<uint4*>(xr + 16 * 128) = xin01;
+    *reinterpret_cast<uint4*>(xr + 16 * OXP) = xin01;
     *reinterpret_cast<uint4*>(xr + 64) = xin10;
-    *reinterpret_cast<uint4*>(xr + 16 * 128 + 64) = xin11;
+    *reinterpret_cast<uint4*>(xr + 16 * OXP + 64) = xin11;
     // the next tile's global loads go out NOW (their registers are free again): a whole tile of work hides their latency, and
     // they precede this tile's stores
     tile += gridDim.x;
@@ -475,10 +480,10 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
     {
       unsigned long long x00l, x00h, x01l, x01h, x10l, x10h, x11l, x11h;      // x^T fragments [cq][k step] lo / hi
       asm volatile(
-          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
-          "ds_read_b64_tr_b16 %2, %8 offset:2048\n\tds_read_b64_tr_b16 %3, %8 offset:2560\n\t"
-          "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:512\n\t"
-          "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:2560\n\t"
+          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:576\n\t"          // + 4, 16, 20 rows of OXP bytes
+          "ds_read_b64_tr_b16 %2, %8 offset:2304\n\tds_read_b64_tr_b16 %3, %8 offset:2880\n\t"
+          "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:576\n\t"
+          "ds_read_b64_tr_b16 %6, %9 offset:2304\n\tds_read_b64_tr_b16 %7, %9 offset:2880\n\t"
           "s_waitcnt lgkmcnt(0)"
           : "=&v"(x00l), "=&v"(x00h), "=&v"(x01l), "=&v"(x01h), "=&v"(x10l), "=&v"(x10h), "=&v"(x11l), "=&v"(x11h)
           : "v"(fa[0]), "v"(fa[1])
@@ -502,8 +507,8 @@ __global__ __launch_bounds__(256, 2) void out_conv_bwd_mfma_kernel(const OutDgra
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     {
-      const uint4 o00 = *reinterpret_cast<const uint4*>(xr), o01 = *reinterpret_cast<const uint4*>(xr + 16 * 128);
-      const uint4 o10 = *reinterpret_cast<const uint4*>(xr + 64), o11 = *reinterpret_cast<const uint4*>(xr + 16 * 128 + 64);
+      const uint4 o00 = *reinterpret_cast<const uint4*>(xr), o01 = *reinterpret_cast<const uint4*>(xr + 16 * OXP);
+      const uint4 o10 = *reinterpret_cast<const uint4*>(xr + 64), o11 = *reinterpret_cast<const uint4*>(xr + 16 * OXP + 64);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (act0) {
