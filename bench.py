@@ -384,6 +384,30 @@ def pmc_traffic(kernel):
     return None, None
 
 
+# family name of the launch table -> kernel symbol in profiles/round4_pmc_northstar.json (bf16 data path; that pass profiled the
+# generator's forward + backward at 256 x 256, batch 32 — the launches of these families in a batch-32 training step are the same)
+BF16_PMC_NAMES = {
+    "conv_igemm<256x256p,A0,B0>": "void pg::conv_bf16_pair_kernel<256>(pg::ConvK)",
+    "conv_igemm<256x128p,A0,B0>": "void pg::conv_bf16_pair_kernel<128>(pg::ConvK)",
+    "conv_igemm<512x64p,A0,B0>": "void pg::conv_bf16_pair_kernel<64>(pg::ConvK)",
+    "conv_igemm<256x256,A0,B0>": "void pg::conv_bf16_big_kernel<256, 64>(pg::ConvK)",
+}
+
+
+def pmc_traffic_bf16(kernel, args):
+    if not (args.batch == 32 and args.size == 256):
+        return None, None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "round4_pmc_northstar.json")))["kernels"]
+        k = d.get(BF16_PMC_NAMES.get(kernel, ""))
+        if k is not None:
+            return int((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), \
+                "profiles/round4_pmc_northstar.json (generator forward + backward, batch 32)"
+    except Exception:
+        pass
+    return None, None
+
+
 def fail(msg, code=2):
     sys.stderr.write(msg + "\n")
     sys.stderr.flush()
@@ -579,7 +603,7 @@ def main():
             # bf16 operand modes run their forward / data-gradient (and, on the data path, weight-gradient) contractions
             # on the bf16 matrix pipe: they are priced against its dense peak
             peak = PEAK_BF16_MFMA_TFLOPS if args.precision in ("bf16", "bf16_data") else PEAK_F32_MFMA_TFLOPS
-            traffic, traffic_src = pmc_traffic(name) if args.precision == "f32" else (None, None)
+            traffic, traffic_src = pmc_traffic(name) if args.precision == "f32" else pmc_traffic_bf16(name, args)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,     # committed PMC summary, NOT measured in this run

@@ -1138,11 +1138,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       float* gradp = p.dst[0].grad;
       const float *fwd0 = p.dst[0].fwd, *aff0 = p.dst[0].aff, *mask0 = p.dst[0].mask;
       int C = p.dst[0].C, dact = p.dst[0].act, dacc = p.dst[0].accumulate, cst = 0, dfl = p.dst[0].flags;
+      // (round 4) fused norm-backward sums: host (conv_impl) keeps pg_dst_t.bsums only when the workgroup's column tile lies
+      // in ONE destination (workgroup-uniform pointer) and a sample has >= 64 rows.  Picked in THIS loop: a second pick loop
+      // over p.dst[] made the compiler keep a 1.3 KB scratch copy of the kernel argument (tools/check_scratch.sh)
+      double* bsq = p.dst[0].bsums;
 #pragma unroll
       for (int q = 1; q < PG_MAX_SRC; ++q)
         if (q < p.ndst && ngs >= p.dstart[q]) {
           gradp = p.dst[q].grad; fwd0 = p.dst[q].fwd; aff0 = p.dst[q].aff; mask0 = p.dst[q].mask;
           C = p.dst[q].C; dact = p.dst[q].act; dacc = p.dst[q].accumulate; cst = p.dstart[q]; dfl = p.dst[q].flags;
+          bsq = p.dst[q].bsums;
         }
       LaneDst ld;
       ld.grad_bf16 = (dfl & PG_DST_GRAD_BF16) != 0; ld.fwd_bf16 = (dfl & PG_DST_FWD_BF16) != 0;
@@ -1155,12 +1160,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
       ld.C = C; ld.c = ngs - cst;
       ld.dslope = ld.has_fwd ? act_slope(dact) : 1.f;
       ld.accum = dacc != 0;
-      // (round 4) fused norm-backward sums: host (conv_impl) keeps pg_dst_t.bsums only when the workgroup's column tile lies
-      // in ONE destination (workgroup-uniform pointer) and a sample has >= 64 rows
-      double* bsq = p.dst[0].bsums;
-#pragma unroll
-      for (int q = 1; q < PG_MAX_SRC; ++q)
-        if (q < p.ndst && ngs >= p.dstart[q]) bsq = p.dst[q].bsums;
       ld.bsums = bsq;
       const bool bs_on = __builtin_amdgcn_readfirstlane((int)(bsq != nullptr)) != 0;
       BsAcc ba;
