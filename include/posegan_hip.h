@@ -58,8 +58,10 @@ typedef struct {
   double* bsums;      /* optional (round 4), [N][PG_STAT_SLOTS][2], zeroed by the caller: the epilogue that writes the FINAL value r of
                        * this gradient also adds the two per-sample sums of the following norm backward — (sum r, sum r * fwd) —
                        * so that pg_norm_bwd_reduce's pass over the tensor does not run (pg_norm_bwd_apply_v2 converts them).
-                       * Only the bf16 256-row kernel and pg_out_conv_bwd_direct's fused pass implement it; whether a launch
-                       * did is reported in pg_last_launch_info() bit 14 (PG_INFO_BSUMS) — otherwise the field is ignored   */
+                       * Implemented by pg_conv's data-gradient epilogues (the bf16 256-row kernels; the generic kernels' row-major
+                       * scatter when a column tile lies in one destination and a sample has >= 64 rows; the split-K fix-up pass),
+                       * pg_out_conv_bwd_direct's fused pass (sums_mode 2) and pg_out_conv_dgrad (fp32).  Whether a launch did is
+                       * reported in pg_last_launch_info() bit 14 (PG_INFO_BSUMS) — otherwise the field is ignored           */
 } pg_dst_t;
 #define PG_INFO_BSUMS (1 << 14)
 #define PG_DST_GRAD_BF16 1
