@@ -352,6 +352,12 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
   // IB / OB: the feature map / the output are bf16 tensors (bf16 STORAGE); relu_out: store max(out, 0) — the decoder reads
   // the warped skip only through its ReLU, and relu(x) > 0 <=> x > 0 keeps the backward's activation derivative
   constexpr int ESI = IB ? 2 : 4, ESO = OB ? 2 : 4;
+#ifdef PG_TIMING_EXPERIMENTS
+  const int fdbg = relu_out >> 8;    // PG_DEBUG_WARP_FWD (timing build only; results are wrong): 1 = no sampling pass, 2 = no pre-pass work
+  relu_out &= 0xff;
+#else
+  constexpr int fdbg = 0;
+#endif
   // TP = pixels per tile (host: 64, fewer on small maps so that the grid still fills the chip)
   extern __shared__ __attribute__((aligned(16))) char wsm[];
   Theta* th = reinterpret_cast<Theta*>(wsm);                   // [MAXT]
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
       const int pix = p0 + pl;
       float m = 0.f;
       if (pix < npix) m = mrow[q];
+      if (fdbg & 2) m = 0.f;
       mval[q] = m;
       if (m != 0.f) {
 #pragma clang fp contract(off)
@@ -415,6 +422,7 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
     }
     __syncthreads();
     // ---- sampling pass: lane = (pixel of the pass, V channels)
+    if (fdbg & 1) continue;
     for (int pl = lp; pl < TP; pl += ppp) {
       const int pix = p0 + pl;
       if (pix >= npix) break;
@@ -478,10 +486,13 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
       }
       wstv<OB, V>(reinterpret_cast<char*>(out), (size_t)o * ESO, best);
       if (amax) {
+        unsigned pk[V / 4];
 #pragma unroll
         for (int q = 0; q < V / 4; ++q)
-          *reinterpret_cast<uchar4*>(amax + o + 4 * q) = make_uchar4((unsigned char)bi[4 * q], (unsigned char)bi[4 * q + 1],
-                                                                      (unsigned char)bi[4 * q + 2], (unsigned char)bi[4 * q + 3]);
+          pk[q] = (unsigned)(bi[4 * q] & 0xff) | ((unsigned)(bi[4 * q + 1] & 0xff) << 8) | ((unsigned)(bi[4 * q + 2] & 0xff) << 16) |
+                  ((unsigned)(bi[4 * q + 3] & 0xff) << 24);
+        if constexpr (V == 8) *reinterpret_cast<uint2*>(amax + o) = make_uint2(pk[0], pk[1]);      // one 8-byte store per lane
+        else *reinterpret_cast<unsigned*>(amax + o) = pk[0];
       }
     }
   }
@@ -498,12 +509,21 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   // GB / DB: the incoming gradient / the written input gradient are bf16 tensors (bf16 STORAGE)
   constexpr int ESG = GB ? 2 : 4, ESD = DB ? 2 : 4;
   constexpr int FLAT = LIST ? GATHER_T * GATHER_CAP : GATHER_FLAT;
+#ifdef PG_TIMING_EXPERIMENTS
+  const int wdbg = align >> 8;       // PG_DEBUG_WARP_BWD (timing build only; results are wrong): 1 = no phase 2, 2 = no phase 1
+  align &= 0xff;
+#else
+  constexpr int wdbg = 0;
+#endif
   __shared__ Theta th[MAXT];
   __shared__ WarpInv inv[MAXT];
   __shared__ int e_pix[GATHER_PIX][FLAT];                 // output pixel | transform << 24
   __shared__ float e_w[GATHER_PIX][FLAT];                 // mask x bilinear weight
   __shared__ int e_cnt[GATHER_PIX];
   __shared__ int e_ovf;
+  __shared__ int pr_n;                                    // accepted (pixel, transform) pairs of the tile:
+  __shared__ int4 pr[GATHER_PIX * GATHER_T];              //   pixel | t << 8, i0, j0 | nj << 16, candidates (<= GATHER_CAP)
+  __shared__ int px_x[GATHER_PIX], px_y[GATHER_PIX];
   __shared__ float xs_t[GATHER_MAXDIM], ys_t[GATHER_MAXDIM];      // normalised grid coordinate per column / row (host: h, w <= 1024)
   const int nent = LIST ? min(g_gather_ovf[0], GATHER_OVF_MAX) : 1;
   for (int ent = LIST ? (int)blockIdx.x : 0; ent < nent; ent += LIST ? (int)gridDim.x : 1) {
@@ -539,62 +559,66 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   if (threadIdx.x == 0) e_ovf = 0;
   __syncthreads();
   const int P0 = tile * GATHER_PIX;
-  // the candidates of (input pixel P = (X, Y), transform t): output pixels of the pre-image box whose mask is non-zero and whose
-  // bilinear footprint contains P; ep[e] = output pixel | t << 24 (or -1), ew[e] = mask x bilinear weight.  Returns the count.
-  auto candidates = [&](int P, int X, int Y, int t, int (&ep)[GATHER_CAP], float (&ew)[GATHER_CAP]) -> int {
-    const WarpInv v = inv[t];
-    if (!v.narrow || P >= h * w) return 0;
-    const float dx = (float)X - v.cx, dy = (float)Y - v.cy;
-    const float jc = v.jx * dx + v.jy * dy, ic = v.ix_ * dx + v.iy_ * dy;
-    if (!(jc + v.ej >= 0.f && jc - v.ej <= (float)w && ic + v.ei >= 0.f && ic - v.ei <= (float)h)) return 0;
-    const int j0 = max((int)ceilf(jc - v.ej), 0), j1 = min((int)floorf(jc + v.ej), w - 1);
-    const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
-    const int nj = j1 - j0 + 1, tot = nj * (i1 - i0 + 1);
-    if (nj <= 0 || tot <= 0) return 0;
-    if (i1 < mb[t][0] || i0 > mb[t][1] || j1 < mb[t][2] || j0 > mb[t][3]) return 0;      // every candidate has a zero mask
-    float mv[GATHER_CAP];
-    int ci[GATHER_CAP], cj[GATHER_CAP];
-    {
-      int ii = i0, jj = j0;
-#pragma unroll
-      for (int e = 0; e < GATHER_CAP; ++e) {
-        const bool val = e < tot;
-        ci[e] = ii; cj[e] = jj;
-        mv[e] = val ? masks[(nb + (long)ii * w + jj) * T + t] : 0.f;
-        ++jj;
-        if (jj > j1) { jj = j0; ii = min(ii + 1, i1); }
-      }
+  // ---- phase 1 (round 4: two stages).  One lane per (input pixel, transform) evaluating up to 16 candidates serially kept ~2 of
+  // 10 lanes busy (the limb masks' bounding boxes reject the rest) with 80 registers of per-lane candidate arrays: 300 of the
+  // 480 us of the level-0 launch at batch 32 (timing build, PG_DEBUG_WARP_BWD).  Now: (a) every pair computes its pre-image box
+  // and the rejections — transform not narrow, box outside the map, box outside the mask's bounding box — and the accepted pairs
+  // are compacted into `pr`; (b) one lane per (accepted pair, candidate): mask value, bilinear footprint test, list append.
+  // The order of a pixel's list entries was already decided by LDS atomics across transforms; it still is.
+  if (threadIdx.x == 0) pr_n = 0;
+  if (threadIdx.x < GATHER_PIX) {
+    const int P = P0 + (int)threadIdx.x;
+    const int Y = P / w;
+    px_y[threadIdx.x] = Y; px_x[threadIdx.x] = P - Y * w;
+  }
+  __syncthreads();
+  if (!(wdbg & 2)) {
+    const int p = threadIdx.x & (GATHER_PIX - 1), P = P0 + p;
+    const int X = px_x[p], Y = px_y[p];
+    for (int t = threadIdx.x / GATHER_PIX; t < T; t += 256 / GATHER_PIX) {
+      const WarpInv v = inv[t];
+      if (!v.narrow || P >= h * w) continue;
+      const float dx = (float)X - v.cx, dy = (float)Y - v.cy;
+      const float jc = v.jx * dx + v.jy * dy, ic = v.ix_ * dx + v.iy_ * dy;
+      if (!(jc + v.ej >= 0.f && jc - v.ej <= (float)w && ic + v.ei >= 0.f && ic - v.ei <= (float)h)) continue;
+      const int j0 = max((int)ceilf(jc - v.ej), 0), j1 = min((int)floorf(jc + v.ej), w - 1);
+      const int i0 = max((int)ceilf(ic - v.ei), 0), i1 = min((int)floorf(ic + v.ei), h - 1);
+      const int nj = j1 - j0 + 1, tot = nj * (i1 - i0 + 1);
+      if (nj <= 0 || tot <= 0) continue;
+      if (i1 < mb[t][0] || i0 > mb[t][1] || j1 < mb[t][2] || j0 > mb[t][3]) continue;      // every candidate has a zero mask
+      const int k = atomicAdd(&pr_n, 1);
+      pr[k] = make_int4(p | (t << 8), i0, j0 | (nj << 16), min(tot, GATHER_CAP));
     }
-    int cnt = 0;
+  }
+  __syncthreads();
+  {
+    const int nitems = pr_n * GATHER_CAP;
+    constexpr int U = 4;                                   // items per lane and round: the mask loads go out as one batch
+    for (int it0 = threadIdx.x; it0 < nitems; it0 += 256 * U) {
+      float mv[U];
+      int pp[U], tt[U], ci[U], cj[U];
 #pragma unroll
-    for (int e = 0; e < GATHER_CAP; ++e) {
-      ep[e] = -1; ew[e] = 0.f;
-      if (mv[e] != 0.f) {
-        const Taps tp = make_taps_xy(th[t], xs_t[cj[e]], ys_t[ci[e]], h, w, align);      // division-free (tables)
-        const int kx = X - tp.x0, ky = Y - tp.y0;
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * 256;
+        const bool in = it < nitems;
+        const int4 d = pr[in ? (it >> 4) : 0];
+        const int e = it & (GATHER_CAP - 1), nj = d.z >> 16;
+        const bool val = in && e < d.w;
+        const int di = (int)(((float)e + 0.5f) * __frcp_rn((float)nj));       // e / nj, e < 16 (exact)
+        pp[u] = d.x & 0xff; tt[u] = d.x >> 8;
+        ci[u] = d.y + di; cj[u] = (d.z & 0xffff) + e - di * nj;
+        mv[u] = val ? masks[(nb + (long)ci[u] * w + cj[u]) * T + tt[u]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (mv[u] == 0.f) continue;
+        const Taps tp = make_taps_xy(th[tt[u]], xs_t[cj[u]], ys_t[ci[u]], h, w, align);      // division-free (tables)
+        const int kx = px_x[pp[u]] - tp.x0, ky = px_y[pp[u]] - tp.y0;
         if ((unsigned)kx <= 1u && (unsigned)ky <= 1u) {
           const float wk = ky ? (kx ? tp.w11 : tp.w10) : (kx ? tp.w01 : tp.w00);
-          ep[e] = (ci[e] * w + cj[e]) | (t << 24); ew[e] = mv[e] * wk; ++cnt;
-        }
-      }
-    }
-    return cnt;
-  };
-  // ---- phase 1: one lane per (input pixel, transform); the <= 16 mask values of the pre-image box are loaded as ONE batch
-  {
-    const int p = threadIdx.x & (GATHER_PIX - 1), P = P0 + p;
-    const int Y = P / w, X = P - Y * w;
-    for (int t = threadIdx.x / GATHER_PIX; t < T; t += 256 / GATHER_PIX) {
-      int ep[GATHER_CAP];
-      float ew[GATHER_CAP];
-      const int cnt = candidates(P, X, Y, t, ep, ew);
-      if (cnt) {
-        int at = atomicAdd(&e_cnt[p], cnt);
-        if (!LIST && at + cnt > FLAT) e_ovf = 1;
-        else {
-#pragma unroll
-          for (int e = 0; e < GATHER_CAP; ++e)
-            if (ep[e] >= 0) { e_pix[p][at] = ep[e]; e_w[p][at] = ew[e]; ++at; }
+          const int at = atomicAdd(&e_cnt[pp[u]], 1);
+          if (at < FLAT) { e_pix[pp[u]][at] = (ci[u] * w + cj[u]) | (tt[u] << 24); e_w[pp[u]][at] = mv[u] * wk; }
+          else e_ovf = 1;                                  // (LIST: FLAT = T x CAP, cannot happen)
         }
       }
     }
@@ -609,6 +633,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
     continue;
   }
   // ---- phase 2: lanes = V channels of an input pixel; entries in batches of four (independent loads in flight)
+  if (wdbg & 1) continue;
   for (int q = threadIdx.x; q < GATHER_PIX * cq; q += 256) {
     const int p = q / cq, c4 = (q - p * cq) * V;
     const int P = P0 + p;
@@ -776,7 +801,10 @@ extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const
   const bool v8 = ib && ob && C % 8 == 0 && 256 % (C / 8) == 0 && !no_v8;
   const int cpp = v8 ? C / 8 : C / 4;
   const size_t lds = ((MAXT * sizeof(Theta) + (size_t)(w + h + 64 * T) * 4 + 15) / 16) * 16 + (size_t)64 * T * sizeof(WarpTap);
-  const int relu = (io_flags & 4) ? 1 : 0;
+  int relu = (io_flags & 4) ? 1 : 0;
+#ifdef PG_TIMING_EXPERIMENTS
+  { static const int fd = getenv("PG_DEBUG_WARP_FWD") ? atoi(getenv("PG_DEBUG_WARP_FWD")) : 0; relu |= fd << 8; }
+#endif
   if (v1 || cpp > 256 || 256 % cpp != 0 || lds > 64 * 1024 || (double)h * w * C * 4.0 >= 2147483648.0) {
     PG_REQUIRE(io_flags == 0, "pg_warp_mask_max_fwd: bf16 storage needs the tiled kernel (C / 4 must divide 256)");
     PG_KLAUNCH(warp_fwd_kernel, dim3(warp_grid(C, h, w), N), dim3(256), 0, (hipStream_t)stream, (const float*)feat, aff, warps,
@@ -786,7 +814,11 @@ extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const
     const int ppp = 256 / cpp;
     while (tp > 8 && tp / 2 >= ppp && (((long)h * w + tp - 1) / tp) * N < 1024) tp /= 2;
     long tiles = ((long)h * w + tp - 1) / tp;
-    if (tiles > 1024) tiles = 1024;
+    // ~8192 workgroups per launch, each walking several tiles (round 4 sweep at batch 32, level 0: 32768 one-tile workgroups
+    // 265 us, 8192: 250, 4096: 257, 2048: 300 — the set-up per workgroup is small, the kernel needs many loads in flight)
+    static const long wcap = getenv("PG_WARP_FWD_WGS") ? atol(getenv("PG_WARP_FWD_WGS")) : 8192;
+    const long cap = wcap / N > 32 ? wcap / N : 32;
+    if (tiles > cap) tiles = cap;
     const dim3 grid((unsigned)tiles, N);
     hipStream_t st = (hipStream_t)stream;
 #define PGW_FWD(IB_, OB_)                                                                                                     \
@@ -848,22 +880,26 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
     int gtiles = (h * w + GATHER_PIX - 1) / GATHER_PIX;
     if (gtiles > gcap) gtiles = gcap;
     static const bool no_v8b = getenv("PG_WARP_NO_V8") != nullptr;
+    int ac_g = align_corners;                            // the gather launches' copy (timing build: + experiment bits)
+#ifdef PG_TIMING_EXPERIMENTS
+    { static const int wd = getenv("PG_DEBUG_WARP_BWD") ? atoi(getenv("PG_DEBUG_WARP_BWD")) : 0; ac_g |= wd << 8; }
+#endif
     static void* ovf_dev = nullptr;                      // g_gather_ovf: tiles whose 48-entry lists overflowed
     if (ovf_dev == nullptr) PG_REQUIRE(hipGetSymbolAddress(&ovf_dev, HIP_SYMBOL(g_gather_ovf)) == hipSuccess, "pg_warp_mask_max_bwd: symbol");
     PG_MEMSET_ASYNC(ovf_dev, 0, 4, st);
     const dim3 g1(gtiles, N), g2(64);                    // second launch: worst-case capacity over the overflow list (usually empty)
     if (gb && db && C % 8 == 0 && !no_v8b) {
       PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
-                 align_corners, dfeat, (const int*)bbox);
+                 ac_g, dfeat, (const int*)bbox);
       PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
-                 align_corners, dfeat, (const int*)bbox);
+                 ac_g, dfeat, (const int*)bbox);
     } else {
 #define PGW_GATHER(GBv, DBv)                                                                                                    \
   do {                                                                                                                          \
     PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, \
-               align_corners, dfeat, (const int*)bbox);                                                                         \
+               ac_g, dfeat, (const int*)bbox);                                                                         \
     PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,  \
-               align_corners, dfeat, (const int*)bbox);                                                                         \
+               ac_g, dfeat, (const int*)bbox);                                                                         \
   } while (0)
       if (gb && db) PGW_GATHER(true, true);
       else if (gb) PGW_GATHER(true, false);
