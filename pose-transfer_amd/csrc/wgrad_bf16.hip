@@ -677,7 +677,9 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
     // side stream NEXT TO the data-gradient chain: a launch that wants every CU only takes them from the main stream, and
     // every extra split adds a full set of float atomics on dW.  Swept on the box (tools/sweep_wgrad_bf16_target.sh), img/s at 256^2 batch
     // 32 / batch 4 / 224^2 P=32 batch 8: target 768 -> 776 / 464 / 704, 256 -> 788 / 465 / 713, 128 -> 793 / 475 / 724,
-    // 64 -> 681 / 439 / 656.
+    // 64 -> 681 / 439 / 656.  (Round 4, per layer in isolation at batch 32 — tools/layer_bench.py — 256 workgroups win on the two layers
+    // with >= 128 K tiles: dec.2 418 -> 349 us, enc.4 135 -> 117 us; in the pass, next to the main stream's kernels, the same rule
+    // LOSES: north-star 18.22 -> 18.33 ms, batch-32 step 1110 -> 1100 img/s.  Kept at 128.)
     const long base = (long)mt * nt * 16;
     static const int target = getenv("PG_WGTR_TARGET") ? atoi(getenv("PG_WGTR_TARGET")) : 128;
     // thin tiles with a long K (the discriminator's 64 -> 128 layer on 63 x 63 maps: one 128 x 64 tile per tap, 1985 K tiles — 0.59 ms
