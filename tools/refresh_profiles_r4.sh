@@ -26,6 +26,15 @@ echo "---- fp32 path, batch 4, random / all-zero operands" >> $O/round4_layer_be
 PG_LB_F32=1 python tools/layer_bench.py 4 dec3 dec4 dec5 enc2 >> $O/round4_layer_bench_b32_bf16.txt 2>/dev/null
 PG_LB_F32=1 PG_LB_ZERO=1 python tools/layer_bench.py 4 dec3 dec4 dec5 enc2 >> $O/round4_layer_bench_b32_bf16.txt 2>/dev/null
 python tools/pyramid_bench.py > $O/round4_mask_pyramid.txt 2>/dev/null
+python tools/warp_bench.py 32 2>/dev/null | grep -v amdgpu > $O/round4_warp_bench.txt
+python tools/optim_bench.py 2>/dev/null | grep -v amdgpu > $O/round4_optim_bench.txt
+if [ -f pose-transfer_amd/lib/libposegan_hip_timing.so ]; then
+  ( export PG_TIMING_EXPERIMENTS=1
+    echo "---- timing build (results are wrong, times are not): PG_DEBUG_WARP_BWD 1 = no gather phase, 2 = no candidate search; PG_DEBUG_WARP_FWD 1 = no sampling pass, 2 = no pre-pass work"
+    for v in "PG_DEBUG_WARP_BWD=1" "PG_DEBUG_WARP_BWD=2" "PG_DEBUG_WARP_BWD=3" "PG_DEBUG_WARP_FWD=1" "PG_DEBUG_WARP_FWD=2" "PG_DEBUG_WARP_FWD=3"; do
+      echo "== [$v]"; env $v python tools/warp_bench.py 32 2>/dev/null | grep "level 0"
+    done ) >> $O/round4_warp_bench.txt
+fi
 # timing experiments of the 256-row kernel (timing library: wrong results, right times)
 if [ -f pose-transfer_amd/lib/libposegan_hip_timing.so ]; then
   ( export PG_TIMING_EXPERIMENTS=1 PG_BIG_PAIR=0
