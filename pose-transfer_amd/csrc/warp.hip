@@ -592,7 +592,9 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   }
   __syncthreads();
   {
-    const int nitems = pr_n * GATHER_CAP;
+    // (tried: one word per candidate written by stage (a) so that stage (b) is dense — the divergent store loop costs more than
+    //  the idle lanes: level 0 at batch 32 372 -> 408 us.  Timing build at that level: stage (a) 53 us, stage (b) 95, gather 178.)
+    const int nitems = (wdbg & 4) ? 0 : pr_n * GATHER_CAP;      // (timing build: 4 = no candidate stage)
     constexpr int U = 4;                                   // items per lane and round: the mask loads go out as one batch
     for (int it0 = threadIdx.x; it0 < nitems; it0 += 256 * U) {
       float mv[U];
