@@ -509,6 +509,10 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   // GB / DB: the incoming gradient / the written input gradient are bf16 tensors (bf16 STORAGE)
   constexpr int ESG = GB ? 2 : 4, ESD = DB ? 2 : 4;
   constexpr int FLAT = LIST ? GATHER_T * GATHER_CAP : GATHER_FLAT;
+#ifndef PG_GATHER_PB
+#define PG_GATHER_PB 4
+#endif
+  constexpr int PB = PG_GATHER_PB;          // list entries per batch of the gather phase (independent loads in flight; batch 32: 4 -> 642 us per pass, 2 -> 699, 1 -> 721)
 #ifdef PG_TIMING_EXPERIMENTS
   const int wdbg = align >> 8;       // PG_DEBUG_WARP_BWD (timing build only; results are wrong): 1 = no phase 2, 2 = no phase 1
   align &= 0xff;
@@ -644,10 +648,10 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = 0.f;
     const int cnt = e_cnt[p];
-    for (int e0 = 0; e0 < cnt; e0 += 4) {
-      long o[4]; float wt[4]; int tt[4]; unsigned am[4][V / 4]; float g[4][V];
+    for (int e0 = 0; e0 < cnt; e0 += PB) {
+      long o[PB]; float wt[PB]; int tt[PB]; unsigned am[PB][V / 4]; float g[PB][V];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < PB; ++u) {
         const bool val = e0 + u < cnt;
         const int ee = val ? e0 + u : e0;
         const int pk = e_pix[p][ee];
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
         wldv<GB, V>(reinterpret_cast<const char*>(gout), (size_t)o[u] * ESG, g[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < PB; ++u)
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const int ab = (int)((am[u][e >> 2] >> (8 * (e & 3))) & 0xffu);
