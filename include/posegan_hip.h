@@ -468,6 +468,14 @@ int pg_stem_conv_bf16_v3(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t H
 int pg_stem_wgrad_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
                           int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* workspace,
                           int64_t workspace_floats, void* stream);
+/* round 4: as _ex, and optionally the layer's BIAS gradient from the same pass — db[co] += sum over pixels of dY, through a constant-one
+ * input channel in a spare slot of the kernel's channel padding (reference: autograd of the conv bias, models/networks.py:186,341).
+ * Done when pg_last_launch_info() has PG_INFO_STEM_BIAS set (Cin below the padded channel count; k3 p1 or p0); otherwise the
+ * caller runs pg_bias_grad / pg_bias_grad_bf16 as before. */
+#define PG_INFO_STEM_BIAS (1 << 15)
+int pg_stem_wgrad_bf16_v2(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K, int32_t stride,
+                          int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* dbias, float* workspace,
+                          int64_t workspace_floats, void* stream);
 /* db[c] += sum over pixels of a dense NHWC bf16 gradient (bias gradient of the first layers, networks.py:186,341) */
 int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, float* db, void* stream);
 /* pg_tap_gather (k3 p1, 3 outputs) over a tap tensor whose pixel rows are `pitch` >= 27 floats apart */

@@ -42,6 +42,7 @@ struct StemK {
   float slope2, slope3;
   const float* dY;            // wgrad: NHWC [N][Ho][Wo][64]
   int dy_bf16;                // wgrad: dY is a bf16 tensor (bf16 STORAGE)
+  int ones_slot;              // wgrad (round 4): patch channel slot Ctot holds the constant 1 — its column of one tap IS the bias gradient
   float* part;                // wgrad: per-workgroup partial results [blocks][64][npad]
   int npad;
   int tiles_x, tiles_y, ntiles, ngroups;
@@ -429,6 +430,11 @@ __global__ __launch_bounds__(NW * 64) void stem_wgrad_bf16_kernel(const StemK p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // (round 4) the bias gradient rides along: a spare channel slot of the patch (Ctot < CP) holds 1.0 at EVERY patch pixel — the
+  // staging below never writes slots >= Ctot — so column (tap, Ctot) of dW is sum over pixels of dY for any tap; the reduce
+  // kernel adds ONE tap's column (one whose input pixel exists for every output pixel: the centre for k3 p1, tap 0 for p0) to db
+  if (p.ones_slot)
+    for (int e = tid; e < PH * ROWP; e += NT) *reinterpret_cast<unsigned short*>(patch + e * PS + p.Ctot * 2) = 0x3f80;
   for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
     int b = t;
     const int tx = b % p.tiles_x; b /= p.tiles_x;
@@ -513,12 +519,13 @@ __global__ __launch_bounds__(NW * 64) void stem_wgrad_bf16_kernel(const StemK p)
 
 // dW[tap][co][ci] += sum over workgroups of part[b][co][n = tap*CP + ci]; blockIdx.y strides over the workgroups
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* part, int nblocks, int npad, int T, int CP, int Ctot,
-                                                                float* dW) {
+                                                                float* dW, float* db, int tap_b) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= 64 * npad) return;
   const int co = e / npad, n = e - co * npad;
   const int tap = n / CP, ci = n - tap * CP;
-  if (tap >= T || ci >= Ctot) return;
+  const bool bias_col = db != nullptr && tap == tap_b && ci == Ctot;       // the constant-one channel's column of one tap
+  if (tap >= T || (ci >= Ctot && !bias_col)) return;
   const long stride = (long)64 * npad;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
   int b = blockIdx.y;
@@ -530,7 +537,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* par
     t3 += part[(b + 3 * step) * stride + e];
   }
   for (; b < nblocks; b += step) t0 += part[b * stride + e];
-  atomicAdd(dW + ((long)tap * 64 + co) * Ctot + ci, (t0 + t1) + (t2 + t3));
+  if (bias_col) atomicAdd(db + co, (t0 + t1) + (t2 + t3));
+  else atomicAdd(dW + ((long)tap * 64 + co) * Ctot + ci, (t0 + t1) + (t2 + t3));
 }
 
 static int stem_fill(StemK& k, const pg_src_t* src, int nsrc, int N, int Hi, int Wi, int K, int stride, int pad) {
@@ -604,7 +612,7 @@ static int launch_stem_conv_pf(StemK& k, hipStream_t st) {
 }
 
 template <int K, int S, int TH, int CP, int NW, int NTW>
-static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hipStream_t st) {
+static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hipStream_t st, float* db = nullptr) {
   constexpr int PH = (TH - 1) * S + K, PW = 15 * S + K, PWH = (PW + 1) / 2, ROWP = (S == 1) ? PW : 2 * PWH;
   constexpr int LDS = TH * 16 * 128 + (PH * ROWP * CP * 2 + 15) / 16 * 16;
   static_assert(LDS <= 160 * 1024, "stem wgrad: LDS");
@@ -630,11 +638,14 @@ static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hip
     if (ws == nullptr || blocks < 1) return -2;
   }
   k.part = ws;
+  // bias gradient through the constant-one channel: needs a spare slot and a tap whose input pixel exists for every output pixel
+  const bool fuse_b = db != nullptr && k.Ctot < CP && ((K == 3 && k.pad == 1) || k.pad == 0);
+  k.ones_slot = fuse_b ? 1 : 0;
   PG_KLAUNCH(kern, dim3((unsigned)blocks), dim3(NW * 64), LDS, st, k);
   const int ry = blocks >= 32 ? 16 : 1;
   PG_KLAUNCH(stem_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256), 0, st, k.part,
-                     blocks, k.npad, K * K, CP, k.Ctot, dW);
-  return 0;
+                     blocks, k.npad, K * K, CP, k.Ctot, dW, fuse_b ? db : (float*)nullptr, (K == 3 && k.pad == 1) ? 4 : 0);
+  return fuse_b ? 1 : 0;
 }
 
 }  // namespace pg
@@ -705,18 +716,25 @@ extern "C" int pg_stem_conv_bf16_v3(const pg_src_t* src, int32_t nsrc, int32_t N
   return 0;
 }
 
+extern "C" int pg_stem_wgrad_bf16_v2(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
+                                     int32_t stride, int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* dbias,
+                                     float* workspace, int64_t workspace_floats, void* stream);
 extern "C" int pg_stem_wgrad_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
                                      int32_t stride, int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* workspace,
-                                     int64_t workspace_floats, void* stream);
+                                     int64_t workspace_floats, void* stream) {
+  return pg_stem_wgrad_bf16_v2(src, nsrc, N, Hi, Wi, K, stride, pad, dY, dy_is_bf16, dW, nullptr, workspace, workspace_floats, stream);
+}
 extern "C" int pg_stem_wgrad_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
                                   int32_t stride, int32_t pad, const float* dY, float* dW, float* workspace,
                                   int64_t workspace_floats, void* stream) {
   return pg_stem_wgrad_bf16_ex(src, nsrc, N, Hi, Wi, K, stride, pad, dY, 0, dW, workspace, workspace_floats, stream);
 }
 // dy_is_bf16: the gradient of the first layer's output is stored as bf16 (bf16 STORAGE, round 3)
-extern "C" int pg_stem_wgrad_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
-                                     int32_t stride, int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* workspace,
-                                     int64_t workspace_floats, void* stream) {
+// dbias (round 4, optional): db[co] += sum over pixels of dY — the layer's bias gradient from the same pass (a constant-one input
+// channel); done when pg_last_launch_info() has PG_INFO_STEM_BIAS set, otherwise the caller runs pg_bias_grad*
+extern "C" int pg_stem_wgrad_bf16_v2(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi, int32_t Wi, int32_t K,
+                                     int32_t stride, int32_t pad, const void* dY, int32_t dy_is_bf16, float* dW, float* dbias,
+                                     float* workspace, int64_t workspace_floats, void* stream) {
   PG_REQUIRE(src && nsrc >= 1 && nsrc <= PG_MAX_SRC && dY && dW, "pg_stem_wgrad_bf16: bad arguments");
   PG_REQUIRE((K == 3 && stride == 1) || (K == 4 && stride == 2), "pg_stem_wgrad_bf16: only k3s1 / k4s2 (got k%d s%d)", K, stride);
   pg::StemK k;
@@ -729,16 +747,16 @@ extern "C" int pg_stem_wgrad_bf16_ex(const pg_src_t* src, int32_t nsrc, int32_t 
   int rc;
   if (K == 3) {
     PG_REQUIRE(c <= 36, "pg_stem_wgrad_bf16: k3 supports Cin <= 36 (got %d)", c);
-    rc = (c <= 24) ? pg::launch_stem_wgrad<3, 1, 8, 24, 4, 4>(k, dW, workspace, workspace_floats, st)
-                   : pg::launch_stem_wgrad<3, 1, 8, 36, 4, 6>(k, dW, workspace, workspace_floats, st);
+    rc = (c <= 24) ? pg::launch_stem_wgrad<3, 1, 8, 24, 4, 4>(k, dW, workspace, workspace_floats, st, dbias)
+                   : pg::launch_stem_wgrad<3, 1, 8, 36, 4, 6>(k, dW, workspace, workspace_floats, st, dbias);
   } else {
     PG_REQUIRE(c <= 72, "pg_stem_wgrad_bf16: k4 supports Cin <= 72 (got %d)", c);
-    rc = (c <= 44) ? pg::launch_stem_wgrad<4, 2, 8, 44, 8, 6>(k, dW, workspace, workspace_floats, st)
-                   : pg::launch_stem_wgrad<4, 2, 8, 72, 8, 9>(k, dW, workspace, workspace_floats, st);
+    rc = (c <= 44) ? pg::launch_stem_wgrad<4, 2, 8, 44, 8, 6>(k, dW, workspace, workspace_floats, st, dbias)
+                   : pg::launch_stem_wgrad<4, 2, 8, 72, 8, 9>(k, dW, workspace, workspace_floats, st, dbias);
   }
   PG_REQUIRE(rc != -2, "pg_stem_wgrad_bf16: a workspace of at least 64 x %d floats is required", k.npad);
-  if (rc) return rc;
-  pg::last_info() = 7 | (1 << 4) | (1 << 16) | (1 << 30);     // tile code 7 = bf16 stem kernel, scalar X
+  if (rc < 0) return rc;
+  pg::last_info() = 7 | (1 << 4) | (1 << 16) | (1 << 30) | (rc == 1 ? PG_INFO_STEM_BIAS : 0);     // tile code 7 = bf16 stem kernel, scalar X
   PG_LAUNCH_OK("pg_stem_wgrad_bf16");
   return 0;
 }

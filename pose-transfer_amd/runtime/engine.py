@@ -822,7 +822,9 @@ def _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, 
 
 
 def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
-           y_strides=None, ksplit=0, cout_store=0):
+           y_strides=None, ksplit=0, cout_store=0, dbias=None):
+    """dbias (first layers only): the layer's bias-gradient tensor; returns True when the weight-gradient pass produced it as
+    well (pg_stem_wgrad_bf16_v2: a constant-one input channel) — otherwise the caller runs the bias-gradient kernel."""
     dyb = None
     if _BF_CTX is not None and _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N,
                                             x_is_large, dY):
@@ -831,16 +833,19 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
         dyb = _BF_CTX.get(dY if isinstance(dY, int) else L.ptr(dY), Cout, L.ACT_NONE, None, None, N, Hy * Wy, dW.device)
     if not SIDE_STREAM or not torch.cuda.is_available():
         return _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x,
-                           y_strides, ksplit, cout_store, dyb)
+                           y_strides, ksplit, cout_store, dyb, dbias)
     side = _side_stream()
     L.call("pg_stream_wait", _raw(side), L.stream())
     with torch.cuda.stream(side):
-        _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x, y_strides,
-                    ksplit, cout_store, dyb)
+        return _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x, y_strides,
+                           ksplit, cout_store, dyb, dbias)
+
+
+STEM_BIAS_FUSED = os.environ.get("PG_NO_STEM_BIAS_FUSED") is None    # ablation switch: separate bias-gradient launches
 
 
 def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
-                y_strides=None, ksplit=0, cout_store=0, dy_bf16=None):
+                y_strides=None, ksplit=0, cout_store=0, dy_bf16=None, dbias=None):
     if _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large, dY):
         run = lambda: _wgrad_bf16_tr(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, dW, dy_bf16)
         if PROFILER is not None:
@@ -869,9 +874,13 @@ def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stri
         if ws is None:
             ws = _SCW_WS[dW.device] = torch.empty(SMALL_CIN_WGRAD_WS, dtype=torch.float32, device=dW.device)
         fn = "pg_stem_wgrad_bf16" if PRECISION == 3 and STEM_BF16 else "pg_small_cin_wgrad"
+        db = L.ptr(dbias) if (dbias is not None and STEM_BIAS_FUSED) else None
         if _is_bf16_ptr(dYp):
             assert fn == "pg_stem_wgrad_bf16", "bf16 storage needs the bf16 first-layer kernels"
-            run = lambda: L.call("pg_stem_wgrad_bf16_ex", arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, 1, L.ptr(dW), L.ptr(ws),
+            run = lambda: L.call("pg_stem_wgrad_bf16_v2", arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, 1, L.ptr(dW), db, L.ptr(ws),
+                                 ws.numel(), L.stream())
+        elif fn == "pg_stem_wgrad_bf16":
+            run = lambda: L.call("pg_stem_wgrad_bf16_v2", arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, 0, L.ptr(dW), db, L.ptr(ws),
                                  ws.numel(), L.stream())
         else:
             run = lambda: L.call(fn, arr, len(srcs), N, Hl, Wl, K, stride, pad, dYp, L.ptr(dW), L.ptr(ws), ws.numel(), L.stream())
@@ -879,7 +888,7 @@ def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stri
             PROFILER.launch("wgrad", 2.0 * N * Hs * Ws * K * K * Cin * Cout, run)
         else:
             run()
-        return
+        return bool(fn == "pg_stem_wgrad_bf16" and db is not None and (L.load().pg_last_launch_info() & L.INFO_STEM_BIAS))
     d = L.WgradDesc()
     for i, s in enumerate(srcs):
         d.src[i] = s
@@ -1476,15 +1485,17 @@ class GeneratorEngine:
         for e in self.encs:
             dz = self.e_dz[e][0]
             s0 = self._enc_in_src(e, self.input)
-            _debug_delay()
             if self.bfs:
                 assert image_grad is None, "bf16 storage: the chained (stacked) generator keeps fp32 storage"
-                L.call("pg_bias_grad_bf16", L.ptr(dz), N * H * W, self.enc[0], L.ptr(A.g(e + ".net.0.bias")), L.stream())
-            else:
-                L.call("pg_bias_grad", L.ptr(dz), N * H * W, 1, self.enc[0], self.enc[0], 0, 1,
-                       L.ptr(A.g(e + ".net.0.bias")), L.stream())
-            _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
-                   A.g(e + ".net.0.weight"), scalar_x=True)
+            # (round 4) the first layer's weight-gradient pass delivers the bias gradient as well where it can
+            if not _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
+                          A.g(e + ".net.0.weight"), scalar_x=True, dbias=A.g(e + ".net.0.bias")):
+                _debug_delay()
+                if self.bfs:
+                    L.call("pg_bias_grad_bf16", L.ptr(dz), N * H * W, self.enc[0], L.ptr(A.g(e + ".net.0.bias")), L.stream())
+                else:
+                    L.call("pg_bias_grad", L.ptr(dz), N * H * W, 1, self.enc[0], self.enc[0], 0, 1,
+                           L.ptr(A.g(e + ".net.0.bias")), L.stream())
             self._ready(e + ".net.0.")
             if image_grad is not None and e in ("encoder_app", "encoder"):
                 # data-gradient of the k3/s1/p1 first convolution restricted to its 3 image channels, written NCHW
@@ -1656,17 +1667,16 @@ class DiscriminatorEngine:
         # stem
         dz0 = self.dz[0]
         cin = 3 + 2 * self.P + 3
-        if need_wgrad:
-            _debug_delay()
-            L.call("pg_bias_grad", L.ptr(dz0), M * self.hs[0] * self.ws[0], 1, 64, 64, 0, 1, L.ptr(A.g("net.0.bias")),
-                   L.stream())
         off = 0
         for pi, pair in enumerate(self.inputs):
             n = pair[0].shape[0]
             dptr = dz0.data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
             if need_wgrad:
-                _wgrad([a.src() for a in self._stem_srcs(pair)], n, L.ACT_NONE, dptr, 64, cin, True, self.hs[0],
-                       self.ws[0], H, W, 4, 2, 0, A.g("net.0.weight"), scalar_x=True)
+                # (round 4) the stem's weight-gradient pass delivers this pair's share of the bias gradient where it can
+                if not _wgrad([a.src() for a in self._stem_srcs(pair)], n, L.ACT_NONE, dptr, 64, cin, True, self.hs[0],
+                              self.ws[0], H, W, 4, 2, 0, A.g("net.0.weight"), scalar_x=True, dbias=A.g("net.0.bias")):
+                    _debug_delay()
+                    L.call("pg_bias_grad", dptr, n * self.hs[0] * self.ws[0], 1, 64, 64, 0, 1, L.ptr(A.g("net.0.bias")), L.stream())
             if image_grad is not None and image_grad[pi] is not None:
                 g = image_grad[pi]
                 s = L.Src()

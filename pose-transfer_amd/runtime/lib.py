@@ -145,6 +145,7 @@ _PROTOS = {
     "pg_warp_mask_max_bwd_bbox": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "pg_stem_conv_bf16_v3": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp],
     "pg_stem_wgrad_bf16_ex": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
+    "pg_stem_wgrad_bf16_v2": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
     "pg_bias_grad_bf16": [_vp, _i64, _i32, _vp, _vp],
     "pg_tap_gather_pitch": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
     "pg_im2col_taps_bf16": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
@@ -234,6 +235,7 @@ DST_GRAD_BF16, DST_FWD_BF16 = 1, 2
 
 
 INFO_BSUMS = 1 << 14     # include/posegan_hip.h PG_INFO_BSUMS
+INFO_STEM_BIAS = 1 << 15  # PG_INFO_STEM_BIAS: pg_stem_wgrad_bf16_v2 also produced the bias gradient
 
 
 def make_dst(grad, C_, fwd=None, aff=None, mask=None, act=ACT_NONE, accumulate=False, bsums=None):

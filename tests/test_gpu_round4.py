@@ -313,3 +313,53 @@ def test_norm_backward_sums_fused_fp32_path(monkeypatch, size, n):
             assert float((a - b).abs()) <= 0.1 * scale + 1e-5, (k, float(a), float(b))
             continue
         assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, (k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("prec,store", [(3, True), (3, False)])
+def test_first_layer_bias_gradient_from_the_weight_gradient_pass(prec, store, monkeypatch):
+    """Round 4: on the bf16 data path the first layers' weight-gradient kernel carries a constant-one input channel in a spare
+    slot of its channel padding, so one tap's column of that channel is the BIAS gradient (pg_stem_wgrad_bf16_v2) and the
+    pg_bias_grad* launches do not run — generator (k3 p1, 21 / 18 input channels) and discriminator stem (k4 p0, 42).  Same
+    gradients as with the separate launches up to the bf16 rounding of the gradient tile (fp32 storage) / the summation order."""
+    monkeypatch.setattr(E, "PRECISION", prec)
+    monkeypatch.setattr(E, "BF16_STORE", store)
+    size, n = (64, 64), 4
+    inp, tgt, wr, mk = dev(*[t(a) for a in synth.batch(403, "sbias", n, P, *size)])
+    drops = dev(*[t(m) for m in synth.dropout_masks(403, "sbias", n)])
+    gout = t(synth.normal(403, "sbias/g", (n, 3, *size))).to(DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, "STEM_BIAS_FUSED", fused)
+        model = DeformablePose_GAN(_opt(size, n), device=DEV, init_seed=7)
+        eng = model.gen.engine(n)
+        eng.set_dropout(drops)
+        counts = {}
+
+        def hook(name, a, launch):
+            counts[name] = counts.get(name, 0) + 1
+            return launch()
+
+        model.gen.zero_grad()
+        model.disc.zero_grad()
+        out = eng.forward(inp, wr, mk)
+        deng = model.disc.engine(2 * n)
+        logits = deng.forward([(inp, tgt), (inp, out.detach().float().contiguous())])
+        dl = torch.linspace(-1.0, 1.0, logits.numel(), device=DEV).view_as(logits).contiguous()
+        monkeypatch.setattr(L, "CALL_HOOK", hook)
+        eng.backward(gout)
+        deng.backward(dl, need_wgrad=True)
+        monkeypatch.setattr(L, "CALL_HOOK", None)
+        torch.cuda.synchronize()
+        g = {("g", k): v.clone() for k, v in model.gen.arena.grad_dict().items() if k.endswith("net.0.bias") or k.endswith("net.0.weight")}
+        g.update({("d", k): v.clone() for k, v in model.disc.arena.grad_dict().items() if k in ("net.0.bias", "net.0.weight")})
+        res[fused] = (g, counts)
+    g1, c1 = res[True]
+    g0, c0 = res[False]
+    nb0 = c0.get("pg_bias_grad_bf16", 0) + c0.get("pg_bias_grad", 0)
+    nb1 = c1.get("pg_bias_grad_bf16", 0) + c1.get("pg_bias_grad", 0)
+    assert nb0 - nb1 == 4, (c0, c1)          # two generator first layers + the discriminator stem's two pairs
+    assert len(g0) == 6
+    for k in g0:
+        a, b = g1[k], g0[k]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-2 * scale + 1e-6, (k, float((a - b).abs().max()), scale)
