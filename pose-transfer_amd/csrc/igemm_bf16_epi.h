@@ -60,7 +60,72 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 template <int TN_, bool OB>
 __device__ __forceinline__ void big_store_64x64(const f32x16 (&acc)[2][TN_], float* T, const RowB* rows, int wm0, int lane, void* obase,
                                                 int n_cnt, int ngc, bool has_bias, float4 bv, bool do_stats, int n_lo, bool one_sample,
-                                                float (&st_s)[2], float (&st_q)[2], double* stats) {
+                                                float (&st_s)[2], float (&st_q)[2], double* stats, const float* bias = nullptr) {
+  if constexpr (OB) {
+    // bf16 rows (round 4): EIGHT columns per lane — 16-byte stores, half the store and row-table instructions of the 4-column
+    // form below (whose bf16 stores were 8 bytes); `bias` = the launch's bias vector or null (the caller's bv is per 4 columns)
+    constexpr int PITCH = 32 * TN_ + 4, LPR = 4 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int rsel = lane / LPR, c8 = (lane % LPR) * 8;
+    const int ncb = ngc - (lane % (8 * TN_)) * 4;            // the wave's first column
+    const int ng8 = ncb + c8;
+    const bool cval = ng8 < n_cnt;
+    char* const ob = reinterpret_cast<char*>(obase) + (size_t)ng8 * 2;
+    const unsigned rowb = (unsigned)n_cnt * 2u;
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (bias != nullptr && cval) { b0 = *reinterpret_cast<const float4*>(bias + ng8); b1 = *reinterpret_cast<const float4*>(bias + ng8 + 4); }
+    float tot_s = 0.f, tot_q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[i][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      int2 ro[NP];
+      float4 va[NP], vb[NP];
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int row = it * RPP + rsel;
+        ro[it] = *reinterpret_cast<const int2*>(&rows[wm0 + i * 32 + row]);            // (n, opix)
+        va[it] = *reinterpret_cast<const float4*>(&T[row * PITCH + c8]);
+        vb[it] = *reinterpret_cast<const float4*>(&T[row * PITCH + c8 + 4]);
+      }
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const bool ok = (ro[it].x >= 0) & cval;
+        if (has_bias) {
+          va[it].x += b0.x; va[it].y += b0.y; va[it].z += b0.z; va[it].w += b0.w;
+          vb[it].x += b1.x; vb[it].y += b1.y; vb[it].z += b1.z; vb[it].w += b1.w;
+        }
+        if (ok)
+          *reinterpret_cast<uint4*>(ob + (size_t)(unsigned)ro[it].y * rowb) =
+              make_uint4(pack_bf16(va[it].x, va[it].y), pack_bf16(va[it].z, va[it].w), pack_bf16(vb[it].x, vb[it].y), pack_bf16(vb[it].z, vb[it].w));
+        if (do_stats) {
+          float s4 = ((va[it].x + va[it].y) + (va[it].z + va[it].w)) + ((vb[it].x + vb[it].y) + (vb[it].z + vb[it].w));
+          float q4 = fmaf(va[it].x, va[it].x, fmaf(va[it].y, va[it].y, fmaf(va[it].z, va[it].z, va[it].w * va[it].w)));
+          q4 = fmaf(vb[it].x, vb[it].x, fmaf(vb[it].y, vb[it].y, fmaf(vb[it].z, vb[it].z, fmaf(vb[it].w, vb[it].w, q4))));
+          if (has_bias) { s4 = ok ? s4 : 0.f; q4 = ok ? q4 : 0.f; }
+          if (one_sample) { tot_s += s4; tot_q += q4; }
+          else {
+            const int dn = ro[it].x - n_lo;
+            st_s[0] += (ok && dn == 0) ? s4 : 0.f; st_q[0] += (ok && dn == 0) ? q4 : 0.f;
+            st_s[1] += (ok && dn == 1) ? s4 : 0.f; st_q[1] += (ok && dn == 1) ? q4 : 0.f;
+            if (ok && dn > 1) {
+              const float e8[8] = {va[it].x, va[it].y, va[it].z, va[it].w, vb[it].x, vb[it].y, vb[it].z, vb[it].w};
+#pragma unroll
+              for (int q = 0; q < 8; ++q) stat_spill(stats, ro[it].x, e8[q]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (one_sample) { st_s[0] += tot_s; st_q[0] += tot_q; }
+    return;
+  }
   const bool cval = ngc < n_cnt;             // n_cnt < the tile width only on the 32-column output-convolution launch
   constexpr int PITCH = 32 * TN_ + 4, LPR = 8 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -310,7 +375,7 @@ __device__ __forceinline__ void big_epilogue(const ConvK& p, f32x16 (&acc)[TM][T
       if (h == 0) stamp(14);
       if (p.out_bf16)
         big_store_64x64<TN, true>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
-                                  ngc, has_bias, bv, do_stats, n_lo, one_sample, st_s, st_q, p.stats);
+                                  ngc, has_bias, bv, do_stats, n_lo, one_sample, st_s, st_q, p.stats, p.bias);
       else
         big_store_64x64<TN, false>(*reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2 * h][0]), T, rows, wm0 + 64 * h, lane, out_g, p.n_cnt,
                                    ngc, has_bias, bv, do_stats, n_lo, one_sample, st_s, st_q, p.stats);
