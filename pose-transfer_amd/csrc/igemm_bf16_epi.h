@@ -328,6 +328,121 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
   if constexpr (BS) flush(run_n, run_s, run_q);
 }
 
+// (round 4) The SIMPLE scatter with EIGHT columns per lane: 16-byte loads of the forward values and 16-byte stores of the
+// gradient — half the global and row-table instructions of the 4-column form.  Caller: the wave's 64 columns lie in ONE destination
+// (wave-uniform descriptor), no mask, no accumulation, every column valid; `c0` = the wave's first column inside the destination.
+template <int TM_, int TN_, bool BS>
+__device__ __forceinline__ void big_scatter_tile8(const f32x16 (&acc)[TM_][TN_], float* T, const RowB* rows, int wm0, int lane,
+                                                  const LaneDst& d, int c0, int m_first, int gg, int M, int N,
+                                                  double* stab = nullptr, int nbase = 0, int stat_n = 0, int gslot = 0) {
+  constexpr int PITCH = 32 * TN_ + 4, LPR = 4 * TN_, RPP = 64 / LPR, NP = 32 / RPP;
+  static_assert(NP == 4, "big_scatter_tile8: 64-column wave tiles");
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int rsel = lane / LPR, c8 = (lane % LPR) * 8;
+  const unsigned dc = (unsigned)(c0 + c8);
+  struct Half {
+    uint4 fb[NP];
+    float2 ab[2];
+    int nlo;
+    unsigned ok;
+  };
+  const unsigned short* const fwd16 = reinterpret_cast<const unsigned short*>(d.fwdp);
+  unsigned short* const grad16 = reinterpret_cast<unsigned short*>(d.gradp);
+  auto issue = [&](int hh, Half& L) {
+    const int mf = min(m_first + 32 * hh, M - 1);
+    L.nlo = __builtin_amdgcn_readfirstlane(mf / gg);
+    const int nhi = min(L.nlo + 1, N - 1);
+    L.ok = 0;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int2 ro = *reinterpret_cast<const int2*>(&rows[wm0 + hh * 32 + it * RPP + rsel]);
+      const bool ok = ro.x >= 0;
+      const unsigned idx = ok ? (unsigned)ro.y * (unsigned)d.C + dc : dc;
+      L.ok |= (ok ? 1u : 0u) << it;
+      L.fb[it] = *reinterpret_cast<const uint4*>(fwd16 + (d.has_fwd ? idx : dc));
+    }
+    L.ab[0] = *reinterpret_cast<const float2*>(d.affp + d.affmul * L.nlo);
+    L.ab[1] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nhi);
+  };
+  int run_n = -1;
+  float run_s = 0.f, run_q = 0.f;
+  auto flush = [&](int n, float s_, float q_) {
+    const double ds = (double)wave_sum_dpp(s_), dq = (double)wave_sum_dpp(q_);
+    if (lane == 0 && n >= 0 && (ds != 0.0 || dq != 0.0)) {
+      const int sl = n - nbase;
+      if (sl >= 0 && sl < stat_n) { atomicAdd(&stab[sl * 2], ds); atomicAdd(&stab[sl * 2 + 1], dq); }
+      else {
+        atomicAdd(&d.bsums[((long)n * PG_STAT_SLOTS + gslot) * 2], ds);
+        atomicAdd(&d.bsums[((long)n * PG_STAT_SLOTS + gslot) * 2 + 1], dq);
+      }
+    }
+  };
+  auto step = [&](int hh, Half& cur, Half& nx, int nh) {
+    float hi_s = 0.f, hi_q = 0.f;
+    if constexpr (BS) {
+      if (cur.nlo != run_n) { flush(run_n, run_s, run_q); run_n = cur.nlo; run_s = 0.f; run_q = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PITCH + j * 32 + l31] = acc[hh][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint4 res[NP];
+    unsigned oidx[NP];
+    float4 va[NP], vb[NP];
+    int2 ro[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int row = u * RPP + rsel;
+      va[u] = *reinterpret_cast<const float4*>(&T[row * PITCH + c8]);
+      vb[u] = *reinterpret_cast<const float4*>(&T[row * PITCH + c8 + 4]);
+      ro[u] = *reinterpret_cast<const int2*>(&rows[wm0 + hh * 32 + row]);
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const bool hi = ro[u].x > cur.nlo;
+      const float a = hi ? cur.ab[1].x : cur.ab[0].x, bb = hi ? cur.ab[1].y : cur.ab[0].y;
+      const float g8[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      const uint4 fq = cur.fb[u];
+      const float f8[8] = {bf16_lo_f32(fq.x), bf16_hi_f32(fq.x), bf16_lo_f32(fq.y), bf16_hi_f32(fq.y),
+                           bf16_lo_f32(fq.z), bf16_hi_f32(fq.z), bf16_lo_f32(fq.w), bf16_hi_f32(fq.w)};
+      float r8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r8[e] = g8[e] * act_grad_s(fmaf(f8[e], a, bb), d.dslope);
+      res[u] = make_uint4(pack_bf16(r8[0], r8[1]), pack_bf16(r8[2], r8[3]), pack_bf16(r8[4], r8[5]), pack_bf16(r8[6], r8[7]));
+      oidx[u] = (unsigned)ro[u].y * (unsigned)d.C + dc;
+      if constexpr (BS) {
+        const float okf = ((cur.ok >> u) & 1u) ? 1.f : 0.f;
+        float s8 = 0.f, q8 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s8 += r8[e]; q8 = fmaf(r8[e], f8[e], q8); }
+        s8 *= okf; q8 *= okf;
+        run_s += hi ? 0.f : s8; run_q += hi ? 0.f : q8;
+        hi_s += hi ? s8 : 0.f; hi_q += hi ? q8 : 0.f;
+      }
+    }
+    if constexpr (BS) {
+      if (__builtin_amdgcn_ballot_w64(hi_s != 0.f || hi_q != 0.f) != 0) flush(cur.nlo + 1, hi_s, hi_q);      // rows of the next sample (rare)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned okh = cur.ok;
+    if (nh >= 0 && nh < TM_) issue(nh, nx);       // later halves' loads go out BEFORE this half's stores
+#pragma unroll
+    for (int it = 0; it < NP; ++it)
+      if ((okh >> it) & 1u) *reinterpret_cast<uint4*>(grad16 + oidx[it]) = res[it];
+  };
+  Half ha, hb, hc;
+  issue(0, ha);
+  if (TM_ > 1) issue(1, hb);
+  step(0, ha, hc, 2);
+  if (TM_ > 1) step(1, hb, ha, 3);
+  if (TM_ > 2) step(2, hc, hb, -1);
+  if (TM_ > 3) step(3, ha, hb, -1);
+  if constexpr (BS) flush(run_n, run_s, run_q);
+}
+
 // The whole epilogue of a 256-row kernel: partial tiles (split-K workspace), forward store (+ fused statistics), data-gradient
 // scatter (+ fused norm-backward sums).  sel_ok: rows outside the problem may hold non-zero accumulators (tap-pair kernel: their A
 // rows are shared with a neighbour) — the statistics then select on the row flag as they do with a bias.
@@ -449,14 +564,31 @@ __device__ __forceinline__ void big_epilogue(const ConvK& p, f32x16 (&acc)[TM][T
       const bool bs_on = __builtin_amdgcn_readfirstlane((int)(ld.bsums != nullptr && ld.has_fwd)) != 0;
       double* const stab = reinterpret_cast<double*>(smem + STAT_OFF);
       const int nbase = m0 / (p.Gy * p.Gx), gslot = (bx + by * 5 + bz * 3) % PG_STAT_SLOTS;
+      // (round 4) the wave's 64 columns in ONE destination, every column valid: the 8-columns-per-lane form of the plain scatter
+      const int cw0 = ld.c - (lane % (8 * TN)) * 4;           // the wave's first column inside its destination, if uniform
+      bool wide = false;
+      if constexpr (TN == 2) {
+        const int cw0u = __builtin_amdgcn_readfirstlane(cw0);
+        const unsigned long long gp = reinterpret_cast<unsigned long long>(ld.gradp), fp = reinterpret_cast<unsigned long long>(ld.fwdp);
+        const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gp), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gp >> 32));
+        const unsigned flo = __builtin_amdgcn_readfirstlane((unsigned)fp), fhi = __builtin_amdgcn_readfirstlane((unsigned)(fp >> 32));
+        wide = plain && __builtin_amdgcn_ballot_w64(cw0 != cw0u || (unsigned)gp != glo || (unsigned)(gp >> 32) != ghi || (unsigned)fp != flo ||
+                                                    (unsigned)(fp >> 32) != fhi || !cval) == 0;
+      }
       if (bs_on) {
-        if (plain) big_scatter_tile<TM, TN, true, true>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
+        if constexpr (TN == 2) {
+          if (wide) big_scatter_tile8<TM, TN, true>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
+        }
+        if (wide) {}
+        else if (plain) big_scatter_tile<TM, TN, true, true>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
         else big_scatter_tile<TM, TN, false, true>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
         __syncthreads();
         if (tid < STAT_N * 2) {
           const double v = stab[tid];
           if (v != 0.0) atomicAdd(&ld.bsums[((long)(nbase + (tid >> 1)) * PG_STAT_SLOTS + gslot) * 2 + (tid & 1)], v);
         }
+      } else if (wide) {
+        if constexpr (TN == 2) big_scatter_tile8<TM, TN, false>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N);
       } else if (plain) big_scatter_tile<TM, TN, true, false>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N);
       else big_scatter_tile<TM, TN, false, false>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N);
     } else {
