@@ -331,7 +331,7 @@ __device__ __forceinline__ void big_scatter_tile(const f32x16 (&acc)[TM_][TN_], 
 // (round 4) The SIMPLE scatter with EIGHT columns per lane: 16-byte loads of the forward values and 16-byte stores of the
 // gradient — half the global and row-table instructions of the 4-column form.  Caller: the wave's 64 columns lie in ONE destination
 // (wave-uniform descriptor), no mask, no accumulation, every column valid; `c0` = the wave's first column inside the destination.
-template <int TM_, int TN_, bool BS>
+template <int TM_, int TN_, bool BS, bool ACC>
 __device__ __forceinline__ void big_scatter_tile8(const f32x16 (&acc)[TM_][TN_], float* T, const RowB* rows, int wm0, int lane,
                                                   const LaneDst& d, int c0, int m_first, int gg, int M, int N,
                                                   double* stab = nullptr, int nbase = 0, int stat_n = 0, int gslot = 0) {
@@ -342,6 +342,7 @@ __device__ __forceinline__ void big_scatter_tile8(const f32x16 (&acc)[TM_][TN_],
   const unsigned dc = (unsigned)(c0 + c8);
   struct Half {
     uint4 fb[NP];
+    uint4 ob[ACC ? NP : 1];      // ACC: the gradient already stored there (the encoders' skip gradients are added to)
     float2 ab[2];
     int nlo;
     unsigned ok;
@@ -360,6 +361,7 @@ __device__ __forceinline__ void big_scatter_tile8(const f32x16 (&acc)[TM_][TN_],
       const unsigned idx = ok ? (unsigned)ro.y * (unsigned)d.C + dc : dc;
       L.ok |= (ok ? 1u : 0u) << it;
       L.fb[it] = *reinterpret_cast<const uint4*>(fwd16 + (d.has_fwd ? idx : dc));
+      if constexpr (ACC) L.ob[it] = *reinterpret_cast<const uint4*>(grad16 + idx);
     }
     L.ab[0] = *reinterpret_cast<const float2*>(d.affp + d.affmul * L.nlo);
     L.ab[1] = *reinterpret_cast<const float2*>(d.affp + d.affmul * nhi);
@@ -410,6 +412,13 @@ __device__ __forceinline__ void big_scatter_tile8(const f32x16 (&acc)[TM_][TN_],
       float r8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) r8[e] = g8[e] * act_grad_s(fmaf(f8[e], a, bb), d.dslope);
+      if constexpr (ACC) {
+        const uint4 oq = cur.ob[u];
+        const float o8[8] = {bf16_lo_f32(oq.x), bf16_hi_f32(oq.x), bf16_lo_f32(oq.y), bf16_hi_f32(oq.y),
+                             bf16_lo_f32(oq.z), bf16_hi_f32(oq.z), bf16_lo_f32(oq.w), bf16_hi_f32(oq.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r8[e] += o8[e];
+      }
       res[u] = make_uint4(pack_bf16(r8[0], r8[1]), pack_bf16(r8[2], r8[3]), pack_bf16(r8[4], r8[5]), pack_bf16(r8[6], r8[7]));
       oidx[u] = (unsigned)ro[u].y * (unsigned)d.C + dc;
       if constexpr (BS) {
@@ -433,13 +442,22 @@ __device__ __forceinline__ void big_scatter_tile8(const f32x16 (&acc)[TM_][TN_],
     for (int it = 0; it < NP; ++it)
       if ((okh >> it) & 1u) *reinterpret_cast<uint4*>(grad16 + oidx[it]) = res[it];
   };
-  Half ha, hb, hc;
-  issue(0, ha);
-  if (TM_ > 1) issue(1, hb);
-  step(0, ha, hc, 2);
-  if (TM_ > 1) step(1, hb, ha, 3);
-  if (TM_ > 2) step(2, hc, hb, -1);
-  if (TM_ > 3) step(3, ha, hb, -1);
+  if constexpr (!ACC) {
+    Half ha, hb, hc;              // few registers per half: two halves of loads in flight
+    issue(0, ha);
+    if (TM_ > 1) issue(1, hb);
+    step(0, ha, hc, 2);
+    if (TM_ > 1) step(1, hb, ha, 3);
+    if (TM_ > 2) step(2, hc, hb, -1);
+    if (TM_ > 3) step(3, ha, hb, -1);
+  } else {
+    Half ha, hb;
+    issue(0, ha);
+    step(0, ha, hb, 1);
+    if (TM_ > 1) step(1, hb, ha, 2);
+    if (TM_ > 2) step(2, ha, hb, 3);
+    if (TM_ > 3) step(3, hb, ha, -1);
+  }
   if constexpr (BS) flush(run_n, run_s, run_q);
 }
 
@@ -572,12 +590,13 @@ __device__ __forceinline__ void big_epilogue(const ConvK& p, f32x16 (&acc)[TM][T
         const unsigned long long gp = reinterpret_cast<unsigned long long>(ld.gradp), fp = reinterpret_cast<unsigned long long>(ld.fwdp);
         const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gp), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gp >> 32));
         const unsigned flo = __builtin_amdgcn_readfirstlane((unsigned)fp), fhi = __builtin_amdgcn_readfirstlane((unsigned)(fp >> 32));
-        wide = plain && __builtin_amdgcn_ballot_w64(cw0 != cw0u || (unsigned)gp != glo || (unsigned)(gp >> 32) != ghi || (unsigned)fp != flo ||
+        wide = __builtin_amdgcn_ballot_w64(ld.has_mask) == 0 && __builtin_amdgcn_ballot_w64(cw0 != cw0u || (unsigned)gp != glo || (unsigned)(gp >> 32) != ghi || (unsigned)fp != flo ||
                                                     (unsigned)(fp >> 32) != fhi || !cval) == 0;
       }
       if (bs_on) {
         if constexpr (TN == 2) {
-          if (wide) big_scatter_tile8<TM, TN, true>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
+          if (wide && plain) big_scatter_tile8<TM, TN, true, false>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
+          else if (wide) big_scatter_tile8<TM, TN, true, true>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
         }
         if (wide) {}
         else if (plain) big_scatter_tile<TM, TN, true, true>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N, stab, nbase, STAT_N, gslot);
@@ -588,7 +607,10 @@ __device__ __forceinline__ void big_epilogue(const ConvK& p, f32x16 (&acc)[TM][T
           if (v != 0.0) atomicAdd(&ld.bsums[((long)(nbase + (tid >> 1)) * PG_STAT_SLOTS + gslot) * 2 + (tid & 1)], v);
         }
       } else if (wide) {
-        if constexpr (TN == 2) big_scatter_tile8<TM, TN, false>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N);
+        if constexpr (TN == 2) {
+          if (plain) big_scatter_tile8<TM, TN, false, false>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N);
+          else big_scatter_tile8<TM, TN, false, true>(acc, T, rows, wm0, lane, ld, cw0, mfw, p.Gy * p.Gx, p.M, p.N);
+        }
       } else if (plain) big_scatter_tile<TM, TN, true, false>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N);
       else big_scatter_tile<TM, TN, false, false>(acc, T, rows, wm0, lane, ld, cval, mfw, p.Gy * p.Gx, p.M, p.N);
     } else {
