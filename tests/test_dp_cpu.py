@@ -213,7 +213,9 @@ def _bf16_bucket_worker(rank, world, port, q):
             g = (g16.float() if g16 is not None else g32) / world
             params = opt.step(params, {"p": g})
         out[dtype] = params["p"].clone()
-    q.put((rank, out["f32"], out["bf16"]))
+    # numpy arrays travel BY VALUE: a torch tensor in a multiprocessing queue is passed as a file descriptor that the parent fetches
+    # from this process — which may have exited by then (FileNotFoundError in the parent, one run in three under load)
+    q.put((rank, out["f32"].numpy().copy(), out["bf16"].numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -229,7 +231,7 @@ def test_bf16_bucket_sum_of_8_ranks_parameter_error():
     port = _free_port()
     procs = [ctx.Process(target=_bf16_bucket_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = {r: (a, b) for r, a, b in (q.get(timeout=300) for _ in procs)}
+    res = {r: (torch.from_numpy(a), torch.from_numpy(b)) for r, a, b in (q.get(timeout=300) for _ in procs)}
     [p.join(60) for p in procs]
     p32, p16 = res[0]
     for r in range(1, world):          # all ranks hold identical parameters in both modes
