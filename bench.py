@@ -44,16 +44,26 @@ P = 18                            # key-points; --pose_dim overrides (config 3 u
 
 
 def make_opt(args):
-    return SimpleNamespace(image_size=(args.size, args.size), use_input_pose=True, pose_dim=P, batch_size=args.batch,
+    return SimpleNamespace(image_size=(args.size, args.size), use_input_pose=True, pose_dim=_kp(args), batch_size=args.batch,
                            num_stacks=4, gen_type="baseline", dataset="fasion", warp_skip="mask", learning_rate=2e-4,
                            content_loss_layer=args.content_loss_layer, nn_loss_area_size=args.nn_loss_area_size,
                            gan_penalty_weight=1.0, l1_penalty_weight=args.l1_penalty_weight)
 
 
+def _kp(args):
+    return int(getattr(args, "pose_dim", P))
+
+
 def iteration(model, batches, od):
+    """one training iteration as main.py runs it (reference main.py:77-108): the batch of the generator update is drawn first
+    and its generator forward enqueued ahead (DeformablePose_GAN.prefetch_gen_forward: dis_update does not touch the generator's
+    weights), then dis_update, then gen_update"""
     a, b, c = batches
+    oc = {"warps": c[2], "masks": c[3]}
+    if hasattr(model, "prefetch_gen_forward"):
+        model.prefetch_gen_forward(c[0], oc)
     model.dis_update(a[0], a[1], {"warps": a[2], "masks": a[3]}, b[0], b[1], od)
-    model.gen_update(c[0], c[1], {"warps": c[2], "masks": c[3]}, od)
+    model.gen_update(c[0], c[1], oc, od)
 
 
 def step_flops(size, pose_dim):
@@ -86,10 +96,11 @@ def parity_device_iteration(args, device, rank):
     n = min(args.batch, 4)
     o = make_opt(args)
     o.batch_size = n
+    kp = _kp(args)
     model = DeformablePose_GAN(o, device=device, init_seed=0)
     gsd = {k: v.detach().cpu().clone() for k, v in model.gen.state_dict().items()}
     dsd = {k: v.detach().cpu().clone() for k, v in model.disc.state_dict().items()}
-    host = [synth.batch(1234 + rank, "bench/%s" % s_, n, P, args.size, args.size) for s_ in "ABC"]
+    host = [synth.batch(1234 + rank, "bench/%s" % s_, n, kp, args.size, args.size) for s_ in "ABC"]
     drops = [synth.dropout_masks(1234 + rank, "bench/d%s" % s_, n) for s_ in "AC"]
     dev = lambda arrs: [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in arrs]
     a, b, c = [dev(h) for h in host]
@@ -103,7 +114,7 @@ def parity_device_iteration(args, device, rank):
     return {"n": n, "gen_sd": gsd, "disc_sd": dsd, "host": host, "drops": drops, "device": res}
 
 
-def cpu_baseline(args, pin=None):
+def cpu_baseline(args, pin=None, iters=None):
     """Oracle (kind 'port') on the host cores: dis_update + gen_update at the bench resolution and per-GPU batch (capped at
     4), 1 warm-up + 3 timed iterations.  With `pin` (parity_device_iteration) the oracle starts from the SAME
     weights, batches and dropout masks as the device did, and its warm-up iteration doubles as the parity check."""
@@ -111,6 +122,8 @@ def cpu_baseline(args, pin=None):
     import ref_cpu as R
     n = min(args.batch, 4)
     size = args.size
+    P = _kp(args)
+    iters = args.cpu_iters if iters is None else iters
     enc, dec = synth.nfilters((size, size))
     t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
     cfg = dict(pose_dim=P, image_size=(size, size), batch_size=n, gan_penalty_weight=1.0,
@@ -149,7 +162,9 @@ def cpu_baseline(args, pin=None):
                   "what": "first dis_update+gen_update from identical weights / batches / dropout masks, %dx%d, batch %d, %s "
                           "on the device vs oracle/ref_cpu.py (fp32, torch-CPU); bars (fp32): out_gen <= 1e-3 max-abs, losses <= "
                           "1e-4 relative (SURVEY.md 8d)" % (size, size, n, args.precision)}
-    times = [iteration() for _ in range(args.cpu_iters)]
+    if iters <= 0:             # parity only (the extra configuration legs): the warm-up iteration WAS the check
+        return {"warmup_iteration_s": round(warm, 2), "cores": cores}, parity
+    times = [iteration() for _ in range(iters)]
     dt = sum(times) / len(times)
     out = {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
            "work": "4 F_G + 8 F_D port (the reference as written executes 6 F_G + 9 F_D: its dis_update also back-propagates "
@@ -214,6 +229,36 @@ def north_star_legs(device, passes, steps):
               "workload": "Deformable_Generator forward + backward, 256x256, 18 kpts, batch 32, bf16 data path "
                           "(bf16 operands and storage, fp32 accumulate / statistics / master weights), warp_skip=mask, "
                           "random dropout; target >= 0.5 (<= 10.6 ms)"}
+        # per-family table of the SAME pass, single stream (no concurrent weight-gradient / warp / encoder streams: a launch's
+        # HIP-event duration is that kernel alone), each launch credited with the faster of two repeats — so that the dominant
+        # kernel's fraction of the bf16 peak can be recomputed from this line alone
+        side, E.SIDE_STREAM = E.SIDE_STREAM, False
+        try:
+            one_pass()
+            torch.cuda.synchronize()
+            E.PROFILER = E.KernelProfiler()
+            one_pass()
+            one_pass()
+            torch.cuda.synchronize()
+            fam = E.PROFILER.summary(None, repeats=2)
+            E.PROFILER = None
+            hp = HbmProfiler()
+            _L.CALL_HOOK = hp.hook
+            for _ in range(2):
+                one_pass()
+            torch.cuda.synchronize()
+            _L.CALL_HOOK = None
+            ns["families"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "gflop": round(v["flops"] * 1e-9, 1),
+                                  "tflops": round(v["flops"] / max(v["ms"], 1e-9) * 1e-9, 1),
+                                  "frac_of_bf16_peak": round(v["flops"] / max(v["ms"], 1e-9) * 1e-9 / PEAK_BF16_MFMA_TFLOPS, 4)}
+                              for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+            ns["contraction_ms_single_stream"] = round(sum(v["ms"] for v in fam.values()), 3)
+            ns["hbm_kernels"] = hp.summary(repeats=2)
+            ns["hbm_side_ms_single_stream"] = round(sum(e["ms"] for e in ns["hbm_kernels"]), 3)
+        finally:
+            E.PROFILER = None
+            _L.CALL_HOOK = None
+            E.SIDE_STREAM = side
         od = dict(vars(o), lazy_losses=True)
         for _ in range(3):
             iteration(model, batches, od)
@@ -230,6 +275,58 @@ def north_star_legs(device, passes, steps):
         return ns, b32
     finally:
         E.PRECISION = prev
+
+
+PREC_CODE = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}
+
+
+def config_leg(device, cfg, steps, parity_n=0):
+    """One more BASELINE.json configuration under the driver's clock (single GPU, rank 0): throughput of the full iteration at
+    the configuration's own per-GPU batch and — with parity_n > 0 — `parity` of the FIRST iteration at batch parity_n (same
+    weights / batches / dropout masks on the device and in the CPU oracle; the norm and every loss are per-sample, so a smaller
+    batch checks the same arithmetic).  cfg: size, batch, pose_dim, precision, content_loss_layer, nn_loss_area_size,
+    l1_penalty_weight."""
+    import copy
+    prev = E.PRECISION
+    E.PRECISION = PREC_CODE[cfg.precision]
+    try:
+        pin = pargs = None
+        if parity_n > 0:
+            pargs = copy.copy(cfg)
+            pargs.batch = parity_n
+            pin = parity_device_iteration(pargs, device, 0)
+        o = make_opt(cfg)
+        kp = _kp(cfg)
+        model = DeformablePose_GAN(o, device=device, init_seed=0)
+        dev = lambda arrs: [torch.from_numpy(a).to(device) for a in arrs]
+        batches = [dev(synth.batch(1234, "leg/%s" % s_, cfg.batch, kp, cfg.size, cfg.size)) for s_ in "ABC"]
+        od = dict(vars(o), lazy_losses=True)
+        for _ in range(5):
+            iteration(model, batches, od)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            iteration(model, batches, od)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        sf, _, _ = step_flops(cfg.size, kp)
+        peak = PEAK_BF16_MFMA_TFLOPS if cfg.precision in ("bf16", "bf16_data") else PEAK_F32_MFMA_TFLOPS
+        leg = {"value": round(cfg.batch / dt, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+               "step_tflops": round(sf * cfg.batch / dt / 1e12, 2), "step_frac_of_peak": round(sf * cfg.batch / dt / 1e12 / peak, 4),
+               "peak": peak,
+               "workload": "dis_update + gen_update, %dx%d, %d kpts, batch %d, %s, content_loss_layer=%s nn_loss_area_size=%d "
+                           "l1_penalty_weight=%g, 1 GPU" % (cfg.size, cfg.size, kp, cfg.batch, PREC_TEXT[cfg.precision],
+                                                            cfg.content_loss_layer, cfg.nn_loss_area_size, cfg.l1_penalty_weight)}
+        del model, batches
+        torch.cuda.empty_cache()
+    finally:
+        E.PRECISION = prev
+    if pin is not None:
+        _, leg["parity"] = cpu_baseline(pargs, pin, iters=0)
+        if cfg.precision != "f32":
+            leg["parity"]["what"] += ("; NOT an fp32 path: the stated bf16 envelope is tests/test_gpu_round5.py BF16_TOL "
+                                      "(2 x the worst value observed over 3 seeds at 256x256, profiles/round5_bf16_tolerance.txt)")
+    return leg
 
 
 PREC_TEXT = {"f32": "fp32", "bf16x3": "fp32 storage, bf16x3 split MFMA operands", "bf16": "fp32 storage, bf16 MFMA operands",
@@ -296,6 +393,10 @@ HBM_MODELS = {
     "pg_tap_gather_pitch": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (27 * 4 + 12),
     # output-conv backward, bf16 storage, ONE pass: dpre (12 B / pixel) + activated operand read once + gradient write (2 + 2 B / channel)
     "pg_out_conv_bwd_direct": lambda a: _ival(a[3]) * _ival(a[4]) * _ival(a[5]) * (12 + 4 * sum(a[6][i].C for i in range(_ival(a[7])))),
+    # (round 4 / 5) norm backward apply with the sums taken from the producer; materialise with the finalize folded in
+    "pg_norm_bwd_apply_v2": lambda a: (6 if _ival(a[11]) == 3 else (14 if a[10] else 12)) * _ival(a[6]) * _ival(a[7]),
+    "pg_norm_bwd_apply_v3": lambda a: (6 if _ival(a[11]) == 3 else (14 if a[10] else 12)) * _ival(a[6]) * _ival(a[7]),
+    "pg_materialise_bf16_norm": lambda a: ((2 if _ival(a[1]) else 4) + (4 if a[15] else 2)) * _ival(a[11]) * _ival(a[12]) * _ival(a[13]),
     "pg_l1_loss": lambda a: 12 * _ival(a[2]),
     "pg_tanh_bwd": lambda a: 12 * _ival(a[2]),
 }
@@ -467,7 +568,11 @@ def dry_run(world, rank, local):
         fail("bench.py --dry-run: the all-reduce returned %r" % float(t.item()), 3)
 
 
-def main():
+def main(argv=None, model_factory=None):
+    """model_factory (tests only — tests/test_dp_cpu.py): callable(opt, device, rank, world) -> an object with dis_update /
+    gen_update / g_reducer / d_reducer standing in for DeformablePose_GAN on a box without a GPU, so that THIS function's
+    N > 1 path (rendezvous, barriers, max-over-ranks timing, the `dp` block, the JSON line) runs end to end on gloo.  The
+    product never passes it: without it a missing GPU is a hard error."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # SURVEY.md §8d: >= 10 warm-up + >= 50 timed iterations
@@ -493,17 +598,21 @@ def main():
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the bf16 batch-32 legs (`north_star`, `bf16_data_b32_img_s`; N=1 only)")
     ap.add_argument("--north-star-passes", type=int, default=20)
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the extra configuration legs (`bf16_data_b4_img_s`, `cfg2_224_p32_b8_bf16`, `cfg3_nnloss_vgg_b4`; N=1 only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check: the ranks rendezvous, all-reduce their rank numbers and rank 0 prints one JSON line; no "
                          "model (works without a GPU: gloo)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--launch-table", default=None, help="write one line per contraction launch of the profiled iteration here")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     global P
     P = args.pose_dim
-    E.PRECISION = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16_data": 3}[args.precision]
+    E.PRECISION = PREC_CODE[args.precision]
+    stand_in = model_factory is not None
 
-    maybe_spawn(args)                 # --gpus N without a launcher: re-executes under torch.distributed.run, never returns
+    if not stand_in:
+        maybe_spawn(args)             # --gpus N without a launcher: re-executes under torch.distributed.run, never returns
     world = dp.init_from_env()
     rank = dp.rank()
     if world != args.gpus:
@@ -513,27 +622,35 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dry_run:
         return dry_run(world, rank, local)
-    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
-        fail("bench.py: rank %d needs GPU %d but %d GPU(s) are visible (no CPU fallback exists)"
-             % (rank, local, torch.cuda.device_count() if torch.cuda.is_available() else 0))
-    device = "cuda:%d" % local
-    torch.cuda.set_device(device)
+    if stand_in:
+        device = "cpu"
+        args.no_kernel_profile = args.no_north_star = args.no_cpu_baseline = args.no_config_legs = True
+    else:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+            fail("bench.py: rank %d needs GPU %d but %d GPU(s) are visible (no CPU fallback exists)"
+                 % (rank, local, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        device = "cuda:%d" % local
+        torch.cuda.set_device(device)
+
+    def sync():
+        if not stand_in:
+            torch.cuda.synchronize()
 
     opt = make_opt(args)
     # N=1: the pinned first iteration for the `parity` field (its own model instance; the oracle repeats it in cpu_baseline)
     pin = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         pin = parity_device_iteration(args, device, rank)
-    model = DeformablePose_GAN(opt, device=device, init_seed=0)
+    model = model_factory(opt, device, rank, world) if stand_in else DeformablePose_GAN(opt, device=device, init_seed=0)
     od = dict(vars(opt), lazy_losses=True)
     dev = lambda arrs: [torch.from_numpy(a).to(device) for a in arrs]
     batches = [dev(synth.batch(1234 + rank, "bench/%s" % s, args.batch, P, args.size, args.size)) for s in "ABC"]
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     graphed = None
     if args.graph:
@@ -567,6 +684,7 @@ def main():
     # what the data-parallel transport itself reports (RCCL communicator behind the C ABI: ncclCommCount)
     rccl_ranks, transport = 1, "single process (no collective)"
     red = getattr(model, "g_reducer", None)
+    dp_block = None
     if red is not None:
         if red.comm is not None:
             import ctypes
@@ -575,8 +693,31 @@ def main():
             _Lc.check(_Lc.load().pg_comm_ranks(red.comm, ctypes.byref(r_), ctypes.byref(w_)), "pg_comm_ranks")
             rccl_ranks, transport = int(w_.value), "RCCL ncclAllReduce behind the C ABI (pg_comm_*), %s buckets" % red.grad_dtype
         else:
-            rccl_ranks, transport = torch.distributed.get_world_size(), "torch.distributed all_reduce (%s), %s buckets" % (
-                torch.distributed.get_backend(), red.grad_dtype)
+            rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+            transport = "torch.distributed all_reduce (%s), %s buckets" % (
+                torch.distributed.get_backend() if torch.distributed.is_initialized() else "none", red.grad_dtype)
+        # ---- `dp`: one more un-timed iteration with every collective bracketed by events on the communication stream —
+        # per-bucket bytes / time and the EXPOSED communication time (how long the optimiser's stream waited in finish())
+        reds = [("gen", model.g_reducer), ("disc", getattr(model, "d_reducer", None))]
+        for _, r in reds:
+            if r is not None:
+                r.profile = True
+        barrier()
+        iteration(model, batches, od)
+        barrier()
+        prof = {}
+        for nm, r in reds:
+            if r is not None:
+                prof[nm] = r.comm_profile()
+                r.profile = False
+        ex = [v["exposed_ms"] for v in prof.values() if v["exposed_ms"] is not None]
+        dp_block = {"ranks": world, "rccl_ranks": rccl_ranks, "transport": transport,
+                    "allreduce_ms_per_step": round(sum(v["allreduce_ms"] for v in prof.values()), 4),
+                    "exposed_comm_ms_per_step": round(sum(ex), 4) if ex else None,
+                    "bytes_per_step": int(sum(v["bytes"] for v in prof.values())),
+                    "what": "rank 0, one extra iteration after the timed region: per bucket = pack + all-reduce on the communication "
+                            "stream (HIP events; gloo: launch -> completion wall time); exposed = how much later than the "
+                            "optimiser's stream the communication stream finished (finish())", **prof}
 
     # ---- roofline leg: one extra profiled iteration, HIP events around every contraction launch
     roof = None
@@ -629,12 +770,31 @@ def main():
             E.SIDE_STREAM = side
         hbm = prof.summary(repeats=3)
     ns = b32 = None
-    if rank == 0 and world == 1 and not args.no_north_star:
+    legs = {}
+    single = rank == 0 and world == 1 and not stand_in
+    if single and not (args.no_north_star and args.no_config_legs):
         del model, batches, step, graphed
         torch.cuda.empty_cache()
+    if single and not args.no_north_star:
         ns, b32 = north_star_legs(device, args.north_star_passes, args.north_star_passes)
+    if single and not args.no_config_legs:
+        # the remaining BASELINE.json configurations under the driver's clock:
+        #   configs[1]'s shape on the bf16 data path = what each of 8 GPUs runs in configs[3] (batch 32 / 8 GPUs);
+        #   configs[2] as written (224 x 224, 32 key-points, batch 8, bf16);
+        #   configs[3]'s per-GPU shape (nn-loss 5 x 5 + VGG block1_conv2, l1_penalty_weight 0.01, batch 4) in fp32 with parity
+        ns_ = SimpleNamespace
+        par = 0 if args.no_cpu_baseline else 2
+        legs["bf16_data_b4_img_s"] = config_leg(device, ns_(size=256, batch=4, pose_dim=18, precision="bf16_data",
+                                                            content_loss_layer="none", nn_loss_area_size=1,
+                                                            l1_penalty_weight=100.0), steps=40, parity_n=0)
+        legs["cfg2_224_p32_b8_bf16"] = config_leg(device, ns_(size=224, batch=8, pose_dim=32, precision="bf16_data",
+                                                              content_loss_layer="none", nn_loss_area_size=1,
+                                                              l1_penalty_weight=100.0), steps=30, parity_n=par)
+        legs["cfg3_nnloss_vgg_b4"] = config_leg(device, ns_(size=256, batch=4, pose_dim=18, precision="f32",
+                                                            content_loss_layer="block1_conv2", nn_loss_area_size=5,
+                                                            l1_penalty_weight=0.01), steps=20, parity_n=par)
     cpu = parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(args, pin)
 
     if rank == 0:
@@ -651,16 +811,18 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "content_loss_layer": args.content_loss_layer, "nn_loss_area_size": args.nn_loss_area_size,
                        "precision": args.precision, **({"hip_graph": True} if args.graph else {}),
-                       **({"launch_tape": True} if args.tape else {})},
+                       **({"launch_tape": True} if args.tape else {}),
+                       **({"stand_in_model": True} if stand_in else {})},
             "step_tflops": round(sf * ips / 1e12, 2),
             "step_frac_of_f32_mfma_peak": round(sf * ips / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "roofline": roof, "parity": parity, "north_star": ns, "bf16_data_b32_img_s": b32,
+            "roofline": roof, "parity": parity, "north_star": ns, "bf16_data_b32_img_s": b32, **legs,
             "rccl_ranks": rccl_ranks, "dp_transport": transport, "per_rank_img_s": [round(v, 3) for v in per_rank],
-            "hbm_kernels": hbm, "cpu_baseline": cpu,
+            "dp": dp_block, "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    return None
 
 
 if __name__ == "__main__":

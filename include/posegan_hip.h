@@ -393,6 +393,18 @@ int pg_apply_affine_act(const float* x, const float* aff, const float* mask, int
 
 const char* pg_last_error(void);
 int pg_version(void);
+/* (round 5) PG_DETERMINISTIC: run-to-run bit-repeatable results at the price of speed.  Every launch path whose result depends on
+ * an arrival order is replaced by an ordered one: split-K contractions only through the workspace + fix-up pass (summed in split
+ * order) or un-split; weight gradients un-split (no float atomics on dW); bias / first-layer / output-convolution partial
+ * reductions by one serial walk per element; loss sums (pg_l1_loss, pg_gan_logloss) by one workgroup; the warp backward's
+ * per-pixel candidate lists sorted before they are summed.  What keeps an arrival order: DOUBLE atomics on the per-sample
+ * statistics (fp32-invisible: the order moves a 53-bit sum of fp32-accurate partials in its last bits), the value (not the
+ * gradient) of pg_nn_loss, and the float-atomic scatter of warp transforms that shrink by more than ~0.6 (none in the synthetic
+ * or data-set transforms).  The environment variable PG_DETERMINISTIC=1 sets the initial value; pg_set_deterministic flips it at
+ * run time (host-side flag, read per launch).  The reference has no counterpart (torch.use_deterministic_algorithms is never
+ * called in src_deformable). */
+int pg_set_deterministic(int32_t on);
+int pg_get_deterministic(void);
 /* diagnostics: tile config | loader modes << 4/8 | split-K << 16 of this thread's last pg_conv / pg_conv_wgrad */
 int pg_last_launch_info(void);
 /* timing helper for bench.py: HIP events on the caller's stream (torch.cuda.Event sees only torch's). */
@@ -445,6 +457,16 @@ int pg_norm_bwd_apply_io(void* dz, const void* y, const float* mr, const double*
 int pg_norm_bwd_apply_v2(void* dz, const void* y, const float* mr, const double* sums, const float* gamma, const float* beta,
                          int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags,
                          int32_t sums_mode, void* stream);
+/* (round 5) sums_mode 2 divides by gamma: ill-conditioned when |gamma| < 1e-3 + 0.02 |beta| (undefined at gamma == 0, where the
+ * gamma gradient could never leave zero).  pg_norm_bwd_reduce_guard is pg_norm_bwd_reduce_ex that runs ONLY then — the predicate
+ * is evaluated on the device from (gamma, beta), no host synchronisation; every workgroup of a well-conditioned layer exits at
+ * once — into `bsums_guard` [N][2] (caller-zeroed); pg_norm_bwd_apply_v3 is pg_norm_bwd_apply_v2 that reads `bsums_guard` under
+ * the same predicate (sums_mode 2 only; NULL = the v2 behaviour).  Reference: autograd of nn.InstanceNorm3d, networks.py:159. */
+int pg_norm_bwd_reduce_guard(const void* dz, const void* y, const float* mr, const float* gamma, const float* beta, int32_t N,
+                             int64_t L, double* bsums_guard, int32_t io_flags, void* stream);
+int pg_norm_bwd_apply_v3(void* dz, const void* y, const float* mr, const double* sums, const float* gamma, const float* beta,
+                         int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16, int32_t io_flags,
+                         int32_t sums_mode, const double* bsums_guard, void* stream);
 /* io_flags: bit 0 = feat is bf16, bit 1 = out is bf16, bit 2 = store relu(out) (the decoder reads the warped skip only
  * through its ReLU; relu(x) > 0 <=> x > 0 keeps the backward's activation derivative) */
 int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const float* warps, const float* lvl_masks, int32_t N,

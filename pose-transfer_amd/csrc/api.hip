@@ -1,5 +1,6 @@
 // libposegan_hip: error reporting, version, HIP-event timing helpers.
 #include "common.h"
+#include <cstdlib>
 
 namespace pg {
 char* err_buf() {
@@ -10,7 +11,15 @@ int& last_info() {
   static thread_local int v = 0;
   return v;
 }
+int& deterministic_flag() {
+  static int v = [] { const char* e = getenv("PG_DETERMINISTIC"); return (e != nullptr && e[0] != '0') ? 1 : 0; }();
+  return v;
+}
 }  // namespace pg
+
+// PG_DETERMINISTIC at run time (the environment variable sets the initial value): see common.h
+extern "C" int pg_set_deterministic(int32_t on) { pg::deterministic_flag() = on ? 1 : 0; return 0; }
+extern "C" int pg_get_deterministic(void) { return pg::deterministic_flag(); }
 
 extern "C" int pg_last_launch_info(void) { return pg::last_info(); }
 extern "C" const char* pg_last_error(void) { return pg::err_buf(); }

@@ -66,6 +66,15 @@ struct Env {
 };
 inline const Env& env() { static const Env e; return e; }
 
+// PG_DETERMINISTIC (round 5; pg_set_deterministic / the environment variable at load time): every launch path whose result
+// depends on an arrival order is replaced by an ordered one — split-K contractions only through the workspace + fix-up pass (or
+// un-split), weight gradients un-split (no float atomics on dW), bias / first-layer reductions by ONE workgroup per output, losses by
+// one workgroup, the warp backward without its float-atomic scatter fall-back... slower, bit-repeatable run to run.  What stays:
+// DOUBLE atomics on the per-sample statistics (sums of fp32-accurate partials whose order moves the 53-bit result in its last
+// bits: invisible after the conversion to fp32 except with probability ~1e-8 per sum).  Host-side flag.
+int& deterministic_flag();
+inline bool deterministic() { return deterministic_flag() != 0; }
+
 // ---- launch tape (round 3, api.hip: pg_tape_*).  Every kernel launch / memset / stream-ordering call of the library goes through
 // these macros: it is issued as usual and, while the calling thread records, also kept as a closure (kernel, geometry, stream
 // and a COPY of the argument block).  pg_tape_replay re-issues the closures: one C call per training iteration instead of

@@ -1726,6 +1726,26 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   };
   if (d->ksplit <= 0 && d->workspace != nullptr)
     while (ks > 1 && !splits_nonempty(ks)) --ks;
+  // split-K through the caller's workspace (plain partial stores + splitk_fixup_kernel, summed in split order) when it is big enough
+  const double out_elems = (double)d->N * d->Ho * d->Wo * k.n_cnt;
+  auto part_ok = [&](int c) {
+    if (!(c > 1 && d->workspace != nullptr && tb == nullptr && k.n_cnt % 4 == 0 && splits_nonempty(c) &&
+          ((size_t)d->workspace & 15) == 0 && out_elems < 2147483648.0 && (double)c * out_elems * 4.0 <= (double)d->workspace_bytes &&
+          !env().no_splitk_ws))
+      return false;
+    if (d->epilogue == 0) {
+      if (((size_t)d->out & 15) != 0 || (d->bias && ((size_t)d->bias & 15) != 0)) return false;
+    } else {
+      for (int j = 0; j < d->ndst; ++j)
+        if (d->dst[j].C % 4 != 0 || ((size_t)d->dst[j].grad & 15) != 0 || ((size_t)d->dst[j].fwd & 15) != 0 ||
+            ((size_t)d->dst[j].mask & 15) != 0)
+          return false;
+    }
+    return true;
+  };
+  // PG_DETERMINISTIC: a split launch that cannot take the workspace path would add its splits with float atomics (arrival
+  // order = rounding order) — it runs un-split instead
+  if (deterministic() && ks > 1 && !part_ok(ks)) ks = 1;
   k.ksplit = ks;
   k.stats = nullptr;
   if (d->stats != nullptr) {
@@ -1734,22 +1754,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
                "pg_conv: fused statistics need a dense NHWC output without output activation");
     if (ks == 1) k.stats = d->stats;
   }
-  // split-K through the caller's workspace (plain partial stores + splitk_fixup_kernel) when it is big enough
-  bool use_part = false;
-  const double out_elems = (double)d->N * d->Ho * d->Wo * k.n_cnt;
-  if (ks > 1 && d->workspace != nullptr && tb == nullptr && k.n_cnt % 4 == 0 && splits_nonempty(ks) &&
-      ((size_t)d->workspace & 15) == 0 && out_elems < 2147483648.0 && (double)ks * out_elems * 4.0 <= (double)d->workspace_bytes &&
-      !env().no_splitk_ws) {
-    use_part = true;
-    if (d->epilogue == 0) {
-      if (((size_t)d->out & 15) != 0 || (d->bias && ((size_t)d->bias & 15) != 0)) use_part = false;
-    } else {
-      for (int j = 0; j < d->ndst; ++j)
-        if (d->dst[j].C % 4 != 0 || ((size_t)d->dst[j].grad & 15) != 0 || ((size_t)d->dst[j].fwd & 15) != 0 ||
-            ((size_t)d->dst[j].mask & 15) != 0)
-          use_part = false;
-    }
-  }
+  const bool use_part = part_ok(ks);
   {
     const bool dense0 = d->epilogue == 0 && d->oC == 1 && d->oW == (long)k.n_cnt && d->oH == (long)d->Wo * k.n_cnt &&
                         d->oN == (long)d->Ho * d->Wo * k.n_cnt && ((size_t)d->out & 15) == 0 &&

@@ -645,6 +645,9 @@ extern "C" int pg_conv_wgrad(const pg_wgrad_t* d, void* stream) {
     if (ks > 512) ks = 512;
     if (ks < 1) ks = 1;
   }
+  // PG_DETERMINISTIC: no K split across workgroups (their float atomics on dW would round in arrival order).  The tiles that split
+  // K inside the workgroup (WGK = 2) add exactly two values into a zero-initialised element: commutative, order-free.
+  if (deterministic()) ks = 1;
   k.ksplit = ks;
   dim3 grid(nt, mt, k.ntaps * ks);
 #define PG_WG(BM, WGM, WGN, WGK, XS, YS) \
@@ -821,12 +824,13 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
     // every workgroup ends with C float atomics on the SAME C addresses: measured ~90 ns per workgroup, serialised
     // (2048 workgroups: 106 us for a 67 MB tensor; 96: 21 us = 3.2 TB/s with eight 16-byte loads in flight per lane)
     if (blocks > 96) blocks = 96;
+    if (deterministic()) blocks = 1;          // one workgroup: no float atomics in arrival order
     PG_KLAUNCH(pg::bias_grad_nhwc_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dY, rows, C, db);
     PG_LAUNCH_OK("pg_bias_grad");
     return 0;
   }
   if (s_inner == 1 && rows_inner % 4 == 0 && rows_inner >= 4096 && s_outer % 4 == 0 && sC % 4 == 0 && ((size_t)dY & 15) == 0 &&
-      rows_outer * C <= 65535) {
+      rows_outer * C <= 65535 && !deterministic()) {
     int sl = (int)((rows_inner / 4 + 4095) / 4096);       // >= 16 K floats per workgroup
     if (sl > 64) sl = 64;
     PG_KLAUNCH(pg::bias_grad_planar_kernel, dim3((unsigned)(rows_outer * C), sl), dim3(256), 0, (hipStream_t)stream, dY, (long)rows_inner, C,
@@ -836,7 +840,7 @@ extern "C" int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_in
   }
   int slices = (int)((rows + 256 * 16 - 1) / (256 * 16));
   if (slices > 64) slices = 64;
-  if (slices < 1) slices = 1;
+  if (slices < 1 || deterministic()) slices = 1;          // PG_DETERMINISTIC: one workgroup per channel
   PG_KLAUNCH(pg::bias_grad_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, dY, (long)rows_outer,
                      (long)rows_inner, C, (long)s_outer, (long)s_inner, (long)sC, db);
   PG_LAUNCH_OK("pg_bias_grad");
@@ -853,6 +857,7 @@ extern "C" int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, f
     static const long bcap8 = getenv("PG_BIAS_GRAD_WGS") ? atol(getenv("PG_BIAS_GRAD_WGS")) : 384;
     const long cap8 = (double)npix * C * 2 >= 64e6 ? bcap8 : 96;
     if (blocks8 > cap8) blocks8 = cap8;
+    if (deterministic()) blocks8 = 1;
     PG_KLAUNCH(pg::bias_grad_bf16x8_kernel, dim3((int)blocks8), dim3(256), 0, (hipStream_t)stream,
                reinterpret_cast<const unsigned short*>(dY_bf16), (long)npix, C, db);
     PG_LAUNCH_OK("pg_bias_grad_bf16");
@@ -865,6 +870,7 @@ extern "C" int pg_bias_grad_bf16(const void* dY_bf16, int64_t npix, int32_t C, f
   static const long bcap = getenv("PG_BIAS_GRAD_WGS") ? atol(getenv("PG_BIAS_GRAD_WGS")) : 384;
   const long cap = (double)npix * C * 2 >= 64e6 ? bcap : 96;
   if (blocks > cap) blocks = cap;
+  if (deterministic()) blocks = 1;
   PG_KLAUNCH(pg::bias_grad_nhwc_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float*>(dY_bf16), (long)npix, C, db);
   PG_LAUNCH_OK("pg_bias_grad_bf16");

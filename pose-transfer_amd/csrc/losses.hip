@@ -373,7 +373,7 @@ using namespace pg;
 extern "C" int pg_gan_logloss(const float* logits, int64_t count, int32_t mode, float scale, float* loss,
                               float* dlogits, float* sig, void* stream) {
   PG_REQUIRE(logits && count > 0 && (mode == 0 || mode == 1), "pg_gan_logloss: bad arguments");
-  PG_KLAUNCH(gan_logloss_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, logits, (long)count,
+  PG_KLAUNCH(gan_logloss_kernel, dim3(deterministic() ? 1 : ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, logits, (long)count,
                      mode, scale, loss, dlogits, sig);
   PG_LAUNCH_OK("pg_gan_logloss");
   return 0;
@@ -382,7 +382,7 @@ extern "C" int pg_gan_logloss(const float* logits, int64_t count, int32_t mode, 
 extern "C" int pg_l1_loss(const float* pred, const float* target, int64_t count, float scale, float* loss, float* gout,
                           int32_t accumulate, void* stream) {
   PG_REQUIRE(pred && target && count > 0, "pg_l1_loss: bad arguments");
-  PG_KLAUNCH(l1_loss_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, pred, target,
+  PG_KLAUNCH(l1_loss_kernel, dim3(deterministic() ? 1 : ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, pred, target,
                      (long)count, scale, loss, gout, accumulate);
   PG_LAUNCH_OK("pg_l1_loss");
   return 0;

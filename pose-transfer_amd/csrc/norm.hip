@@ -90,11 +90,19 @@ __device__ __forceinline__ float ld1(const T* base, long i) {
 }
 
 // dz and y share the storage type (fp32 or bf16): every lane moves 16-byte chunks of both
+// sums_mode 2 recovers sum(r * xhat) as (S2 - beta S1) / gamma from the ACTIVATED, bf16-rounded operand: ill-conditioned when
+// |gamma| is small against |beta| (and undefined at gamma == 0).  Such a layer takes the plain reduce pass over (dz, y) instead:
+// pg_norm_bwd_reduce_guard runs this kernel with `guard` = (gamma, beta) and exits at once when the layer is well-conditioned;
+// the apply kernel evaluates the same predicate and reads whichever sums are valid.
+__device__ __forceinline__ bool norm_gamma_small(float g, float b) { return fabsf(g) < 1e-3f + 0.02f * fabsf(b); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* dz, const T* y, const float* mr, long L,
-                                                              double* bsums) {
+                                                              double* bsums, const float* guard_gamma = nullptr,
+                                                              const float* guard_beta = nullptr) {
   constexpr int V = Chunk<T>::N;
   __shared__ double red[8];
+  if (guard_gamma != nullptr && !norm_gamma_small(guard_gamma[0], guard_beta[0])) return;
   const int n = blockIdx.y;
   const float mean = mr[2 * n], rstd = mr[2 * n + 1];
   const T* bd = dz + (long)n * L;
@@ -134,8 +142,11 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* dz, const
 // (round 4): [N][PG_STAT_SLOTS][2] accumulated by the epilogue that wrote dz — (sum r, sum r * y_raw) or (sum r, sum r * x_act);
 // see pg_norm_bwd_apply_v2 in include/posegan_hip.h.
 template <int MODE>
-__device__ __forceinline__ void bwd_sums(const double* bsums, int n, float mean, float rstd, float g, float b, double& s1, double& s2) {
+__device__ __forceinline__ void bwd_sums(const double* bsums, int n, float mean, float rstd, float g, float b, double& s1, double& s2,
+                                         const double* bsums0 = nullptr) {
   if constexpr (MODE == 0) { s1 = bsums[2 * n]; s2 = bsums[2 * n + 1]; return; }
+  if constexpr (MODE == 2)
+    if (bsums0 != nullptr && norm_gamma_small(g, b)) { s1 = bsums0[2 * n]; s2 = bsums0[2 * n + 1]; return; }
   double a1 = 0.0, a2 = 0.0;
   for (int k = 0; k < PG_STAT_SLOTS; ++k) { a1 += bsums[((long)n * PG_STAT_SLOTS + k) * 2]; a2 += bsums[((long)n * PG_STAT_SLOTS + k) * 2 + 1]; }
   s1 = a1;
@@ -146,14 +157,15 @@ __device__ __forceinline__ void bwd_sums(const double* bsums, int n, float mean,
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(T* dz, const T* y, const float* mr,
                                                              const double* bsums, const float* gamma, const float* beta, int N, long L,
-                                                             float* dgamma, float* dbeta, unsigned short* dy_bf16) {
+                                                             float* dgamma, float* dbeta, unsigned short* dy_bf16,
+                                                             const double* bsums0) {
   constexpr int V = Chunk<T>::N;
   const int n = blockIdx.y;
   const float mean = mr[2 * n], rstd = mr[2 * n + 1];
   const float g = gamma[0];
   const float bta = (MODE == 2) ? beta[0] : 0.f;
   double s1d, s2d;
-  bwd_sums<MODE>(bsums, n, mean, rstd, g, bta, s1d, s2d);
+  bwd_sums<MODE>(bsums, n, mean, rstd, g, bta, s1d, s2d, bsums0);
   const float m1 = (float)(s1d / (double)L);
   const float m2 = (float)(s2d / (double)L);
   const float k = g * rstd;
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(T* dz, const T* y, 
     double sg = 0.0, sb = 0.0;
     for (int i = 0; i < N; ++i) {
       double a1, a2;
-      bwd_sums<MODE>(bsums, i, mr[2 * i], mr[2 * i + 1], g, bta, a1, a2);
+      bwd_sums<MODE>(bsums, i, mr[2 * i], mr[2 * i + 1], g, bta, a1, a2, bsums0);
       sb += a1; sg += a2;
     }
     if (dgamma) atomicAdd(dgamma, (float)sg);
@@ -243,10 +255,27 @@ extern "C" int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float*
   typedef unsigned short bf;
   hipStream_t st = (hipStream_t)stream;
   if (io_flags == 0)
-    PG_KLAUNCH((norm_bwd_reduce_kernel<float>), dim3(norm_blocks_bwd(L, N, 4), N), dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums);
+    PG_KLAUNCH((norm_bwd_reduce_kernel<float>), dim3(norm_blocks_bwd(L, N, 4), N), dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums,
+               (const float*)nullptr, (const float*)nullptr);
   else
-    PG_KLAUNCH((norm_bwd_reduce_kernel<bf>), dim3(norm_blocks_bwd(L, N, 8), N), dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums);
+    PG_KLAUNCH((norm_bwd_reduce_kernel<bf>), dim3(norm_blocks_bwd(L, N, 8), N), dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums,
+               (const float*)nullptr, (const float*)nullptr);
   PG_LAUNCH_OK("pg_norm_bwd_reduce");
+  return 0;
+}
+// the reduce pass of a layer whose sums the producer of dz already wrote in activated-operand form (sums_mode 2): runs only when
+// the layer's gamma is too small for that form (decided on the device: no host synchronisation); see norm_gamma_small
+extern "C" int pg_norm_bwd_reduce_guard(const void* dz, const void* y, const float* mr, const float* gamma, const float* beta,
+                                        int32_t N, int64_t L, double* bsums, int32_t io_flags, void* stream) {
+  PG_REQUIRE(dz && y && mr && bsums && gamma && beta && N > 0 && L > 0 && ((io_flags == 0 && L % 4 == 0) || (io_flags == 3 && L % 8 == 0)),
+             "pg_norm_bwd_reduce_guard: bad arguments");
+  typedef unsigned short bf;
+  hipStream_t st = (hipStream_t)stream;
+  if (io_flags == 0)
+    PG_KLAUNCH((norm_bwd_reduce_kernel<float>), dim3(norm_blocks_bwd(L, N, 4), N), dim3(256), 0, st, (const float*)dz, (const float*)y, mr, (long)L, bsums, gamma, beta);
+  else
+    PG_KLAUNCH((norm_bwd_reduce_kernel<bf>), dim3(norm_blocks_bwd(L, N, 8), N), dim3(256), 0, st, (const bf*)dz, (const bf*)y, mr, (long)L, bsums, gamma, beta);
+  PG_LAUNCH_OK("pg_norm_bwd_reduce_guard");
   return 0;
 }
 extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* mr, int32_t N, int64_t L,
@@ -256,16 +285,26 @@ extern "C" int pg_norm_bwd_reduce(const float* dz, const float* y, const float* 
 
 // io_flags as in pg_norm_bwd_reduce_ex; with bf16 storage the in-place result IS the bf16 operand of the layer's gradient
 // contractions (dy_bf16 must be NULL then).  sums_mode: where the two per-sample sums come from (include/posegan_hip.h).
+extern "C" int pg_norm_bwd_apply_v3(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma,
+                                    const float* beta, int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16,
+                                    int32_t io_flags, int32_t sums_mode, const double* bsums_guard, void* stream);
 extern "C" int pg_norm_bwd_apply_v2(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma,
                                     const float* beta, int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16,
                                     int32_t io_flags, int32_t sums_mode, void* stream) {
+  return pg_norm_bwd_apply_v3(dz, y, mr, bsums, gamma, beta, N, L, dgamma, dbeta, dy_bf16, io_flags, sums_mode, nullptr, stream);
+}
+// bsums_guard (sums_mode 2 only, optional): [N][2] sums of pg_norm_bwd_reduce_guard — read instead of `bsums` when the layer's gamma
+// is too small for the activated-operand form
+extern "C" int pg_norm_bwd_apply_v3(void* dz, const void* y, const float* mr, const double* bsums, const float* gamma,
+                                    const float* beta, int32_t N, int64_t L, float* dgamma, float* dbeta, uint16_t* dy_bf16,
+                                    int32_t io_flags, int32_t sums_mode, const double* bsums_guard, void* stream) {
   PG_REQUIRE(dz && y && mr && bsums && gamma && N > 0 && L > 0 && L % 4 == 0 && (io_flags == 0 || (io_flags == 3 && L % 8 == 0 && !dy_bf16)) &&
              sums_mode >= 0 && sums_mode <= 2 && (sums_mode != 2 || beta != nullptr), "pg_norm_bwd_apply: bad arguments");
   typedef unsigned short bf;
   hipStream_t st = (hipStream_t)stream;
 #define PG_NBA(TT, VEC, MODE)                                                                                                 \
   PG_KLAUNCH((norm_bwd_apply_kernel<TT, MODE>), dim3(norm_blocks(L, VEC), N), dim3(256), 0, st, (TT*)dz, (const TT*)y, mr, bsums, \
-             gamma, beta, N, (long)L, dgamma, dbeta, dy_bf16)
+             gamma, beta, N, (long)L, dgamma, dbeta, dy_bf16, sums_mode == 2 ? bsums_guard : (const double*)nullptr)
   if (io_flags == 0) {
     if (sums_mode == 0) PG_NBA(float, 4, 0); else if (sums_mode == 1) PG_NBA(float, 4, 1); else PG_NBA(float, 4, 2);
   } else {

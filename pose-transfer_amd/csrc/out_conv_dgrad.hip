@@ -657,7 +657,7 @@ extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const f
     k.wpart = workspace;
     PG_KLAUNCH(pg::out_conv_bwd_mfma_kernel, dim3((unsigned)fb), dim3(256), 0, st, k);
     PG_LAUNCH_OK("pg_out_conv_bwd_direct (fused MFMA pass)");
-    PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, 16), dim3(256), 0, st, workspace, (int)fb, c, dW);
+    PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, pg::deterministic() ? 1 : 16), dim3(256), 0, st, workspace, (int)fb, c, dW);
     PG_LAUNCH_OK("pg_out_conv_bwd_direct (reduce)");
     {
       bool bs = false;
@@ -682,7 +682,7 @@ extern "C" int pg_out_conv_bwd_direct(const float* G, int32_t g_is_dpre, const f
   if (g_is_dpre) PG_KLAUNCH((pg::out_conv_dgrad_kernel<false, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
   else PG_KLAUNCH((pg::out_conv_dgrad_kernel<false, true, true, false>), dim3((unsigned)blocks), dim3(256), 0, wst, k);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (weight gradient)");
-  PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, 16), dim3(256), 0, wst, workspace, (int)blocks, c, dW);
+  PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, pg::deterministic() ? 1 : 16), dim3(256), 0, wst, workspace, (int)blocks, c, dW);
   PG_LAUNCH_OK("pg_out_conv_dgrad_wgrad (reduce)");
   return 0;
 }
@@ -720,7 +720,7 @@ extern "C" int pg_out_conv_wgrad_bf16(const void* G_bf16, int32_t g_pitch, int32
   k.wpart = workspace;
   PG_KLAUNCH((pg::out_conv_dgrad_kernel<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   PG_LAUNCH_OK("pg_out_conv_wgrad_bf16");
-  PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, 16), dim3(256), 0, (hipStream_t)stream, workspace,
+  PG_KLAUNCH(pg::out_conv_wgrad_reduce_kernel, dim3((c * 28 + 255) / 256, pg::deterministic() ? 1 : 16), dim3(256), 0, (hipStream_t)stream, workspace,
                      (int)blocks, c, dW);
   PG_LAUNCH_OK("pg_out_conv_wgrad_bf16 (reduce)");
   return 0;

@@ -204,6 +204,7 @@ static int launch_small_cin_wgrad(SmallCinWgK& k, float* ws, long ws_floats, hip
   k.npad = (K * K * k.Ctot + 31) / 32 * 32;
   const long need = (long)blocks * 64 * k.npad;
   if (ws == nullptr || ws_floats < need) {                   // no (or too small a) workspace: float atomics into dW
+    PG_REQUIRE(!deterministic(), "pg_small_cin_wgrad: PG_DETERMINISTIC needs the workspace (%ld floats)", need);
     k.part = nullptr;
     if (blocks > 256) blocks = 256;                          // measured: the atomics, not the MFMA loop, set the time
   } else {
@@ -211,7 +212,7 @@ static int launch_small_cin_wgrad(SmallCinWgK& k, float* ws, long ws_floats, hip
   }
   PG_KLAUNCH(kern, dim3((unsigned)blocks, (unsigned)groups), dim3(256), lds, st, k);
   if (k.part) {
-    const int ry = blocks >= 32 ? 16 : 1;
+    const int ry = (blocks >= 32 && !deterministic()) ? 16 : 1;
     PG_KLAUNCH(small_cin_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256),
                        0, st, k.part, blocks, k.npad, K * K * k.Ctot, k.Ctot, k.dW);
   }

@@ -633,6 +633,9 @@ static int launch_stem_conv_pf(StemK& k, hipStream_t st) {
   return 0;
 }
 
+// return code of launch_stem_wgrad: 0 = launched, STEM_RC_BIAS_FUSED = launched AND the bias gradient rode along, anything else
+// (PG_FAIL / PG_REQUIRE / PG_HIP codes 1..3, -2 = workspace too small) = error
+constexpr int STEM_RC_BIAS_FUSED = 100;
 template <int K, int S, int TH, int CP, int NW, int NTW>
 static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hipStream_t st, float* db = nullptr) {
   constexpr int PH = (TH - 1) * S + K, PW = 15 * S + K, PWH = (PW + 1) / 2, ROWP = (S == 1) ? PW : 2 * PWH;
@@ -664,10 +667,10 @@ static int launch_stem_wgrad(StemK& k, float* dW, float* ws, long ws_floats, hip
   const bool fuse_b = db != nullptr && k.Ctot < CP && ((K == 3 && k.pad == 1) || k.pad == 0);
   k.ones_slot = fuse_b ? 1 : 0;
   PG_KLAUNCH(kern, dim3((unsigned)blocks), dim3(NW * 64), LDS, st, k);
-  const int ry = blocks >= 32 ? 16 : 1;
+  const int ry = (blocks >= 32 && !deterministic()) ? 16 : 1;      // PG_DETERMINISTIC: one serial walk per element, no float atomics in arrival order
   PG_KLAUNCH(stem_wgrad_reduce_kernel, dim3((unsigned)((64 * k.npad + 255) / 256), (unsigned)ry), dim3(256), 0, st, k.part,
                      blocks, k.npad, K * K, CP, k.Ctot, dW, fuse_b ? db : (float*)nullptr, (K == 3 && k.pad == 1) ? 4 : 0);
-  return fuse_b ? 1 : 0;
+  return fuse_b ? STEM_RC_BIAS_FUSED : 0;
 }
 
 }  // namespace pg
@@ -777,8 +780,8 @@ extern "C" int pg_stem_wgrad_bf16_v2(const pg_src_t* src, int32_t nsrc, int32_t 
                    : pg::launch_stem_wgrad<4, 2, 8, 72, 8, 9>(k, dW, workspace, workspace_floats, st, dbias);
   }
   PG_REQUIRE(rc != -2, "pg_stem_wgrad_bf16: a workspace of at least 64 x %d floats is required", k.npad);
-  if (rc < 0) return rc;
-  pg::last_info() = 7 | (1 << 4) | (1 << 16) | (1 << 30) | (rc == 1 ? PG_INFO_STEM_BIAS : 0);     // tile code 7 = bf16 stem kernel, scalar X
+  if (rc != 0 && rc != pg::STEM_RC_BIAS_FUSED) return rc;        // (error message already set by the failing macro)
+  pg::last_info() = 7 | (1 << 4) | (1 << 16) | (1 << 30) | (rc == pg::STEM_RC_BIAS_FUSED ? PG_INFO_STEM_BIAS : 0);     // tile code 7 = bf16 stem kernel, scalar X
   PG_LAUNCH_OK("pg_stem_wgrad_bf16");
   return 0;
 }

@@ -505,8 +505,10 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
 template <bool GB, bool DB, int V = 4, bool LIST = false>
 __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, const uint8_t* amax, const float* warps,
                                                               const float* masks, int T, int C, int h, int w, int H0, int W0,
-                                                              int align, void* dfeat, const int* bbox) {
+                                                              int align, void* dfeat, const int* bbox, int det) {
   // GB / DB: the incoming gradient / the written input gradient are bf16 tensors (bf16 STORAGE)
+  // det (PG_DETERMINISTIC): every pixel's list is sorted by (output pixel, transform) before it is summed — the append order is
+  // the arrival order of LDS atomics, i.e. the fp32 summation order would differ from run to run in the last bits
   constexpr int ESG = GB ? 2 : 4, ESD = DB ? 2 : 4;
   constexpr int FLAT = LIST ? GATHER_T * GATHER_CAP : GATHER_FLAT;
 #ifndef PG_GATHER_PB
@@ -637,6 +639,19 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
       if (slot < GATHER_OVF_MAX) g_gather_ovf[1 + slot] = (n << 20) | tile;
     }
     continue;
+  }
+  if (det) {
+    if (threadIdx.x < GATHER_PIX) {
+      const int p = threadIdx.x, cnt = min(e_cnt[p], FLAT);
+      for (int a = 1; a < cnt; ++a) {             // insertion sort (<= 48 entries, usually < 8)
+        const int key = e_pix[p][a];
+        const float wv = e_w[p][a];
+        int b = a - 1;
+        while (b >= 0 && e_pix[p][b] > key) { e_pix[p][b + 1] = e_pix[p][b]; e_w[p][b + 1] = e_w[p][b]; --b; }
+        e_pix[p][b + 1] = key; e_w[p][b + 1] = wv;
+      }
+    }
+    __syncthreads();
   }
   // ---- phase 2: lanes = V channels of an input pixel; entries in batches of four (independent loads in flight)
   if (wdbg & 1) continue;
@@ -890,22 +905,23 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
 #ifdef PG_TIMING_EXPERIMENTS
     { static const int wd = getenv("PG_DEBUG_WARP_BWD") ? atoi(getenv("PG_DEBUG_WARP_BWD")) : 0; ac_g |= wd << 8; }
 #endif
+    const int det_g = deterministic() ? 1 : 0;           // PG_DETERMINISTIC: sorted candidate lists (the float-atomic scatter of strongly minifying transforms below stays order-dependent)
     static void* ovf_dev = nullptr;                      // g_gather_ovf: tiles whose 48-entry lists overflowed
     if (ovf_dev == nullptr) PG_REQUIRE(hipGetSymbolAddress(&ovf_dev, HIP_SYMBOL(g_gather_ovf)) == hipSuccess, "pg_warp_mask_max_bwd: symbol");
     PG_MEMSET_ASYNC(ovf_dev, 0, 4, st);
     const dim3 g1(gtiles, N), g2(64);                    // second launch: worst-case capacity over the overflow list (usually empty)
     if (gb && db && C % 8 == 0 && !no_v8b) {
       PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
-                 ac_g, dfeat, (const int*)bbox);
+                 ac_g, dfeat, (const int*)bbox, det_g);
       PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
-                 ac_g, dfeat, (const int*)bbox);
+                 ac_g, dfeat, (const int*)bbox, det_g);
     } else {
 #define PGW_GATHER(GBv, DBv)                                                                                                    \
   do {                                                                                                                          \
     PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, \
-               ac_g, dfeat, (const int*)bbox);                                                                         \
+               ac_g, dfeat, (const int*)bbox, det_g);                                                                         \
     PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,  \
-               ac_g, dfeat, (const int*)bbox);                                                                         \
+               ac_g, dfeat, (const int*)bbox, det_g);                                                                         \
   } while (0)
       if (gb && db) PGW_GATHER(true, true);
       else if (gb) PGW_GATHER(true, false);

@@ -641,6 +641,7 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
       if (ks4 > ktot / 8) ks4 = ktot / 8;                       // >= 8 K tiles per workgroup
       if (ks4 < 1) ks4 = 1;
       while (ks4 > 1 && (long)(ks4 - 1) * ((ktot + ks4 - 1) / ks4) >= ktot) --ks4;
+      if (deterministic()) ks4 = 1;       // PG_DETERMINISTIC: no float atomics on dW
       q.ksplit = ks4; q.atomic = ks4 > 1 ? 1 : 0;
       q.xcd_remap = (((long)mt4 * nt4 * ks4) % 8 == 0 && !env().no_xcd_swizzle) ? 1 : 0;
       dim3 grid4(mt4, nt4, 4 * ks4);
@@ -694,6 +695,7 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   while (ks > 1 && (long)(ks - 1) * ((ktot + ks - 1) / ks) >= ktot) --ks;      // no empty split
   if (ks >= 8 && ks % 8 != 0 && ktot / ((ks + 7) / 8 * 8) >= 8) ks = (ks + 7) / 8 * 8;       // whole XCD groups of taps
   while (ks > 1 && (long)(ks - 1) * ((ktot + ks - 1) / ks) >= ktot) --ks;
+  if (deterministic()) ks = 1;            // PG_DETERMINISTIC: no float atomics on dW
   k.ksplit = ks; k.atomic = ks > 1 ? 1 : 0;
   k.xcd_remap = (((long)mt * nt * ks) % 8 == 0 && !env().no_xcd_swizzle) ? 1 : 0;
   dim3 grid(mt, nt, 16 * ks);

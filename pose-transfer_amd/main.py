@@ -94,11 +94,16 @@ def main(argv=None):
         gen_losses, disc_losses = [], []
         t0 = time.time()
         for it in range(opt.iters_per_epoch):
-            for _ in range(opt.training_ratio):
+            for k in range(opt.training_ratio):
                 a, b = train.next(), train.next()
+                if k == opt.training_ratio - 1:
+                    # the generator update's batch, drawn in the reference's order (after the last discriminator pair) but BEFORE
+                    # that discriminator update runs: its generator forward is enqueued ahead (models/pose_gan.py)
+                    c = train.next()
+                    oc = other_inputs(opt, c)
+                    model.prefetch_gen_forward(c[0], oc)
                 disc_losses.append(model.dis_update(a[0], a[1], other_inputs(opt, a), b[0], b[1], od))
-            c = train.next()
-            out, outputs, gl = model.gen_update(c[0], c[1], other_inputs(opt, c), od)
+            out, outputs, gl = model.gen_update(c[0], c[1], oc, od)
             gen_losses.append(gl)
             done += 1
             model.iteration += 1

@@ -21,6 +21,9 @@ from ..utils import pose_utils, synth
 from .networks import Deformable_Generator, Discriminator, Generator, Stacked_Generator, xavier_weights_init
 
 
+GEN_PREFETCH = os.environ.get("PG_NO_GEN_PREFETCH") is None
+
+
 class FusedAdam:
     """Stand-in for torch.optim.Adam(params, lr, betas=(0.5,0.999)) over a ParamArena (pose_gan.py:50-51)."""
 
@@ -140,7 +143,51 @@ class DeformablePose_GAN(nn.Module):
         eng._drop_counter = 0
         eng.set_dropout(drop_masks, train=True, seed=self.seed)
 
-    def _gen_forward(self, input, other_inputs, drop_masks, call="g"):
+    # ---- generator forward of the NEXT gen_update, issued ahead (round 5) --------------------------------------------
+    # dis_update steps only the discriminator (reference pose_gan.py:117-171), so the generator forward gen_update starts
+    # with (pose_gan.py:72-79) sees the same weights whether it is enqueued after dis_update or BEFORE it.  At small per-GPU
+    # batches (BASELINE.json configs[3]: 4 per GPU) most launches of an iteration leave most CUs idle; enqueued ahead on its
+    # own stream and into its own engine (activation buffers), that forward runs NEXT TO dis_update's work instead of
+    # after it.  Same kernels, same dropout stream (`call="g"` of this iteration), same results — gen_update recognises the
+    # prefetched pass by its input tensors and the arena's weight version and otherwise computes the forward as before.
+    # Single-stage generators only, not in replay sessions.  PG_NO_GEN_PREFETCH=1 switches it off.
+    def prefetch_gen_forward(self, input, other_inputs):
+        self._pf = None
+        if not (GEN_PREFETCH and self.gen_type != "stacked" and self.deformable and E.REPLAY_CTR is None and E.SIDE_STREAM
+                and torch.is_tensor(input) and input.is_cuda):
+            return False
+        input = input.contiguous()
+        if getattr(self, "_pf_stream", None) is None:
+            self._pf_stream = torch.cuda.Stream(device=input.device)
+        if E.PRECISION == 3:
+            self._core.arena.bf16_params()      # (first use after load_state_dict converts: on THIS stream, before the fork)
+        L.call("pg_stream_wait", E._raw(self._pf_stream), L.stream())        # (the inputs were produced on this stream)
+        with torch.cuda.stream(self._pf_stream):
+            engs, out = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"), engine_stage=1)
+        self._pf = {"key": self._pf_key(input, other_inputs), "engs": engs, "out": out, "input": input}
+        return True
+
+    def _pf_key(self, input, other_inputs):
+        oi = other_inputs or {}
+        ptr = lambda v: (v.data_ptr(), tuple(v.shape), v.dtype) if torch.is_tensor(v) else None
+        return (ptr(input), ptr(oi.get("warps")), ptr(oi.get("masks")),
+                tuple(ptr(m) for m in (oi.get("drop_masks") or ())), self._core.arena.version(), self.iteration)
+
+    def _take_prefetched(self, input, other_inputs):
+        pf, self._pf = getattr(self, "_pf", None), None
+        if pf is None:
+            return None
+        if pf["key"] != self._pf_key(input, other_inputs):
+            # not the pass gen_update asks for (other tensors, weights changed since): forget it, and give the dropout stream of
+            # this iteration's generator update back so that the forward computed now draws the masks it would have drawn
+            L.call("pg_stream_wait", L.stream(), E._raw(self._pf_stream))
+            if getattr(self, "_drop_n", None):
+                self._drop_n.pop(("g", 0), None)
+            return None
+        L.call("pg_stream_wait", L.stream(), E._raw(self._pf_stream))        # this stream continues behind the prefetched pass
+        return pf["engs"], pf["out"]
+
+    def _gen_forward(self, input, other_inputs, drop_masks, call="g", engine_stage=0):
         """One generator forward (the chained stages of the stacked generator).  Returns ([engines], out_gen)."""
         other_inputs = other_inputs or {}
         if self.gen_type == "stacked":       # reference pose_gan.py:72-77
@@ -154,7 +201,7 @@ class DeformablePose_GAN(nn.Module):
                 out = eng.forward(x, wr[:, i], None if mk is None else mk[:, i].contiguous())
                 engs.append(eng)
             return engs, out
-        eng = self._core.engine(input.shape[0])
+        eng = self._core.engine(input.shape[0], engine_stage) if self.deformable else self._core.engine(input.shape[0])
         self._drop_setup(eng, drop_masks, 0, call)
         if self.deformable:
             return [eng], eng.forward(input, other_inputs["warps"].float(),
@@ -173,7 +220,11 @@ class DeformablePose_GAN(nn.Module):
         input, target = input.contiguous(), target.contiguous()
         self.gen.zero_grad()
         E.dev_zero(self._loss[0:3])
-        engs, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
+        pre = self._take_prefetched(input, other_inputs)
+        if pre is not None:
+            engs, out_gen = pre
+        else:
+            engs, out_gen = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"))
         # discriminator on [img, src_pose, out_gen, tgt_pose] — forward + data-gradient only
         deng = self.disc.engine(n)
         logits = deng.forward([(input, out_gen)])
@@ -200,11 +251,22 @@ class DeformablePose_GAN(nn.Module):
         L.call("pg_tanh_bwd", L.ptr(gout), L.ptr(out_gen), gout.numel(), L.stream())
         if self.g_reducer is not None:
             self.g_reducer.begin()
+        # single process, one stage: the optimiser step runs in ranges UNDER the backward pass (engine.EagerAdam)
+        eager = None
+        if (self.g_reducer is None and len(engs) == 1 and E.EAGER_ADAM and E.REPLAY_CTR is None and E.SIDE_STREAM
+                and hasattr(engs[0], "param_release_cb") and input.is_cuda):
+            if getattr(self, "_eager_g", None) is None:
+                self._eager_g = E.EagerAdam(self._core.arena, self.gen_opt.lr, self.gen_opt.betas[0], self.gen_opt.betas[1],
+                                            self.gen_opt.eps)
+            eager = self._eager_g
+            eager.begin()
         # stacked: back through the chained stages; stage i's image input is stage i-1's output (networks.py:320).  The
         # shared weights' gradients accumulate in the arena; only the LAST backward (stage 0) reports them ready.
         for i in range(len(engs) - 1, -1, -1):
             eng = engs[i]
             eng.grad_ready_cb = self.g_reducer.mark_ready if (self.g_reducer is not None and i == 0) else None
+            if hasattr(eng, "param_release_cb"):
+                eng.param_release_cb = eager.release if eager is not None else None
             if i > 0:
                 gprev = self._buf("gprev%d" % (i & 1), gout.shape)
                 eng.backward(gout, image_grad=gprev)
@@ -216,7 +278,11 @@ class DeformablePose_GAN(nn.Module):
         if self.g_reducer is not None:
             self.g_reducer.finish()
             scale, gb = 1.0 / self.g_reducer.divisor, self.g_reducer.grad_source()[1]
-        self.gen_opt.step(grad_scale=scale, grads_bf16=gb)
+        if eager is not None:
+            engs[0].param_release_cb = None
+            eager.finish()
+        else:
+            self.gen_opt.step(grad_scale=scale, grads_bf16=gb)
         lp = L.ptr(self._loss)
         L.call("pg_add2", lp, lp + 4, lp + 8, 1, L.stream())        # total = ll + ad  (pose_gan.py:109)
         losses = self._losses(0, opt.get("lazy_losses", False))

@@ -103,6 +103,9 @@ class GradReducer:
 
     def __init__(self, arena, world, bucket_bytes=64 << 20, group=None, backend=None, grad_dtype=None, min_bucket_bytes=2 << 20):
         self.arena, self.world, self.group = arena, world, group
+        # test aid (tests/test_gpu_round5.py: one bucket per layer): PG_DP_BUCKET_BYTES / PG_DP_MIN_BUCKET_BYTES override the sizes
+        bucket_bytes = int(os.environ.get("PG_DP_BUCKET_BYTES", bucket_bytes))
+        min_bucket_bytes = int(os.environ.get("PG_DP_MIN_BUCKET_BYTES", min_bucket_bytes))
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.min_bucket_elems = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.keys = list(arena.keys)
@@ -144,6 +147,11 @@ class GradReducer:
                 print("[pose_transfer_amd.dp] pg_comm_init failed (%s); using torch.distributed all_reduce" % e, file=sys.stderr)
                 self.backend = "torch"
         self.launch_count = 0
+        # per-bucket timing (bench.py's `dp` block; off in the timed region): `profile = True` brackets every collective with
+        # events on the COMMUNICATION stream and measures, in finish(), how long the optimiser's stream really waits for it
+        self.profile = False
+        self._prof = []          # (bytes, start event | wall start, end event | wall end)
+        self._exposed = None
         self.begin()
 
     def begin(self):
@@ -152,6 +160,8 @@ class GradReducer:
         self.launched = 0        # arena offset up to which all-reduces were issued
         self.works = []
         self.launch_count = 0
+        self._prof = []
+        self._exposed = None
 
     def _end_offset(self, i):
         return self.arena.off[self.keys[i]] if i < len(self.keys) else self.arena.total
@@ -213,10 +223,19 @@ class GradReducer:
                 buf = self.packed[lo:upto]
             if self.world > 1:
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.profile:
+                    import time
+                    self._prof.append([buf.numel() * buf.element_size(), time.perf_counter(), None])
             return
         self._wait_producers(final)
         buf = self.arena.grads[lo:upto]
+        ev0 = ev1 = None
+        if self.profile:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._prof.append([n * (2 if self.bf16 else 4), ev0, ev1])
         with torch.cuda.stream(self.comm_stream):
+            if ev0 is not None:
+                ev0.record(self.comm_stream)         # after the producer waits: the bracket holds pack + collective only
             if self.debug_peer:                     # the sum a second rank with identical gradients would contribute
                 L.call("pg_add2", L.ptr(buf), L.ptr(buf), L.ptr(buf), n, L.stream())
             if self.bf16:
@@ -228,16 +247,50 @@ class GradReducer:
                         "pg_comm_allreduce_bucket")
             elif self.world > 1:
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)      # enqueued on the current (= comm) stream
+            if ev1 is not None:
+                ev1.record(self.comm_stream)
 
     def finish(self):
         """Issue whatever is left (keys never reported count as ready: e.g. unused parameters) and make the optimiser's
         stream wait for the collectives."""
         self._launch(self.arena.total, final=True)
+        if self.profile and not self.on_device:
+            import time
+            t0 = time.perf_counter()
+            for i, w in enumerate(self.works):
+                w.wait()
+                self._prof[i][2] = time.perf_counter()
+            self._exposed = (time.perf_counter() - t0) * 1e3
         for w in self.works:
             w.wait()
         self.works = []
         if self.on_device:
-            torch.cuda.current_stream(self.arena.grads.device).wait_stream(self.comm_stream)
+            main = torch.cuda.current_stream(self.arena.grads.device)
+            if self.profile:
+                # exposed communication = how much later the communication stream finishes than the optimiser's stream gets here
+                ea, ec = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(main)
+                ec.record(self.comm_stream)
+                self._exposed = (ea, ec)
+            main.wait_stream(self.comm_stream)
+
+    def comm_profile(self):
+        """What the last profiled pass (profile = True) measured — call after a device synchronisation: per-bucket bytes and
+        milliseconds (device: events on the communication stream around pack + collective; CPU / gloo: launch -> completion
+        wall time, an upper bound), their sum, and the EXPOSED time: how long the optimiser's stream waited in finish()."""
+        buckets = []
+        for nbytes, a, b in self._prof:
+            if self.on_device:
+                ms = a.elapsed_time(b)
+            else:
+                ms = ((b if b is not None else a) - a) * 1e3
+            buckets.append({"bytes": int(nbytes), "ms": round(float(ms), 4)})
+        exposed = self._exposed
+        if isinstance(exposed, tuple):
+            exposed = max(0.0, exposed[0].elapsed_time(exposed[1]))
+        return {"buckets": buckets, "allreduce_ms": round(sum(b["ms"] for b in buckets), 4),
+                "exposed_ms": None if exposed is None else round(float(exposed), 4), "grad_dtype": self.grad_dtype,
+                "bytes": int(sum(b["bytes"] for b in buckets))}
 
     def grad_source(self):
         """(fp32 grads, bf16 grads or None): what the optimiser step reads after finish()."""

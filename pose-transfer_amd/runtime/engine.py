@@ -219,6 +219,39 @@ class ParamArena:
     def zero_grad(self):
         dev_zero(self.grads)
 
+    # ---- the same optimiser step issued in RANGES while the backward pass is still running (round 5, EagerAdam below)
+    def adam_begin(self, lr, b1=0.5, b2=0.999, eps=1e-8):
+        self.step += 1
+        bc1 = 1.0 - b1 ** self.step
+        bc2 = 1.0 - b2 ** self.step
+        want_bf16 = PRECISION == 3 and self.params.is_cuda
+        if want_bf16 and self.params_bf16 is None:
+            self.params_bf16 = torch.empty(self.total, dtype=torch.bfloat16, device=self.params.device)
+        self._eager = (float(b1), float(b2), eps, lr / bc1, math.sqrt(bc2), want_bf16)
+
+    def adam_range(self, lo, hi):
+        """Adam on the arena elements [lo, hi) (multiples of ALIGN) on the current stream"""
+        b1, b2, eps, step_size, bc2s, want_bf16 = self._eager
+        n = hi - lo
+        if n <= 0:
+            return
+        o4 = 4 * lo
+        if not want_bf16:
+            L.call("pg_adam", self.params.data_ptr() + o4, self.grads.data_ptr() + o4, self.m.data_ptr() + o4,
+                   self.v.data_ptr() + o4, n, b1, b2, eps, step_size, bc2s, 1.0, L.stream())
+            return
+        L.call("pg_adam_ex", self.params.data_ptr() + o4, self.grads.data_ptr() + o4, None, self.m.data_ptr() + o4,
+               self.v.data_ptr() + o4, n, b1, b2, eps, step_size, bc2s, 1.0, self.params_bf16.data_ptr() + 2 * lo, L.stream())
+
+    def adam_end(self):
+        """every range has been issued: the parameters changed (the per-tap transposed bf16 copy is stale; the forward-layout
+        copy was written by the range launches)"""
+        want_bf16 = self._eager[5]
+        self._eager = None
+        self._bump_version()
+        if want_bf16:
+            self.bf16_version = self.version()
+
     def adam_step(self, lr, b1=0.5, b2=0.999, eps=1e-8, grad_scale=1.0, grads_bf16=None):
         """torch.optim.Adam semantics (reference models/pose_gan.py:50-51); bias corrections in double.
         grads_bf16: read the (all-reduced) bf16 gradient sums instead of the fp32 arena (runtime/dp.py bf16 buckets)."""
@@ -525,9 +558,11 @@ def _conv(srcs, N, Hi, Wi, act, mode, K, stride, pad, Ho, Wo, W, wCout, wCin, tr
     d.stats = L.ptr(stats)
     if SPLITK_WS_BYTES > 0 and os.environ.get("PG_WS_SKIP") != str(d.epilogue):     # PG_WS_SKIP: debugging switch
         dev_ = W.device if isinstance(W, torch.Tensor) else torch.device("cuda", torch.cuda.current_device())
-        ws = _SPLITK_WS.get(dev_)
+        # one scratch per (device, stream): launches on different streams run concurrently (the two encoder chains, round 5)
+        wkey = (dev_, L.stream().value)
+        ws = _SPLITK_WS.get(wkey)
         if ws is None:
-            ws = _SPLITK_WS[dev_] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev_)
+            ws = _SPLITK_WS[wkey] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev_)
         d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
     if PROFILER is not None:
         sp = (Ho * Wo) if mode == 0 else (Hi * Wi)
@@ -693,6 +728,44 @@ def _join_aux():
         L.call("pg_stream_wait", L.stream(), _raw(_AUX[torch.cuda.current_device()]))
 
 
+# Fourth stream (round 5): the two encoders of the deformable generator are independent chains between the network input and
+# the decoder (forward) / between the decoder's data gradients and the first layers (backward).  Their 16^2 ... 4^2 levels are
+# short launches that leave most CUs idle (and, at batch 4 per GPU — the per-GPU shape of BASELINE.json configs[3] — so does
+# every level): the pose encoder's levels >= ENC_PAR_LEVEL run on a second stream next to the appearance encoder's.
+#   PG_ENC_PAR=0 switches it off; PG_ENC_PAR_LEVEL=l pins the first concurrent level (default: chosen per engine from the
+#   workgroup count of the level's forward launch, GeneratorEngine._enc_par_level)
+ENC_PAR = os.environ.get("PG_ENC_PAR", "1") != "0"
+_ENC2 = {}
+
+
+def _enc2_on():
+    return ENC_PAR and SIDE_STREAM and torch.cuda.is_available()
+
+
+def _enc2_stream():
+    dev = torch.cuda.current_device()
+    st = _ENC2.get(dev)
+    if st is None:
+        st = _ENC2[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+@contextlib.contextmanager
+def _on_enc2(fork=False):
+    """run the body's launches on the second encoder stream (fork: it first waits for everything on the main stream so far)"""
+    st = _enc2_stream()
+    if fork:
+        L.call("pg_stream_wait", _raw(st), L.stream())
+    with torch.cuda.stream(st):
+        yield
+
+
+def _join_enc2():
+    """main stream waits for everything enqueued on the second encoder stream so far"""
+    if _ENC2.get(torch.cuda.current_device()) is not None:
+        L.call("pg_stream_wait", L.stream(), _raw(_ENC2[torch.cuda.current_device()]))
+
+
 OUT_CONV_STREAM = os.environ.get("PG_NO_OUT_CONV_STREAM") is None   # ablation switch: K=32 pg_conv launch instead
 _BF_WG = {}        # device -> [small operand, large operand planes, fp32 product] scratch of the bf16 weight gradient
 SMALL_CIN_DGRAD = os.environ.get("PG_NO_SMALL_CIN_DGRAD") is None   # ablation switch: GEMM-N = 3 pg_conv launch instead
@@ -844,6 +917,27 @@ def _wgrad(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, p
 STEM_BIAS_FUSED = os.environ.get("PG_NO_STEM_BIAS_FUSED") is None    # ablation switch: separate bias-gradient launches
 
 
+def _stem_bias_fusable(K, stride, pad, cin):
+    """Will the first layer's weight-gradient pass (pg_stem_wgrad_bf16_v2) deliver the bias gradient too?  Mirrors the launch code
+    (csrc/stem_bf16.hip launch_stem_wgrad: the bf16 stem kernel, a spare channel slot for the constant-one channel, a tap whose
+    input pixel exists for every output pixel).  The caller decides BEFORE the call: a bias gradient that needs its own kernel is
+    enqueued in front of the weight-gradient call, so that the data-parallel reducer's ordering invariant holds (every main-stream
+    write into a layer's gradients precedes the layer's _wgrad call)."""
+    if not (PRECISION == 3 and STEM_BF16 and STEM_BIAS_FUSED and SMALL_CIN_WGRAD):
+        return False
+    if K == 3 and stride == 1:
+        if cin > 36:
+            return False
+        cp = 24 if cin <= 24 else 36
+        return cin < cp and pad == 1
+    if K == 4 and stride == 2:
+        if cin > 72:
+            return False
+        cp = 44 if cin <= 44 else 72
+        return cin < cp and pad == 0
+    return False
+
+
 def _wgrad_main(srcs, N, act, dY, Cout, Cin, x_is_large, Hs, Ws, Hl, Wl, K, stride, pad, dW, scalar_x=False,
                 y_strides=None, ksplit=0, cout_store=0, dy_bf16=None, dbias=None):
     if _wgrad_tr_ok(srcs, Cout, K, stride, pad, scalar_x, y_strides, cout_store, Cin, Hs, Ws, Hl, Wl, dW, N, x_is_large, dY):
@@ -991,8 +1085,14 @@ class NormState:
             bf = None
             if not (io & 1) and PRECISION == 3 and NORM_BWD_BF16 and _BF_CTX is not None and C > 0 and C % 64 == 0:
                 bf = _BF_CTX.reserve(L.ptr(dz), C, L.ACT_NONE, None, None, N * Lr, dz.device)
-            L.call("pg_norm_bwd_apply_v2", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.fsums if fused else self.bsums), L.ptr(gamma),
-                   L.ptr(beta), N, Lr, L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), io, int(fused), L.stream())
+            if fused == 2:
+                # sums in activated-operand form divide by gamma: a layer whose gamma is too small takes the plain reduce pass
+                # (decided on the device; a well-conditioned layer's launch exits at once — csrc/norm.hip norm_gamma_small)
+                L.call("pg_norm_bwd_reduce_guard", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(gamma), L.ptr(beta), N, Lr,
+                       L.ptr(self.bsums), io, L.stream())
+            L.call("pg_norm_bwd_apply_v3", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.fsums if fused else self.bsums), L.ptr(gamma),
+                   L.ptr(beta), N, Lr, L.ptr(dgamma), L.ptr(dbeta), L.ptr(bf), io, int(fused),
+                   L.ptr(self.bsums) if fused == 2 else None, L.stream())
             if (io & 1) and _BF_CTX is not None and C > 0:
                 _BF_CTX.adopt(L.ptr(dz), C, L.ACT_NONE, None, None, dz)
             return
@@ -1010,6 +1110,58 @@ class NormState:
         else:
             L.call("pg_norm_bwd_apply", L.ptr(dz), L.ptr(y), L.ptr(self.mr), L.ptr(self.bsums), L.ptr(gamma), N, Lr,
                    L.ptr(dgamma), L.ptr(dbeta), L.stream())
+
+
+# Adam under the backward pass (round 5).  The optimiser step is a pure streaming pass (28 - 30 bytes per parameter: 0.39 ms for
+# the generator's 82 M parameters — 6 % of the batch-4 bf16 iteration, after which the next forward has to wait for it) and the
+# deep layers, which hold almost all parameters, finish their gradients EARLY in the backward pass.  A layer's parameters are
+# released as soon as (a) its gradients are complete — weight gradient enqueued on the side stream, norm / bias gradients on the
+# stream that runs the layer — and (b) the pass has read its weights for the last time (the layer's data gradient is enqueued).
+# Released ranges (the arena is laid out in backward-completion order: an advancing offset) are updated on the weight-gradient
+# side stream, which first waits for the releasing stream.  Same arithmetic per element as the single launch: bit-identical
+# parameters.  Single process only (a data-parallel run must all-reduce first), not in replay sessions, not for the stacked
+# generator (its stages accumulate into the shared arena).  PG_NO_EAGER_ADAM=1 switches it off.
+EAGER_ADAM = os.environ.get("PG_NO_EAGER_ADAM") is None
+EAGER_ADAM_MIN = int(os.environ.get("PG_EAGER_ADAM_MIN", str(1 << 20)))      # elements per range launch (4 MB of parameters)
+
+
+class EagerAdam:
+    def __init__(self, arena, lr, b1=0.5, b2=0.999, eps=1e-8):
+        self.A, self.hyper = arena, (lr, b1, b2, eps)
+        self.index = {k: i for i, k in enumerate(arena.keys)}
+
+    def begin(self):
+        self.free = [False] * len(self.A.keys)
+        self.next_key, self.done = 0, 0
+        self.streams = {}            # streams that released keys since the last range launch (the two encoder chains)
+        self.A.adam_begin(*self.hyper)
+
+    def _end_offset(self, i):
+        return self.A.off[self.A.keys[i]] if i < len(self.A.keys) else self.A.total
+
+    def release(self, keys):
+        """called on the stream that ran the layers' last reader: their gradients are complete, their weights free"""
+        for k in keys:
+            self.free[self.index[k]] = True
+        cur = L.stream()
+        self.streams[cur.value] = cur
+        while self.next_key < len(self.free) and self.free[self.next_key]:
+            self.next_key += 1
+        upto = self._end_offset(self.next_key)
+        if upto - self.done >= EAGER_ADAM_MIN and SIDE_STREAM and torch.cuda.is_available():
+            side = _side_stream()
+            for st in self.streams.values():      # every stream that ran a last reader of the range (events recorded NOW cover them)
+                L.call("pg_stream_wait", _raw(side), st)
+            self.streams = {}
+            with torch.cuda.stream(side):
+                self.A.adam_range(self.done, upto)
+            self.done = upto
+
+    def finish(self):
+        """after the pass (the caller's stream has joined the side stream): whatever is left"""
+        self.A.adam_range(self.done, self.A.total)
+        self.done = self.A.total
+        self.A.adam_end()
 
 
 def generator_param_order(spec, nlev, ndec, deformable=True):
@@ -1106,6 +1258,7 @@ class GeneratorEngine:
         self._drop_counter = 0
         self.drop_stream = "drop"      # mixed into the dropout key (the trainer sets seed / rank / global iteration)
         self.grad_ready_cb = None      # DP hook: called with the parameter keys whose gradients are complete
+        self.param_release_cb = None   # EagerAdam hook: keys whose gradients are complete AND whose weights this pass no longer reads
         self._bf_fwd, self._bf_bwd = BfCache(), BfCache()      # bf16 data path: operand tensors of the last forward / backward
         self._fsum = {}                # (kind, index) -> sums_mode: norm layers whose backward sums a producer's epilogue wrote
 
@@ -1115,6 +1268,22 @@ class GeneratorEngine:
         # the main stream keeps running the data-gradient chain, the side stream the weight gradients
         if self.grad_ready_cb is not None:
             self.grad_ready_cb([k for k in self.A.keys if k.startswith(prefixes)])
+
+    def _release(self, *prefixes):
+        if self.param_release_cb is not None:
+            self.param_release_cb([k for k in self.A.keys if k.startswith(prefixes)])
+
+    def _enc_par_level(self):
+        """First encoder level whose pose-encoder launches go to the second encoder stream (ENC_PAR), nlev = none."""
+        if not (self.deformable and len(self.encs) == 2 and _enc2_on()):
+            return self.nlev
+        pin = os.environ.get("PG_ENC_PAR_LEVEL")
+        if pin is not None:
+            return max(0, min(self.nlev, int(pin)))
+        # measured (round 5, one box, generator forward + backward at batch 32 / bf16 batch-4 step / fp32 batch-4 step):
+        # off 17.8 ms / 576 img/s / 173.6 img/s; from level 4 (the 16^2 ... 4^2 levels only) 17.8 / - / -; from level 3 17.5;
+        # from level 1 17.3 / 592 / 175.5; from level 0 - / 590 / 175.2.  The first layers stay on the main stream.
+        return min(1, self.nlev)
 
     def _enc_in_src(self, e, inp):
         """NCHW channel slice of `input` feeding encoder level 0 (get_imgpose, utils/pose_utils.py:227-233)."""
@@ -1205,17 +1374,31 @@ class GeneratorEngine:
         # shallow levels of both encoders first: everything the warps need exists, then the warps go to the auxiliary stream
         # while the deep levels and the deep decoder blocks run here
         cut = self.nwarp if (self.nwarp > 0 and _aux_on()) else self.nlev
-        for e in self.encs:
+        pl = self._enc_par_level()       # first level of the pose encoder that runs on the second encoder stream (nlev: none)
+        if pl < self.nlev:
+            if PRECISION == 3:
+                A.bf16_params()          # (first use after load_state_dict converts: on THIS stream, before the chains fork)
+            e_app, e_pose = self.encs
+            self._forward_encoder(e_pose, inp, bfs, npx, 0, pl)
+            with _on_enc2(fork=True):
+                self._forward_encoder(e_pose, inp, bfs, npx, pl, self.nlev)
+            encs_main = (e_app,)
+        else:
+            encs_main = self.encs
+        for e in encs_main:
             self._forward_encoder(e, inp, bfs, npx, 0, cut)
         if cut < self.nlev:
             for l in range(self.nwarp):      # the deepest warped level's affine is still pending: publish it on THIS stream, before the fork
                 _flush_norm(L.ptr(self._enc_act("encoder_app", l).aff))
             with _on_aux():
                 self._forward_warps(bfs)
-            for e in self.encs:
+            for e in encs_main:
                 self._forward_encoder(e, inp, bfs, npx, cut, self.nlev)
         else:
+            _join_aux()                  # the mask pyramid / boxes were enqueued on the auxiliary stream (nwarp == nlev: no fork below)
             self._forward_warps(bfs)
+        if pl < self.nlev:
+            _join_enc2()                 # the decoder's first block reads both encoders
         self._forward_rest(inp, bfs, joined=cut >= self.nlev)
         _flush_all_norms()
         return self.out
@@ -1389,6 +1572,7 @@ class GeneratorEngine:
             self._ready("decoder.net.%d." % (i + 1))
         else:
             self._backward_final_fp32(srcs, cin, wkey, i)
+        self._release("decoder.net.%d." % (i + 1))       # (its data gradient read `wt_out`, a copy of the weight made above)
         self._backward_rest(image_grad)
 
     def _backward_final_fp32(self, srcs, cin, wkey, i):
@@ -1443,6 +1627,7 @@ class GeneratorEngine:
                                self._dsts_for(srcs, True))
             if i > 0 and (info or 0) & L.INFO_BSUMS:
                 self._fsum[("d", i - 1)] = 1
+            self._release("decoder.net.%d." % i)
             if i == i_fork:
                 # every warped skip's gradient w_g[0 .. nwarp-1] is complete (block i wrote the deepest one): the warp
                 # backward goes to the auxiliary stream, deepest level first (the first one the encoder chain needs)
@@ -1452,50 +1637,75 @@ class GeneratorEngine:
         # ---- deformable skips
         if not forked:
             warp_bwd(range(self.nwarp))
-        # ---- encoders
+        # ---- encoders (round 5: the pose encoder's levels >= pl on the second encoder stream, next to the appearance encoder's)
+        pl = self._enc_par_level()
+        par_open = pl < self.nlev
+        if par_open:
+            with _on_enc2(fork=True):    # every decoder data gradient (the first writers of both encoders' gradients) is enqueued
+                pass
         for l in range(self.nlev - 1, 0, -1):
             if forked and l - 1 < self.nwarp:
                 _join_aux()              # this level's data gradient accumulates into a gradient the warp backward wrote
                 forked = False
+            if par_open and l < pl:
+                _join_enc2()             # the remaining pose levels run on this stream again
+                par_open = False
             for e in self.encs:
-                hi, wi = self.hw[l - 1]
-                ho, wo = self.hw[l]
-                wkey = "%s.net.%d.net.1.weight" % (e, l)
-                dz = self.e_dz[e][l]
-                if l < self.nlev - 1:
-                    self.e_norm[e][l].backward(dz, self.e_raw[e][l], N, ho * wo * self.enc[l],
-                                               A.p("%s.net.%d.net.2.weight" % (e, l)), A.g("%s.net.%d.net.2.weight" % (e, l)),
-                                               A.g("%s.net.%d.net.2.bias" % (e, l)), C=self.enc[l], fused=self._fsum.pop((e, l), 0))
-                xin = self._enc_act(e, l - 1)
-                _wgrad([xin.src()], N, L.ACT_LEAKY, dz, self.enc[l], self.enc[l - 1], True, ho, wo, hi, wi, 4, 2, 1,
-                       A.g(wkey))
-                self._ready("%s.net.%d." % (e, l))
-                # this launch is the LAST writer of level l-1's gradient (skip / warp contributions were written before): it may
-                # carry the sums of that level's norm backward
-                nst = self.e_norm[e][l - 1]
-                bs = nst.fsums if (nst is not None and FUSE_NORM_SUMS) else None
-                info = _conv_dgrad(Act(dz, self.enc[l]).src(), N, ho, wo, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
-                                   self.enc[l - 1],
-                                   [L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
-                                               accumulate=True, bsums=bs)])
-                if bs is not None and (info or 0) & L.INFO_BSUMS:
-                    self._fsum[(e, l - 1)] = 1
+                par = par_open and e == self.encs[-1]
+                with (_on_enc2() if par else contextlib.nullcontext()):
+                    self._backward_encoder_level(e, l)
+        if par_open:
+            _join_enc2()
         if forked:
             _join_aux()
+        self._backward_stems(image_grad)
+
+    def _backward_encoder_level(self, e, l):
+        A, N = self.A, self.N
+        hi, wi = self.hw[l - 1]
+        ho, wo = self.hw[l]
+        wkey = "%s.net.%d.net.1.weight" % (e, l)
+        dz = self.e_dz[e][l]
+        if l < self.nlev - 1:
+            self.e_norm[e][l].backward(dz, self.e_raw[e][l], N, ho * wo * self.enc[l],
+                                       A.p("%s.net.%d.net.2.weight" % (e, l)), A.g("%s.net.%d.net.2.weight" % (e, l)),
+                                       A.g("%s.net.%d.net.2.bias" % (e, l)), C=self.enc[l], fused=self._fsum.pop((e, l), 0))
+        xin = self._enc_act(e, l - 1)
+        _wgrad([xin.src()], N, L.ACT_LEAKY, dz, self.enc[l], self.enc[l - 1], True, ho, wo, hi, wi, 4, 2, 1,
+               A.g(wkey))
+        self._ready("%s.net.%d." % (e, l))
+        # this launch is the LAST writer of level l-1's gradient (skip / warp contributions were written before): it may
+        # carry the sums of that level's norm backward
+        nst = self.e_norm[e][l - 1]
+        bs = nst.fsums if (nst is not None and FUSE_NORM_SUMS) else None
+        info = _conv_dgrad(Act(dz, self.enc[l]).src(), N, ho, wo, 1, 4, 2, 1, hi, wi, A.p(wkey), self.enc[l],
+                           self.enc[l - 1],
+                           [L.make_dst(self.e_dz[e][l - 1], self.enc[l - 1], fwd=xin.t, aff=xin.aff, act=L.ACT_LEAKY,
+                                       accumulate=True, bsums=bs)])
+        if bs is not None and (info or 0) & L.INFO_BSUMS:
+            self._fsum[(e, l - 1)] = 1
+        self._release("%s.net.%d." % (e, l))
+
+    def _backward_stems(self, image_grad=None):
+        A, N, H, W = self.A, self.N, self.H, self.W
         for e in self.encs:
             dz = self.e_dz[e][0]
             s0 = self._enc_in_src(e, self.input)
             if self.bfs:
                 assert image_grad is None, "bf16 storage: the chained (stacked) generator keeps fp32 storage"
-            # (round 4) the first layer's weight-gradient pass delivers the bias gradient as well where it can
-            if not _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
-                          A.g(e + ".net.0.weight"), scalar_x=True, dbias=A.g(e + ".net.0.bias")):
+            # (round 4) the first layer's weight-gradient pass delivers the bias gradient as well where it can; where it cannot,
+            # the bias-gradient kernel goes FIRST (main stream, before the weight-gradient call: the reducer's ordering invariant)
+            fuse = self.enc[0] == 64 and _stem_bias_fusable(3, 1, 1, s0.C)
+            if not fuse:
                 _debug_delay()
                 if self.bfs:
                     L.call("pg_bias_grad_bf16", L.ptr(dz), N * H * W, self.enc[0], L.ptr(A.g(e + ".net.0.bias")), L.stream())
                 else:
                     L.call("pg_bias_grad", L.ptr(dz), N * H * W, 1, self.enc[0], self.enc[0], 0, 1,
                            L.ptr(A.g(e + ".net.0.bias")), L.stream())
+            done = _wgrad([s0.src()], N, L.ACT_NONE, dz, self.enc[0], s0.C, True, H, W, H, W, 3, 1, 1,
+                          A.g(e + ".net.0.weight"), scalar_x=True, dbias=A.g(e + ".net.0.bias") if fuse else None)
+            assert bool(done) == bool(fuse), "first-layer bias gradient: the launch code and _stem_bias_fusable disagree"
             self._ready(e + ".net.0.")
             if image_grad is not None and e in ("encoder_app", "encoder"):
                 # data-gradient of the k3/s1/p1 first convolution restricted to its 3 image channels, written NCHW
@@ -1507,6 +1717,7 @@ class GeneratorEngine:
                     _conv([Act(dz, self.enc[0]).src()], N, H, W, L.ACT_NONE, 1, 3, 1, 1, H, W, A.p(e + ".net.0.weight"),
                           self.enc[0], s0.C, transposed=True, out=image_grad, out_strides=(3 * H * W, H * W, W, 1),
                           n_off=0, n_cnt=3)
+            self._release(e + ".net.0.")
 
 
 # ------------------------------------------------------------------------------------------ discriminator
@@ -1672,11 +1883,15 @@ class DiscriminatorEngine:
             n = pair[0].shape[0]
             dptr = dz0.data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
             if need_wgrad:
-                # (round 4) the stem's weight-gradient pass delivers this pair's share of the bias gradient where it can
-                if not _wgrad([a.src() for a in self._stem_srcs(pair)], n, L.ACT_NONE, dptr, 64, cin, True, self.hs[0],
-                              self.ws[0], H, W, 4, 2, 0, A.g("net.0.weight"), scalar_x=True, dbias=A.g("net.0.bias")):
+                # (round 4) the stem's weight-gradient pass delivers this pair's share of the bias gradient where it can; where it
+                # cannot, the bias-gradient kernel goes first (see GeneratorEngine._backward_stems)
+                fuse = _stem_bias_fusable(4, 2, 0, cin)
+                if not fuse:
                     _debug_delay()
                     L.call("pg_bias_grad", dptr, n * self.hs[0] * self.ws[0], 1, 64, 64, 0, 1, L.ptr(A.g("net.0.bias")), L.stream())
+                done = _wgrad([a.src() for a in self._stem_srcs(pair)], n, L.ACT_NONE, dptr, 64, cin, True, self.hs[0],
+                              self.ws[0], H, W, 4, 2, 0, A.g("net.0.weight"), scalar_x=True, dbias=A.g("net.0.bias") if fuse else None)
+                assert bool(done) == bool(fuse), "stem bias gradient: the launch code and _stem_bias_fusable disagree"
             if image_grad is not None and image_grad[pi] is not None:
                 g = image_grad[pi]
                 s = L.Src()

@@ -137,6 +137,8 @@ _PROTOS = {
     "pg_materialise_bf16_norm": [_vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _vp],
     "pg_norm_bwd_apply_io": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
     "pg_norm_bwd_apply_v2": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp],
+    "pg_norm_bwd_reduce_guard": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp],
+    "pg_norm_bwd_apply_v3": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "pg_warp_mask_max_fwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "pg_warp_mask_max_bwd_io": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "pg_debug_conv_timeline": [_vp, _i32],
@@ -153,6 +155,8 @@ _PROTOS = {
     "pg_out_conv_bwd_direct": [_vp, _i32, _vp, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp, _vp],
     "pg_out_conv_dgrad_wgrad": [_vp, _vp, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp],
     "pg_version": [],
+    "pg_set_deterministic": [_i32],
+    "pg_get_deterministic": [],
     "pg_last_launch_info": [],
 }
 EXPORTS = sorted(list(_PROTOS) + ["pg_last_error"])

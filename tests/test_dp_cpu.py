@@ -245,6 +245,136 @@ def test_bf16_bucket_sum_of_8_ranks_parameter_error():
     assert rms < 0.003 and worst < 0.02, (rms, worst)
 
 
+class _FlatArena:
+    """CPU stand-in of engine.ParamArena for the reducer: keys in backward-completion order, 64-element aligned offsets."""
+
+    def __init__(self, shapes):
+        self.keys = list(shapes)
+        self.shape = dict(shapes)
+        self.off, self.numel, o = {}, {}, 0
+        for k, shp in shapes.items():
+            n = int(np.prod(shp)) if len(shp) else 1
+            self.off[k], self.numel[k] = o, n
+            o += (n + 63) // 64 * 64
+        self.total = o
+        self.grads = torch.zeros(o)
+
+
+class _OracleStandIn:
+    """What bench.main(model_factory=...) drives on a box without a GPU: the CPU oracle as the compute of dis_update / gen_update
+    and the PRODUCT's GradReducer (runtime/dp.py) over gloo as the gradient exchange — the reducer sees the gradients become ready
+    in backward order, issues its buckets, finish() waits for them.  Test infrastructure only."""
+
+    def __init__(self, opt, device, rank, world):
+        import ref_cpu as R
+        from pose_transfer_amd.runtime import dp
+        from pose_transfer_amd.utils import synth
+        H, W = opt.image_size
+        P = opt.pose_dim
+        enc, dec = synth.nfilters((H, W))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        gpar = {k: t(v) for k, v in synth.init_params(5, "bench8/gen", synth.generator_spec(P, enc, dec), 0.1).items()}
+        dpar = {k: t(v) for k, v in synth.init_params(5, "bench8/disc", synth.discriminator_spec(3 + 2 * P + 3), 0.1).items()}
+        cfg = dict(pose_dim=P, image_size=(H, W), batch_size=opt.batch_size, gan_penalty_weight=opt.gan_penalty_weight,
+                   l1_penalty_weight=opt.l1_penalty_weight, learning_rate=opt.learning_rate, content_loss_layer="none",
+                   nn_loss_area_size=1, nfilters_enc=enc, nfilters_dec=dec)
+        self.tr = R.Trainer(cfg, gpar, dpar)
+        self.world = world
+        # backward-completion order = reverse of the forward (state_dict) order
+        self.g_arena = _FlatArena({k: tuple(v.shape) for k, v in reversed(list(gpar.items()))})
+        self.d_arena = _FlatArena({k: tuple(v.shape) for k, v in reversed(list(dpar.items()))})
+        self.g_reducer = dp.GradReducer(self.g_arena, world, bucket_bytes=1 << 20, min_bucket_bytes=1 << 16)
+        self.d_reducer = dp.GradReducer(self.d_arena, world, bucket_bytes=1 << 20, min_bucket_bytes=1 << 16)
+        self.buckets = {"gen": 0, "disc": 0}
+
+    def _avg(self, name, red, arena):
+        def fn(grads):
+            red.begin()
+            for k in arena.keys:                       # "backward": one layer's gradient after the other
+                o, n = arena.off[k], arena.numel[k]
+                arena.grads[o:o + n] = grads[k].reshape(-1)
+                red.mark_ready([k])
+            red.finish()
+            self.buckets[name] = red.launch_count
+            return {k: (arena.grads[arena.off[k]:arena.off[k] + arena.numel[k]] / red.divisor).view(arena.shape[k]).clone()
+                    for k in grads}
+        return fn
+
+    def dis_update(self, inp, target, other, real_inp, real_target, od):
+        return self.tr.dis_update(inp, target, other["warps"], other["masks"], real_inp, real_target, None,
+                                  average_fn=self._avg("disc", self.d_reducer, self.d_arena))
+
+    def gen_update(self, inp, target, other, od):
+        out, losses = self.tr.gen_update(inp, target, other["warps"], other["masks"], None,
+                                         average_fn=self._avg("gen", self.g_reducer, self.g_arena))
+        return out, [], losses
+
+
+def _bench8_worker(rank, world, port, q):
+    try:
+        import contextlib
+        import io
+        import json
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        sys.path.insert(0, ROOT)
+        import bench
+        buf = io.StringIO()
+        holder = {}
+
+        def factory(opt, device, r, w):
+            holder["m"] = _OracleStandIn(opt, device, r, w)
+            return holder["m"]
+
+        with contextlib.redirect_stdout(buf):
+            bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--size", "64", "--batch", "2"],
+                       model_factory=factory)
+        m = holder["m"]
+        psum = float(sum(v.double().sum() for v in m.tr.gp.values()) + sum(v.double().sum() for v in m.tr.dp.values()))
+        line = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+        q.put((rank, json.loads(line[-1]) if line else None, psum, dict(m.buckets)))
+    except Exception as e:
+        import traceback
+        q.put((rank, "ERROR: %r\n%s" % (e, traceback.format_exc()), None, None))
+        raise
+
+
+def test_bench_n_gt_1_path_end_to_end_world_8():
+    """bench.py's OWN multi-rank code path — rendezvous from the launcher's environment, warm-up, barrier-bracketed timed steps,
+    max over ranks, the `dp` block (per-bucket all-reduce time, exposed communication time), ONE JSON line from rank 0 — run end
+    to end by 8 gloo ranks on a 64 x 64 model.  The compute is the CPU oracle (no GPU here), the
+    gradient exchange is the product's GradReducer; afterwards every rank must hold the same parameters."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench8_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=900) for _ in procs]
+    [p.join(60) for p in procs]
+    by = {r[0]: r for r in res}
+    assert all(not isinstance(r[1], str) for r in res), [r[1] for r in res if isinstance(r[1], str)][:1]
+    line = by[0][1]
+    assert line is not None and all(by[r][1] is None for r in range(1, world)), "exactly rank 0 prints the line"
+    assert line["n_gpus"] == world and line["config"]["global_batch"] == 2 * world and line["config"]["parallelism"] == "dp8"
+    assert line["scaling"] == "weak" and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
+    assert len(line["per_rank_img_s"]) == world
+    # value = global images / (max over ranks of the timed region)
+    assert abs(line["value"] - 2 * world * 2 / (line["ms_per_step"] * 2e-3)) < 1e-2 * line["value"]
+    d = line["dp"]
+    assert d["ranks"] == world and d["rccl_ranks"] == world and "gloo" in d["transport"]
+    for nm in ("gen", "disc"):
+        assert len(d[nm]["buckets"]) >= 2 and all(b["bytes"] > 0 and b["ms"] >= 0 for b in d[nm]["buckets"]), d[nm]
+        assert d[nm]["exposed_ms"] is not None and d[nm]["exposed_ms"] >= 0
+    assert d["bytes_per_step"] == sum(b["bytes"] for nm in ("gen", "disc") for b in d[nm]["buckets"])
+    assert d["exposed_comm_ms_per_step"] is not None and d["allreduce_ms_per_step"] > 0
+    # the ranks trained the SAME model: identical parameter checksums after 1 + 2 + 1 iterations on rank-different batches
+    sums = [by[r][2] for r in range(world)]
+    assert max(sums) - min(sums) <= 1e-6 * max(1.0, abs(sums[0])), sums
+    assert all(by[r][3]["gen"] >= 2 and by[r][3]["disc"] >= 1 for r in range(world)), [by[r][3] for r in range(world)]
+
+
 def test_c_abi_exports_every_declared_symbol():
     """The shared library loads on a GPU-less host and exports every entry point include/posegan_hip.h declares."""
     import re

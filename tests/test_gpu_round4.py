@@ -268,7 +268,7 @@ def test_norm_backward_sums_fused_into_producers(monkeypatch):
     g1, c1 = res[True]
     g0, c0 = res[False]
     nred1, nred0 = c1.get("pg_norm_bwd_reduce_ex", 0), c0.get("pg_norm_bwd_reduce_ex", 0)
-    assert nred0 == c0["pg_norm_bwd_apply_v2"] and nred1 <= nred0 - 3, (nred1, nred0)      # at least the large layers fused
+    assert nred0 == c0["pg_norm_bwd_apply_v3"] and nred1 <= nred0 - 3, (nred1, nred0)      # at least the large layers fused
     for k in g0:
         a, b = g1[k].float(), g0[k].float()
         scale = float(b.abs().max())

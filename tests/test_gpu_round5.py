@@ -1,0 +1,353 @@
+"""Round-5 GPU tests (all through the C ABI):
+  * PG_DETERMINISTIC (pg_set_deterministic): two runs of the same trajectory are BIT-equal, in fp32 and on the bf16 data path;
+    with it the stream schedules can be compared bitwise: single stream == side / auxiliary / second-encoder streams, the
+    optimiser step in ranges under the backward pass (engine.EagerAdam) == one launch after it, every PG_ENC_PAR_LEVEL;
+  * the bf16 data path against the reference at 256 x 256 with bars taken from what the path DOES: 2 x the worst value observed
+    over three seeds (profiles/round5_bf16_tolerance.txt), scalar norm gamma / beta gradients included;
+  * the fused norm-backward sums fall back to the plain reduce pass when gamma is too small for their activated-operand form;
+  * the data-parallel reducer's ordering with one bucket per layer (first-layer bias gradients: ADVICE round 4)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpu_util import DEV, E, L, maxdiff, synth, t
+    from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
+from conftest import GOLDEN, ROOT
+from types import SimpleNamespace
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+P = 18
+PREC = {"f32": 0, "bf16_data": 3}
+
+
+def tp(d):
+    return {k: t(v) for k, v in d.items()}
+
+
+def dev(*xs):
+    return [x.to(DEV) for x in xs]
+
+
+def _opt(size, n, **kw):
+    o = SimpleNamespace(image_size=size, use_input_pose=True, pose_dim=P, batch_size=n, num_stacks=4, gen_type="baseline",
+                        dataset="fasion", warp_skip="mask", learning_rate=2e-4, content_loss_layer="none",
+                        nn_loss_area_size=1, gan_penalty_weight=1.0, l1_penalty_weight=100.0)
+    o.__dict__.update(kw)
+    return o
+
+
+@pytest.fixture
+def deterministic():
+    lib = L.load()
+    lib.pg_set_deterministic(1)
+    assert lib.pg_get_deterministic() == 1
+    yield
+    lib.pg_set_deterministic(0)
+
+
+def _run(size, n, iters, seed=7, stream="det", prefetch=False):
+    """`iters` iterations of dis_update + gen_update from init_seed `seed` on fixed batches / dropout masks; returns the final
+    parameter arenas, the last out_gen, every loss triple and the first iteration's gradient arenas."""
+    opt = _opt(size, n)
+    model = DeformablePose_GAN(opt, device=DEV, init_seed=seed)
+    od = vars(opt)
+    b = [dev(*[t(a) for a in synth.batch(501, "%s/%s" % (stream, s), n, P, *size)]) for s in "ABC"]
+    d = [dev(*[t(m) for m in synth.dropout_masks(501, "%s/d%s" % (stream, s), n)]) for s in "AC"]
+    losses, g0 = [], None
+    og = None
+    for it in range(iters):
+        oc = {"warps": b[2][2], "masks": b[2][3], "drop_masks": d[1]}
+        if prefetch:        # the generator update's forward enqueued ahead of dis_update (models/pose_gan.py)
+            assert model.prefetch_gen_forward(b[2][0], oc)
+        dl = model.dis_update(b[0][0], b[0][1], {"warps": b[0][2], "masks": b[0][3], "drop_masks": d[0]}, b[1][0], b[1][1], od)
+        og, _, gl = model.gen_update(b[2][0], b[2][1], oc, od)
+        if prefetch:
+            assert model._pf is None
+        losses.append(list(dl) + list(gl))
+        if it == 0:
+            g0 = (model.gen.arena.grads.clone(), model.disc.arena.grads.clone())
+    torch.cuda.synchronize()
+    return {"gen": model.gen.arena.params.clone(), "disc": model.disc.arena.params.clone(), "out": og.clone(),
+            "losses": np.array(losses), "g0": g0}
+
+
+def _assert_bitwise(a, b, what):
+    for k in ("gen", "disc", "out"):
+        assert torch.equal(a[k], b[k]), (what, k, float((a[k].float() - b[k].float()).abs().max()))
+    for x, y in zip(a["g0"], b["g0"]):
+        assert torch.equal(x, y), (what, "first-iteration gradients", float((x - y).abs().max()))
+    assert np.array_equal(a["losses"], b["losses"]), (what, "losses", np.abs(a["losses"] - b["losses"]).max())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16_data"])
+def test_deterministic_mode_repeats_bitwise(prec, monkeypatch, deterministic):
+    """with PG_DETERMINISTIC two trajectories from the same state are bit-equal — parameters of both
+    networks after 4 iterations (4 Adam steps amplify any summation-order difference into O(lr) changes), out_gen, every loss and
+    the first iteration's gradients.  128 x 128, batch 4: the deep layers' split-K launches (ordered fix-up), the weight
+    gradients (un-split here), the first layers' partial reductions and the warp backward's candidate lists are all on the path.
+    The default mode must compute the same step up to summation order."""
+    monkeypatch.setattr(E, "PRECISION", PREC[prec])
+    a = _run((128, 128), 4, 4)
+    b = _run((128, 128), 4, 4)
+    _assert_bitwise(a, b, "two deterministic runs, " + prec)
+    L.load().pg_set_deterministic(0)
+    c = _run((128, 128), 4, 1)
+    for x, y in zip(a["g0"], c["g0"]):       # same gradients as the default launch paths, up to the order of the sums
+        assert float((x - y).abs().max()) <= (1e-4 if prec == "f32" else 2e-2) * float(x.abs().max())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16_data"])
+def test_stream_schedules_are_bitwise_equal_in_deterministic_mode(prec, monkeypatch, deterministic):
+    """ADVICE round 4 (the side-stream test's band had to be widened because run-to-run noise hid what it checks): with ordered
+    sums the comparison is exact.  Single stream (no weight-gradient side stream, hence no auxiliary / second-encoder stream and
+    no optimiser ranges under the backward pass) == the default schedule (all four streams + EagerAdam), bit for bit, after three
+    iterations.  A missing stream dependency — a gradient read before it is written, a buffer reused too early, an Adam range
+    issued before the layer's data gradient has read the weights — changes bits here."""
+    monkeypatch.setattr(E, "PRECISION", PREC[prec])
+    monkeypatch.setattr(E, "SIDE_STREAM", False)
+    ref = _run((128, 128), 4, 3)
+    monkeypatch.setattr(E, "SIDE_STREAM", True)
+    got = _run((128, 128), 4, 3)
+    _assert_bitwise(ref, got, "single stream vs default schedule, " + prec)
+    # every placement of the second encoder stream, and the second stream alone without the optimiser ranges
+    for lvl in ("0", "3", "5"):
+        monkeypatch.setenv("PG_ENC_PAR_LEVEL", lvl)
+        _assert_bitwise(ref, _run((128, 128), 4, 3), "PG_ENC_PAR_LEVEL=%s, %s" % (lvl, prec))
+    monkeypatch.delenv("PG_ENC_PAR_LEVEL")
+    monkeypatch.setattr(E, "EAGER_ADAM", False)
+    _assert_bitwise(ref, _run((128, 128), 4, 3), "no optimiser ranges, " + prec)
+    monkeypatch.setattr(E, "EAGER_ADAM", True)
+    monkeypatch.setattr(E, "ENC_PAR", False)
+    _assert_bitwise(ref, _run((128, 128), 4, 3), "no second encoder stream, " + prec)
+    monkeypatch.setattr(E, "ENC_PAR", True)
+    # the generator update's forward enqueued AHEAD of dis_update on its own stream and engine: same kernels, same dropout stream
+    _assert_bitwise(ref, _run((128, 128), 4, 3, prefetch=True), "prefetched generator forward, " + prec)
+
+
+def test_eager_adam_issues_ranges_under_the_backward_pass(monkeypatch):
+    """engine.EagerAdam: the generator's optimiser step is issued in ranges while the backward pass runs (reference
+    pose_gan.py:111 `self.gen_opt.step()` is one call after it): several pg_adam launches per gen_update, together covering the
+    arena exactly once, the first of them BEFORE the last weight gradient of the pass."""
+    monkeypatch.setattr(E, "PRECISION", 0)
+    size, n = (128, 128), 2
+    opt = _opt(size, n)
+    model = DeformablePose_GAN(opt, device=DEV, init_seed=7)
+    od = vars(opt)
+    b = dev(*[t(a) for a in synth.batch(502, "eager", n, P, *size)])
+    calls = []
+
+    def hook(name, a, launch):
+        calls.append((name, a))
+        return launch()
+
+    monkeypatch.setattr(L, "CALL_HOOK", hook)
+    model.gen_update(b[0], b[1], {"warps": b[2], "masks": b[3]}, od)
+    monkeypatch.setattr(L, "CALL_HOOK", None)
+    torch.cuda.synchronize()
+    names = [c[0] for c in calls]
+    adam = [i for i, nm in enumerate(names) if nm == "pg_adam"]
+    # (the contraction launches bypass the call hook; the norm backward of the shallow encoder levels and the first layers'
+    #  weight gradients are late landmarks of the backward pass that do not)
+    late = [i for i, nm in enumerate(names) if nm.startswith("pg_norm_bwd_apply") or nm == "pg_small_cin_wgrad"]
+    assert len(adam) >= 3, names.count("pg_adam")
+    assert adam[0] < late[-1] and adam[1] < late[-1], "no optimiser range was issued under the backward pass"
+    arena = model.gen.arena
+    covered = sorted((int(calls[i][1][0]) - arena.params.data_ptr()) // 4 for i in adam)
+    sizes = {(int(calls[i][1][0]) - arena.params.data_ptr()) // 4: int(calls[i][1][4]) for i in adam}
+    pos = 0
+    for off in covered:
+        assert off == pos, (off, pos)
+        pos += sizes[off]
+    assert pos == arena.total and arena.step == 1
+
+
+# ------------------------------------------------------------------------------------------ bf16 data path vs the reference, 256^2
+# Bars = 2 x the worst value observed over three seeds at 256 x 256, batch 2 (seed 92: the REAL reference's capture
+# tests/golden/g256.npz; seeds 93 / 94: the oracle, itself pinned to that capture at 2e-5) — profiles/round5_bf16_tolerance.txt
+# (PG_TOL_STUDY=1 prints the observations).  Round 4 stated 0.3 / 2.6e-2 / 3e-2 / 0.2: what bf16 autocast does to the reference,
+# not what this path does.
+BF16_TOL = {"out_max": 0.16, "out_mean": 1.2e-2, "loss_rel": 1.6e-2, "grad": 0.12, "grad_scalar": 0.5}
+F32_SCALAR_TOL = 2e-2
+
+
+def _summ(x):
+    f = x.detach().reshape(-1).double().cpu()
+    idx = torch.linspace(0, f.numel() - 1, 32).long()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item(), f.abs().max().item()], f[idx].numpy()])
+
+
+def _grad_obs(grads, ref_summ):
+    """per tensor: worst |summary sample - reference| / tensor max; scalars (norm gamma / beta: cancelling sums over a whole
+    activation) against max(|ref|, a tenth of the median scalar gradient of the network)"""
+    scal = [abs(float(ref_summ(k)[0])) for k, g in grads.items() if g.numel() == 1]
+    floor = 0.1 * float(np.median(scal)) if scal else 0.0
+    obs = {}
+    for k, g in grads.items():
+        ref = ref_summ(k)
+        if g.numel() == 1:
+            obs[k] = ("scalar", abs(float(g) - float(ref[0])) / max(abs(float(ref[0])), floor, 1e-12))
+        else:
+            obs[k] = ("tensor", float(np.abs(_summ(g)[2:] - ref[2:]).max() / max(ref[2], 1e-12)))
+    return obs
+
+
+def _step_256(name, seed, prec, monkeypatch):
+    """one dis_update + gen_update at 256 x 256, batch 2, on the device in `prec`; the reference values: seed 92 -> g256.npz
+    (strided out_gen, summaries), other seeds -> the oracle run here (full tensors reduced to the same summaries)"""
+    monkeypatch.setattr(E, "PRECISION", PREC[prec])
+    H = W = 256
+    N, STRIDE = 2, 5
+    enc, dec = synth.nfilters((H, W))
+    kw = {} if name == "l1" else dict(content_loss_layer="block1_conv2", nn_loss_area_size=5, l1_penalty_weight=0.01)
+    opt = _opt((H, W), N, **kw)
+    model = DeformablePose_GAN(opt, device=DEV)
+    gpar = synth.init_params(seed, "g256/%s/gen" % name, synth.generator_spec(P, enc, dec), 0.1)
+    dpar = synth.init_params(seed, "g256/%s/disc" % name, synth.discriminator_spec(3 + 2 * P + 3), 0.1)
+    model.gen.load_state_dict(tp(gpar))
+    model.disc.load_state_dict(tp(dpar))
+    od = vars(opt)
+    hb = [[t(a) for a in synth.batch(seed, "g256/%s/%s" % (name, s), N, P, H, W)] for s in "ABC"]
+    hd = [[t(m) for m in synth.dropout_masks(seed, "g256/%s/d%s" % (name, s), N)] for s in "AC"]
+    bA, bB, bC = [dev(*x) for x in hb]
+    dA, dC = [dev(*x) for x in hd]
+    dl = model.dis_update(bA[0], bA[1], {"warps": bA[2], "masks": bA[3], "drop_masks": dA}, bB[0], bB[1], od)
+    dgr = {k: v.clone() for k, v in model.disc.arena.grad_dict().items()}
+    og, _, gl = model.gen_update(bC[0], bC[1], {"warps": bC[2], "masks": bC[3], "drop_masks": dC}, od)
+    ggr = model.gen.arena.grad_dict()
+    if seed == 92:
+        fix = np.load(os.path.join(GOLDEN, "g256.npz"))
+        ref = {"dis": fix[name + "_dis_losses"], "gen": fix[name + "_gen_losses"], "out": t(fix[name + "_out_gen_strided"]),
+               "dg": lambda k: fix[name + "_dgrad_" + k], "gg": lambda k: fix[name + "_ggrad_" + k]}
+    else:
+        import ref_cpu as R
+        cfg = dict(pose_dim=P, image_size=(H, W), batch_size=N, gan_penalty_weight=1.0, l1_penalty_weight=opt.l1_penalty_weight,
+                   learning_rate=2e-4, content_loss_layer=opt.content_loss_layer, nn_loss_area_size=opt.nn_loss_area_size,
+                   nfilters_enc=enc, nfilters_dec=dec)
+        vgg = (model.vgg_w.cpu(), model.vgg_b.cpu()) if name != "l1" else None
+        tr = R.Trainer(cfg, tp(gpar), tp(dpar), vgg)
+        rdl = tr.dis_update(hb[0][0], hb[0][1], hb[0][2], hb[0][3], hb[1][0], hb[1][1], hd[0])
+        rog, rgl = tr.gen_update(hb[2][0], hb[2][1], hb[2][2], hb[2][3], hd[1])
+        dgs = {k: _summ(v) for k, v in tr.last_disc_grads.items()}
+        ggs = {k: _summ(v) for k, v in tr.last_gen_grads.items()}
+        ref = {"dis": np.array(rdl), "gen": np.array(rgl), "out": rog[:, :, ::STRIDE, ::STRIDE],
+               "dg": lambda k: dgs[k], "gg": lambda k: ggs[k]}
+    d = (og[:, :, ::STRIDE, ::STRIDE].cpu() - ref["out"]).abs()
+    rel = lambda x, y: float(np.max(np.abs(np.array(x) - np.array(y)) / np.maximum(np.abs(np.array(y)), 5e-2)))
+    obs = {"out_max": float(d.max()), "out_mean": float(d.mean()), "loss_rel": max(rel(dl, ref["dis"]), rel(gl, ref["gen"]))}
+    g = {}
+    g.update({"d/" + k: v for k, v in _grad_obs(dgr, ref["dg"]).items()})
+    g.update({"g/" + k: v for k, v in _grad_obs(ggr, ref["gg"]).items()})
+    obs["grad"] = max(v for kind, v in g.values() if kind == "tensor")
+    obs["grad_scalar"] = max(v for kind, v in g.values() if kind == "scalar")
+    if os.environ.get("PG_TOL_STUDY") == "1":
+        worst_t = max(((v, k) for k, (kind, v) in g.items() if kind == "tensor"))
+        worst_s = max(((v, k) for k, (kind, v) in g.items() if kind == "scalar"))
+        print("TOLSTUDY5 %s seed %d %s: out_gen max %.4f mean %.5f | losses rel %.5f | gradients %.4f (%s) | scalar gradients %.4f (%s)"
+              % (name, seed, prec, obs["out_max"], obs["out_mean"], obs["loss_rel"], worst_t[0], worst_t[1], worst_s[0], worst_s[1]))
+    return obs
+
+
+@pytest.mark.parametrize("seed", [92, 93, 94])
+@pytest.mark.parametrize("name", ["l1", "nn"])
+def test_bf16_data_step_256_vs_reference(name, seed, monkeypatch):
+    """the bf16 data path — the path every north-star number is quoted on — at the metric
+    resolution against the reference (seed 92: the real reference's capture; 93 / 94: the oracle), with bars that are 2 x what
+    the path was observed to do.  'l1' = BASELINE.json configs[1]'s loss, 'nn' = configs[3]'s (nearest-neighbour loss 5 x 5
+    over VGG block1_conv2).  Scalar norm gamma / beta gradients are compared too (item 5c)."""
+    obs = _step_256(name, seed, "bf16_data", monkeypatch)
+    bad = {k: (v, BF16_TOL[k]) for k, v in obs.items() if not v <= BF16_TOL[k]}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["l1", "nn"])
+def test_fp32_step_256_scalar_gradients_vs_golden(name, monkeypatch):
+    """the 32 + 6 scalar norm gamma / beta gradients of the metric configuration against the
+    real reference's capture at the 2e-2 the 64 x 64 tests use (tests/test_gpu_networks.py) — round 4 skipped them at 256^2."""
+    obs = _step_256(name, 92, "f32", monkeypatch)
+    assert obs["grad_scalar"] <= F32_SCALAR_TOL, obs
+    assert obs["out_max"] < 1e-3 and obs["loss_rel"] < 1e-4 and obs["grad"] < 5e-3, obs
+
+
+# ------------------------------------------------------------------------------------------ small gamma: the guarded reduce pass
+@pytest.mark.parametrize("gamma", [0.0, 2e-4, 1.0])
+def test_norm_backward_sums_small_gamma_guard(gamma, monkeypatch):
+    """ADVICE round 4 (csrc/norm.hip sums_mode 2): the output convolution's fused backward hands the last block's norm backward
+    (sum r, sum r * f) with f the ACTIVATED, bf16-rounded operand, from which sum r * xhat = (S2 - beta S1) / gamma — undefined
+    at gamma = 0 (round 4 forced the gamma gradient to 0 there: gamma could never leave 0) and cancelling for small gamma.
+    pg_norm_bwd_reduce_guard runs the plain reduce pass over (dz, y) exactly then, decided on the device.  Every gradient must
+    agree with the unfused path (FUSE_NORM_SUMS off), the last block's gamma gradient included."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    size, n = (128, 128), 4
+    inp, tgt, wr, mk = dev(*[t(a) for a in synth.batch(503, "guard", n, P, *size)])
+    drops = dev(*[t(m) for m in synth.dropout_masks(503, "guard", n)])
+    gout = t(synth.normal(503, "guard/g", (n, 3, *size))).to(DEV)
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(E, "FUSE_NORM_SUMS", fuse)
+        model = DeformablePose_GAN(_opt(size, n), device=DEV, init_seed=7)
+        sd = model.gen.state_dict()
+        last = max(int(k.split(".")[2]) for k in sd if k.startswith("decoder.net.") and k.endswith(".net.3.weight"))
+        sd = {k: v.clone() for k, v in sd.items()}
+        sd["decoder.net.%d.net.3.weight" % last] = torch.full_like(sd["decoder.net.%d.net.3.weight" % last], gamma)
+        sd["decoder.net.%d.net.3.bias" % last] = torch.full_like(sd["decoder.net.%d.net.3.bias" % last], 0.3)
+        model.gen.load_state_dict(sd)
+        eng = model.gen.engine(n)
+        assert eng.bfs
+        eng.set_dropout(drops)
+        counts = {}
+
+        def hook(name, a, launch):
+            counts[name] = counts.get(name, 0) + 1
+            return launch()
+
+        model.gen.zero_grad()
+        eng.forward(inp, wr, mk)
+        monkeypatch.setattr(L, "CALL_HOOK", hook)
+        eng.backward(gout)
+        monkeypatch.setattr(L, "CALL_HOOK", None)
+        torch.cuda.synchronize()
+        res[fuse] = ({k: v.clone() for k, v in model.gen.arena.grad_dict().items()}, counts, last)
+    g1, c1, last = res[True]
+    g0, c0, _ = res[False]
+    assert c1.get("pg_norm_bwd_reduce_guard", 0) == 1 and "pg_norm_bwd_reduce_guard" not in c0, (c1, c0)
+    gk = "decoder.net.%d.net.3.weight" % last
+    a, b = float(g1[gk]), float(g0[gk])
+    assert np.isfinite(a) and abs(a - b) <= 5e-2 * abs(b) + 1e-6, (gamma, a, b)       # the gamma gradient itself (0 in round 4 at gamma = 0)
+    if gamma == 0.0:
+        assert abs(b) > 1e-6 and abs(a) > 1e-6, (a, b)
+    for k in g0:
+        x, y = g1[k].float(), g0[k].float()
+        if x.numel() == 1:
+            continue
+        assert float((x - y).abs().max()) <= 2e-2 * float(y.abs().max()) + 1e-7, (gamma, k)
+
+
+# ------------------------------------------------------------------------------------------ reducer ordering, one bucket per layer
+@pytest.mark.parametrize("prec_env", [{}, {"PG_PRECISION": "bf16_data", "PG_NO_STEM_BIAS_FUSED": "1"}])
+def test_reducer_stream_order_one_bucket_per_layer(tmp_path, prec_env):
+    """where the first layer's bias gradient needs its own kernel (the fp32 path; the bf16 path without
+    the fused form) it was enqueued on the MAIN stream AFTER the layer's weight-gradient call, i.e. after the side stream's last
+    wait for the main stream — a bucket handed over from that layer's `_ready` hook could all-reduce a bias gradient that was
+    still being written.  With buckets of a few KB every layer is its own hand-over; the main stream is delayed by 300 us in
+    front of every gradient it writes and the 'all-reduce' is bucket += bucket (as in the round-3 stress test): the result must
+    equal the plain run."""
+    from test_gpu_round2 import _run_dp_child
+    tiny = {"PG_DP_BUCKET_BYTES": "65536", "PG_DP_MIN_BUCKET_BYTES": "1024"}
+    base = dict(prec_env, PG_FORCE_REDUCER="1", PG_DP_DEBUG_PEER="1", PG_DEBUG_MAIN_DELAY_US="300", **tiny)
+    ref = _run_dp_child(1, tmp_path, dict(prec_env))
+    fast = _run_dp_child(1, tmp_path, base)
+    assert fast["divisor"] == 2 and fast["buckets"] >= 20, fast["buckets"]
+    tol = 1e-4 if not prec_env else 2e-2
+    for k in ("gen_grads", "disc_grads"):
+        assert float((fast[k] - ref[k]).abs().max()) < tol * float(ref[k].abs().max()), k
+    broken = _run_dp_child(1, tmp_path, dict(base, PG_DP_DEBUG_NO_WAIT="1"))
+    worst = max(float((broken[k] - ref[k]).abs().max()) / float(ref[k].abs().max()) for k in ("gen_grads", "disc_grads"))
+    assert worst > 1e-2, "negative control: reducing without producer events went unnoticed (%.2e)" % worst
