@@ -390,6 +390,9 @@ HBM_MODELS = {
                              * ((_ival(a[3]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1)
                              * ((_ival(a[4]) + 2 * _ival(a[7]) - _ival(a[5])) // _ival(a[6]) + 1),
     "pg_bias_grad_bf16": lambda a: 2 * _ival(a[1]) * _ival(a[2]),
+    # (round 5) output convolution forward in one pass: every source read once (2 B / channel), the block's activated operand and out_gen written
+    "pg_out_conv_fwd_fused": lambda a: _ival(a[17]) * _ival(a[18]) * _ival(a[19])
+                             * (2 * (_ival(a[1]) + _ival(a[12]) + _ival(a[14])) + 2 * _ival(a[1]) + 12),
     "pg_tap_gather_pitch": lambda a: _ival(a[2]) * _ival(a[3]) * _ival(a[4]) * (27 * 4 + 12),
     # output-conv backward, bf16 storage, ONE pass: dpre (12 B / pixel) + activated operand read once + gradient write (2 + 2 B / channel)
     "pg_out_conv_bwd_direct": lambda a: _ival(a[3]) * _ival(a[4]) * _ival(a[5]) * (12 + 4 * sum(a[6][i].C for i in range(_ival(a[7])))),

@@ -443,6 +443,18 @@ int pg_materialise_bf16_ex(const void* x, int32_t x_is_bf16, const float* aff, c
 int pg_materialise_bf16_norm(const void* x, int32_t x_is_bf16, const double* sums, const float* gamma, const float* beta,
                              int64_t L, float eps, float* mr, float* aff, const float* mask, int32_t act, int32_t N, int64_t HW,
                              int32_t C, void* out_bf16, void* out2_bf16, int32_t act2, void* stream);
+/* (round 5) The generator's output convolution, forward, in ONE streaming pass on the bf16 data path (csrc/out_conv_fwd.hip;
+ * replaces networks.py:228 `ReLU -> Conv2d(cin, 3, k3, p1) -> Tanh` over the concat of the last decoder block's normalised output
+ * and the level-0 skips, networks.py:236-250): x0 = the block's RAW bf16 output [N][H][W][C0], normalised here with the published
+ * per-sample affine `aff` or — pg_norm_finalize folded in as in pg_materialise_bf16_norm — from the complete statistics `sums`
+ * (then gamma / beta / L / eps / mr / aff_out are required and (mean, rstd), (a, b) are published); op0 receives
+ * bf16(relu(a x0 + b)), the activated operand the backward pass reads; x1 / x2 = further sources as bf16 ACTIVATED operands
+ * (C = 0: absent); W27 = the fp32 weight viewed as [27 = tap * 3 + co][C0 + C1 + C2]; out = act(bias + conv) as NCHW fp32.
+ * (C0, C1, C2) in {(128, 64, 64), (128, 64, 0), (64, 64, 0)}. */
+int pg_out_conv_fwd_fused(const void* x0_bf16, int32_t C0, const float* aff, const double* sums, const float* gamma,
+                          const float* beta, int64_t L, float eps, float* mr, float* aff_out, void* op0_bf16, const void* x1_bf16,
+                          int32_t C1, const void* x2_bf16, int32_t C2, const float* W27, const float* bias, int32_t N, int32_t H,
+                          int32_t W, int32_t out_act, float* out, void* stream);
 /* io_flags: bit 0 = dz is bf16, bit 1 = y is bf16 */
 int pg_norm_bwd_reduce_ex(const void* dz, const void* y, const float* mr, int32_t N, int64_t L, double* bsums,
                           int32_t io_flags, void* stream);

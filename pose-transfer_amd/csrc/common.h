@@ -197,4 +197,28 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return 1.f;
 }
 
+// The per-sample affine of a norm layer whose statistics have just been completed by the producing convolution (round 4:
+// pg_norm_finalize folded into the first reader — materialise_bf16_kernel, optim.hip; out_conv_fwd_kernel, out_conv_fwd.hip).
+struct NormFold {
+  const double* sums;       // [N][PG_STAT_SLOTS][2] or null
+  const float* gamma; const float* beta;
+  long L; float eps;
+  float* mr; float* aff;
+};
+// norm_finalize_kernel's arithmetic for sample n; `publish`: this thread writes (mean, rstd) and (a, b) for the later readers
+__device__ __forceinline__ void norm_fold_affine(const NormFold& nf, int n, bool publish, float& a, float& b) {
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < PG_STAT_SLOTS; ++k) { s1 += nf.sums[((long)n * PG_STAT_SLOTS + k) * 2]; s2 += nf.sums[((long)n * PG_STAT_SLOTS + k) * 2 + 1]; }
+  const double mean = s1 / (double)nf.L;
+  double var = s2 / (double)nf.L - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)nf.eps);
+  const double g = (double)nf.gamma[0], bt = (double)nf.beta[0];
+  a = (float)(g * rstd); b = (float)(bt - g * mean * rstd);
+  if (publish) {
+    nf.mr[2 * n] = (float)mean; nf.mr[2 * n + 1] = (float)rstd;
+    nf.aff[2 * n] = a; nf.aff[2 * n + 1] = b;
+  }
+}
+
 }  // namespace pg

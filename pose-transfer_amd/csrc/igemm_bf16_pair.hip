@@ -20,6 +20,16 @@
 // LDS row of A is not a tile row's private copy any more (the swizzle is a function of the LDS row), an A fragment address is
 // per (lane, tap of the pair, M tile): two VALU instructions per ds_read_b128 instead of an immediate offset.
 // Host conditions (conv_impl): every phase's taps pair up, ksplit = 1, Gx large enough for the extra rows.
+//
+// MG (round 5) — X-PHASE MERGING for the transposed k4 s2 convolutions with few output channels (the last decoder block's forward,
+// the data gradients of encoder levels 1 / 2: N = 128 or 64).  Sub-pixel phase (py, 0) reads taps dx = -1, 0 and phase (py, 1) reads
+// dx = 0, +1 of the SAME input rows: with Gx + 2 slots per image row in the A tile, one tile serves both phases — the waves of the
+// left column half (phase px = 0) read LDS rows rho, rho + 1 for the two taps of a step, the waves of the right half (px = 1) rows
+// rho + 1, rho + 2 — and the B tile holds the two phases' weights side by side.  The workgroup tile becomes 256 x 2 Cout: the
+// DMA volume per FLOP of the 256 x 256 kernel instead of the 256 x 128 one (A tile - 47 %, all DMA - 24 %), half the workgroups,
+// and the two phases' outputs are neighbouring pixels: column n of the tile is channel n mod Cout of pixel (oy, 2 qx + n / Cout),
+// i.e. offset n from the left pixel — the epilogues see an image of half the width with 2 Cout channels (host: n_cnt, dst C doubled,
+// row table entries hold the pixel-PAIR index), nothing else changes.
 #include "igemm_bf16_epi.h"
 
 namespace pg {
@@ -29,8 +39,10 @@ struct ARow {      // LDS row of the A ring -> the input pixel it holds, before 
   short iy, ix;    // qy * si, slot * si
 };
 
-template <int BN>
+template <int BN, bool MG = false>
 __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
+  static_assert(!(MG && BN == 64), "x-phase merging: 256-row tiles");
+  constexpr int XS = MG ? 2 : 1;                         // extra slots per image row of the A tile
   constexpr int BM = (BN == 64) ? 512 : 256;
   constexpr int WGN = BN / 64, WGM = 8 / WGN;
   constexpr int TM = BM / WGM / 32, TN = 2;
@@ -43,7 +55,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
   constexpr int B_OFF = 2 * A_ST;                        // [A ring: 2 stages][B ring: 2 stages]
   constexpr int OPS = 2 * (A_ST + B_ST);
   constexpr int ROWS_OFF = OPS, AROW_OFF = ROWS_OFF + BM * (int)sizeof(RowB), TAPS_OFF = AROW_OFF + AROWS * (int)sizeof(ARow);
-  constexpr int STAT_OFF = (TAPS_OFF + MAXTAP * 4 + 7) & ~7, STAT_N = 8;
+  constexpr int STAT_OFF = (TAPS_OFF + MAXTAP * 8 + 7) & ~7, STAT_N = 8;      // two tap tables (MG: the right half's phase)
   static_assert(8 * (32 * (32 * TN + 4)) * 4 <= OPS && AROWS % 8 == 0, "epilogue tiles / DMA rows");
   static_assert(STAT_OFF + STAT_N * 16 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(1024))) char smem[STAT_OFF + STAT_N * 2 * 8];
@@ -73,6 +85,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
   if (tid >= 64 && tid < 64 + STAT_N * 2) reinterpret_cast<double*>(smem + STAT_OFF)[tid - 64] = 0.0;
   if (tid < MAXTAP)
     taps_l[tid] = (p.dy[phase][tid] & 0xff) | ((p.dx[phase][tid] & 0xff) << 8) | ((int)p.wtap[phase][tid] << 16);
+  if (MG && tid >= 64 && tid < 64 + MAXTAP) {           // the right half's taps (phase (py, 1)): host keeps them in slot 2 + py
+    const int q = tid - 64;
+    taps_l[MAXTAP + q] = (p.dy[2 + phase][q] & 0xff) | ((p.dx[2 + phase][q] & 0xff) << 8) | ((int)p.wtap[2 + phase][q] << 16);
+  }
   if (tid < BM) {
     RowB ri;
     const int m = m0 + tid;
@@ -88,13 +104,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
       if (oy < p.Ho && ox < p.Wo) {
         ri.n = n; ri.iy = (short)(qy * p.si); ri.ix = (short)(qx * p.si); ri.oy = (short)oy; ri.ox = (short)ox;
         ri.opix = (n * p.Ho + oy) * p.Wo + ox;
+        if (MG) ri.opix >>= 1;                            // pixel PAIR (ox = 2 qx, Wo even): the epilogues' rows are 2 Cout wide
       }
     }
     rows[tid] = ri;
   }
-  for (int rho = tid; rho < AROWS; rho += 512) {          // LDS row -> (local image row j, slot k): rho + qx0 = j (Gx + 1) + k
+  for (int rho = tid; rho < AROWS; rho += 512) {          // LDS row -> (local image row j, slot k): rho + qx0 = j (Gx + XS) + k
     const int t = rho + qx0;
-    const int j = t / (gx + 1), k = t - j * (gx + 1);
+    const int j = t / (gx + XS), k = t - j * (gx + XS);
     const int Rg = R0 + j;
     const int n = Rg / p.Gy, qy = Rg - n * p.Gy;
     ARow a;
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
   unsigned pa[A_PASS], pb[B_PASS];
   unsigned pa_ok = 0, pb_ok = 0;
   const char* a_src = zero_pg;                       // uniform: source tensor of the A cursor's chunk
-  long wdelta = 0;                                   // uniform: byte offset from the pair's first to its second tap in W
+  long wdelta = 0, wdelta1 = 0;                      // uniform: byte offset from the pair's first to its second tap in W (MG: per column half)
   int a_g = 0, a_ci = 0, a_left = npc;               // A cursor: next (pair, chunk) to load; steps not yet loaded
   int b_g = 0, b_ci = 0, b_left = npc;               // B cursor: next (pair, chunk); its two tiles are issued one by one
   auto rebuild_a = [&]() __attribute__((always_inline)) {
@@ -174,12 +191,19 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
     const int tp0 = lds_rd32_now(lds0 + TAPS_OFF + (2 * b_g) * 4), tp1 = lds_rd32_now(lds0 + TAPS_OFF + (2 * b_g + 1) * 4);
     const int base = __builtin_amdgcn_readfirstlane((tp0 >> 16) * p.wCout);
     wdelta = (long)__builtin_amdgcn_readfirstlane((tp1 >> 16) - (tp0 >> 16)) * p.wCout * p.wCin * 2;
+    int base1 = 0;
+    if constexpr (MG) {                              // the right column half: phase (py, 1)'s pair g
+      const int tq0 = lds_rd32_now(lds0 + TAPS_OFF + (MAXTAP + 2 * b_g) * 4), tq1 = lds_rd32_now(lds0 + TAPS_OFF + (MAXTAP + 2 * b_g + 1) * 4);
+      base1 = __builtin_amdgcn_readfirstlane((tq0 >> 16) * p.wCout);
+      wdelta1 = (long)__builtin_amdgcn_readfirstlane((tq1 >> 16) - (tq0 >> 16)) * p.wCout * p.wCin * 2;
+    }
     pb_ok = 0;
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      const int n = nb0 + (tid >> 3) + 64 * i;
-      const bool ok = n < p.n_cnt;
-      pb[i] = ok ? ((unsigned)(base + p.n_off + n) * (unsigned)p.wCin + (unsigned)(b_ci * 64 + chunk * 8)) * 2u : 0u;
+      const bool right = MG && 64 * i >= BN / 2;      // compile-time per pass: rows [BN / 2, BN) of the B tile
+      const int n = nb0 + (tid >> 3) + 64 * i - (right ? BN / 2 : 0);
+      const bool ok = MG ? true : n < p.n_cnt;        // (MG: host guarantees Cout == BN / 2)
+      pb[i] = ok ? ((unsigned)((right ? base1 : base) + p.n_off + n) * (unsigned)p.wCin + (unsigned)(b_ci * 64 + chunk * 8)) * 2u : 0u;
       pb_ok |= (ok ? 1u : 0u) << i;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -203,7 +227,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
     float* const Bs = reinterpret_cast<float*>(smem + B_OFF + stage * B_ST);
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      const char* src = ((pb_ok >> i) & 1u) ? wp + (second ? wdelta : 0) + pb[i] : zero_pg + (tid & 7) * 16;
+      const long wd = (MG && 64 * i >= BN / 2) ? wdelta1 : wdelta;
+      const char* src = ((pb_ok >> i) & 1u) ? wp + (second ? wd : 0) + pb[i] : zero_pg + (tid & 7) * 16;
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), Bs + (i * 8 + wave) * 256, 16, 0, 0);
     }
   };
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm0 + 32 * i + l31;
-    const int rho = r + (qx0 + r) / gx;
+    const int rho = r + XS * ((qx0 + r) / gx) + ((MG && wn0 >= BN / 2) ? 1 : 0);      // (MG, right half: taps dx = 0, +1 -> one slot further)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = rho + j, s = (row >> 1) & 7;
@@ -367,7 +392,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
 }
 
 void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
-  if (bn == 256) PG_KLAUNCH((conv_bf16_pair_kernel<256>), grid, dim3(512), 0, st, k);
+  if (bn == 1256) PG_KLAUNCH((conv_bf16_pair_kernel<256, true>), grid, dim3(512), 0, st, k);       // x-phase merged: 256 x (2 x 128)
+  else if (bn == 1128) PG_KLAUNCH((conv_bf16_pair_kernel<128, true>), grid, dim3(512), 0, st, k);  // 256 x (2 x 64)
+  else if (bn == 256) PG_KLAUNCH((conv_bf16_pair_kernel<256>), grid, dim3(512), 0, st, k);
   else if (bn == 64) PG_KLAUNCH((conv_bf16_pair_kernel<64>), grid, dim3(512), 0, st, k);
   else PG_KLAUNCH((conv_bf16_pair_kernel<128>), grid, dim3(512), 0, st, k);
 }

@@ -1835,12 +1835,14 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
       if (wgs >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr) {
         // (round 4) tap-pair sharing of the A tile (igemm_bf16_pair.hip): every phase's taps must pair up as (dy, dx), (dy, dx + si)
         // — reordered here so that taps 2g, 2g + 1 are pair g — and the tile's extra LDS rows (one per image row) must suffice
-        bool pair = false;
+        bool pair = false, pair_taps = false;      // pair_taps: every phase's taps pair up (kp = the launch with pair-ordered taps)
+        ConvK kp = k;
         {
           const char* pe = getenv("PG_BIG_PAIR");          // "0" / "1": read per launch (the test-suite flips it inside one process)
           const int bm_p = bn == 64 ? 512 : 256, axr = bn == 64 ? 8 : 16;
           bool want = pe ? pe[0] != '0' : true;
-          want = want && k.Gx >= 2 && (bm_p + k.Gx - 2) / k.Gx + 1 <= axr && k.Wi * 1 < 32000 && k.Hi < 32000;
+          want = want && k.Gx >= 2 && k.Wi * 1 < 32000 && k.Hi < 32000;
+          const bool rows_ok = (bm_p + k.Gx - 2) / k.Gx + 1 <= axr;      // (the x-phase merged form below has its own row condition)
           if (want) {
             ConvK kk = k;
             bool ok = true;
@@ -1868,28 +1870,78 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
                 }
               }
             }
-            if (ok) { k = kk; pair = true; }
+            if (ok) { kp = kk; pair_taps = true; pair = rows_ok; }
+            if (pair) k = kk;
           }
         }
         if (pair && code == 129) { code = 128; mtb = cdiv(k.M, 256); }          // 128 columns: the paired 256 x 128 tile instead of 512 x 128 x 32
         k.xcd_swizzle = (mtb % 8 == 0 && (ntb > 1 || k.nphase > 1) && !env().no_xcd_swizzle) ? 1 : 0;
         k.xcd_swizzle |= (int)env().debug_bits;       // zero unless built with -DPG_TIMING_EXPERIMENTS
         if (k.dst_io == 1 && k.Gy * k.Gx < 32) k.dst_io = 2;      // the pipelined bf16 scatter assumes <= 2 samples per 32 rows
+        // (round 5) x-phase merging (igemm_bf16_pair.hip, MG): a transposed k4 s2 convolution with N = 128 / 64 output columns runs
+        // its phases (py, 0) and (py, 1) in ONE workgroup tile of 2 N columns — the A tile carries Gx + 2 slots per image row, the B
+        // tile both phases' weights; the outputs of the two phases are neighbouring pixels, so the epilogues see an image of half
+        // the width with 2 N channels (n_cnt, the destination's C and its column start doubled; row table = pixel-pair index).
+        int bn_l = bn;             // the launch's tile width
+        bool merged = false;
+        ConvK kmerged;
+        {
+          const char* me = getenv("PG_BIG_MERGE");          // "0" / "1": read per launch (the test-suite flips it inside one process)
+          const ConvK& k = kp;                               // (the pair-ordered tap tables, whether or not the unmerged launch pairs)
+          bool want = pair_taps && (me ? me[0] != '0' : true) && d->mode == 1 && k.nphase == 4 && k.so == 2 && (bn == 128 || bn == 64) &&
+                      ntb == 1 && k.n_cnt == bn && k.n_off == 0 && k.n_cnt == nfull && d->bias == nullptr && d->Wo == 2 * k.Gx &&
+                      d->Wo % 2 == 0 && k.Gx >= 43 && ((long)cdiv(k.M, 256) * 2 >= big_min || getenv("PG_FORCE_BF16_BIG") != nullptr);
+          if (want && d->epilogue == 1)
+            want = d->ndst == 1 && d->dst[0].mask == nullptr && d->dst[0].C == k.n_cnt && k.dst_io == 1;
+          if (want && d->epilogue == 0) want = k.vec_out != 0;
+          for (int py = 0; py < 2 && want; ++py) {           // phase (py, 1)'s pair-ordered taps = phase (py, 0)'s one step to the right
+            const int a = 2 * py, b = 2 * py + 1;
+            if (k.ntap[a] != k.ntap[b] || k.phy[a] != py || k.phy[b] != py || k.phx[a] != 0 || k.phx[b] != 1) { want = false; break; }
+            for (int t = 0; t < k.ntap[a]; ++t)
+              if (k.dy[a][t] != k.dy[b][t] || k.dx[b][t] != k.dx[a][t] + 1) want = false;
+          }
+          if (want) {
+            ConvK km = k;
+            for (int py = 0; py < 2; ++py) {
+              const int srcs[2] = {2 * py, 2 * py + 1}, dsts_[2] = {py, 2 + py};
+              for (int h = 0; h < 2; ++h) {
+                km.ntap[dsts_[h]] = k.ntap[srcs[h]];
+                for (int t = 0; t < MAXTAP; ++t) {
+                  km.dy[dsts_[h]][t] = k.dy[srcs[h]][t]; km.dx[dsts_[h]][t] = k.dx[srcs[h]][t]; km.wtap[dsts_[h]][t] = k.wtap[srcs[h]][t];
+                }
+              }
+              km.phy[py] = py; km.phx[py] = 0;
+            }
+            km.nphase = 2;
+            km.n_cnt = 2 * k.n_cnt;
+            if (d->epilogue == 1) {
+              km.dst[0].C = 2 * k.dst[0].C;
+              for (int j = 1; j <= PG_MAX_SRC; ++j) km.dstart[j] = km.n_cnt;
+            }
+            mtb = cdiv(k.M, 256);
+            km.xcd_swizzle = ((mtb % 8 == 0 && !env().no_xcd_swizzle) ? 1 : 0) | (int)env().debug_bits;
+            kmerged = km;
+            merged = true;
+            bn_l = 2 * bn;
+          }
+        }
         // (round 4) fused norm-backward sums (pg_dst_t.bsums): the pipelined bf16 scatter implements them when a workgroup's
         // column tile lies inside one destination; otherwise the field is dropped and PG_INFO_BSUMS stays clear
-        bool bs_any = false, bs_ok = d->epilogue == 1 && k.dst_io == 1 && k.n_cnt % bn == 0;
+        if (merged) k = kmerged;
+        bool bs_any = false, bs_ok = d->epilogue == 1 && k.dst_io == 1 && k.n_cnt % bn_l == 0;
         if (d->epilogue == 1)
           for (int j = 0; j < d->ndst; ++j) {
             if (d->dst[j].bsums == nullptr) continue;
             bs_any = true;       // its column range must be tile-aligned: no workgroup mixes it with another destination
-            if (k.dstart[j] % bn != 0 || d->dst[j].C % bn != 0 || d->dst[j].fwd == nullptr) bs_ok = false;
+            if (k.dstart[j] % bn_l != 0 || k.dst[j].C % bn_l != 0 || d->dst[j].fwd == nullptr) bs_ok = false;
           }
         if (!(bs_any && bs_ok))
           for (int j = 0; j < PG_MAX_SRC; ++j) k.dst[j].bsums = nullptr;
-        if (pair) launch_conv_bf16_pair(k, bn, dim3(mtb, ntb, k.nphase), st);
+        if (merged) launch_conv_bf16_pair(k, 1000 + bn_l, dim3(mtb, 1, 2), st);
+        else if (pair) launch_conv_bf16_pair(k, bn, dim3(mtb, ntb, k.nphase), st);
         else launch_conv_bf16_big(k, code, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
-        last_info() = (pair ? (bn == 256 ? 8 : (bn == 128 ? 9 : 10)) : (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6)))) |
+        last_info() = (merged ? (bn_l == 256 ? 11 : 12) : pair ? (bn == 256 ? 8 : (bn == 128 ? 9 : 10)) : (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6)))) |
                       (amode << 4) | (bmode << 8) | (1 << 16) | ((bs_any && bs_ok) ? PG_INFO_BSUMS : 0);
         return 0;
       }

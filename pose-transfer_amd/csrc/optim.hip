@@ -221,32 +221,14 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
 // norm_finalize_kernel's arithmetic, evaluated by every workgroup for its own sample (32 doubles) — the separate 5 us launch per
 // norm layer goes away; the first workgroup of a sample publishes (mean, rstd) and (a, b) for the later readers (data-gradient
 // epilogues, warp kernels, norm backward: all in later launches).
-struct NormFold {
-  const double* sums;       // [N][PG_STAT_SLOTS][2] or null
-  const float* gamma; const float* beta;
-  long L; float eps;
-  float* mr; float* aff;
-};
+// (struct NormFold: common.h)
 
 template <bool IN_BF16>
 __global__ __launch_bounds__(256) void materialise_bf16_kernel(const void* x, const float* aff, const float* mask, int act,
                                                                long HW, int C, uint4* out, uint4* out2, int act2, NormFold nf) {
   const int n = blockIdx.y;
   float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
-  if (nf.sums != nullptr) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < PG_STAT_SLOTS; ++k) { s1 += nf.sums[((long)n * PG_STAT_SLOTS + k) * 2]; s2 += nf.sums[((long)n * PG_STAT_SLOTS + k) * 2 + 1]; }
-    const double mean = s1 / (double)nf.L;
-    double var = s2 / (double)nf.L - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)nf.eps);
-    const double g = (double)nf.gamma[0], bt = (double)nf.beta[0];
-    a = (float)(g * rstd); b = (float)(bt - g * mean * rstd);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      nf.mr[2 * n] = (float)mean; nf.mr[2 * n + 1] = (float)rstd;
-      nf.aff[2 * n] = a; nf.aff[2 * n + 1] = b;
-    }
-  }
+  if (nf.sums != nullptr) norm_fold_affine(nf, n, blockIdx.x == 0 && threadIdx.x == 0, a, b);
   const float slope = act_slope(act), slope2 = act_slope(act2);
   const long per = HW * C / 8;                       // 8 elements (one 16-byte bf16 chunk) per thread-iteration
   uint4* ob = out + (long)n * per;

@@ -28,7 +28,7 @@ class KernelProfiler:
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
     CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32", 4: "256x256", 5: "256x128", 6: "512x64", 7: "512x128", 8: "256x256p", 9: "256x128p",
-                  10: "512x64p"}
+                  10: "512x64p", 11: "256x256m", 12: "256x128m"}
     WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin", 6: "bf16-tr-256", 7: "bf16-stem"}
 
     def __init__(self):
@@ -359,6 +359,7 @@ def _bf16_weight(W, taps, Cout, Cin, transposed):
     return ent[2 + idx]
 
 
+OUT_FWD_FUSED = os.environ.get("PG_NO_OUT_FWD_FUSED") is None     # ablation switch: the output convolution's forward as materialise + contraction + tap gather
 WARP_BBOX = os.environ.get("PG_NO_WARP_BBOX") is None    # ablation switch: warp backward without the mask bounding boxes
 BATCH_WT = os.environ.get("PG_NO_BATCH_WT") is None      # ablation switch: one pg_weights_to_bf16 launch per layer and step
 _BF_W_EXT = {}              # (data_ptr, numel, transposed) -> (weakref to the weight tensor, its bf16 buffer)
@@ -1477,6 +1478,8 @@ class GeneratorEngine:
         cin = sum(a.C for _, _, a in srcs)
         # 256->3 output conv (networks.py:228) re-associated: 1x1 conv to 27 = 9 taps x 3 channels, then tap gather
         # + bias + tanh (csrc/edge.hip) — a 3-wide GEMM-N would leave 29/32 of every MFMA tile empty
+        if bfs and self._out_conv_fused(srcs, cin, i):
+            return self.out
         if bfs:
             # bf16 STORAGE: the three sources are bf16 operands already (normalised block output, relu'd warp, the stem's
             # ReLU copy); the 27 tap columns are padded to the 64-column tile of the bf16 kernels
@@ -1491,6 +1494,34 @@ class GeneratorEngine:
         L.call("pg_tap_gather", L.ptr(self.y_taps), N, H, W, 3, 3, 1, 3, L.ptr(A.p("decoder.net.%d.bias" % (i + 1))),
                L.OUT_TANH, L.ptr(self.out), 3 * H * W, H * W, W, 1, L.stream())
         return self.out
+
+    def _out_conv_fused(self, srcs, cin, i):
+        """(round 5) the output convolution's forward as ONE streaming pass (csrc/out_conv_fwd.hip): the last block's raw bf16
+        output is normalised + ReLU'd in registers (its activated operand is still written: the backward pass reads it), the other
+        sources are the bf16 operands their producers wrote, the 27 tap columns never touch HBM.  False: not eligible, the caller
+        runs the materialise / contraction / tap-gather chain."""
+        A, N, H, W = self.A, self.N, self.H, self.W
+        (k0, _, a0), rest = srcs[0], srcs[1:]
+        if (not OUT_FWD_FUSED or k0 != "dec" or a0.mask is not None or not _is_bf16_ptr(L.ptr(a0.t)) or len(rest) > 2
+                or tuple(a.C for _, _, a in srcs) not in ((128, 64, 64), (128, 64), (64, 64))
+                or _BF_CTX.lookup(L.ptr(a0.t), a0.C, L.ACT_RELU, L.ptr(a0.aff), None) is not None):
+            return False
+        dev = a0.t.device
+        ops = [_BF_CTX.get(L.ptr(a.t) if a.base_ptr is None else a.base_ptr, a.C, L.ACT_RELU, L.ptr(a.aff), L.ptr(a.mask), N, H * W, dev)
+               for _, _, a in rest]
+        op0 = _BF_CTX.reserve(L.ptr(a0.t), a0.C, L.ACT_RELU, L.ptr(a0.aff), None, N * H * W * a0.C, dev)
+        pend = _PENDING_NORM.pop(int(L.ptr(a0.aff) or 0), None) if (_PENDING_NORM and a0.aff is not None) else None
+        if pend is not None:
+            st, gamma, beta, _n, Lr = pend
+            fold = (None, L.ptr(st.sums), L.ptr(gamma), L.ptr(beta), Lr, NORM_EPS, L.ptr(st.mr), L.ptr(st.aff))
+        else:
+            fold = (L.ptr(a0.aff), None, None, None, 0, NORM_EPS, None, None)
+        x1, c1 = (L.ptr(ops[0]), rest[0][2].C) if len(rest) > 0 else (None, 0)
+        x2, c2 = (L.ptr(ops[1]), rest[1][2].C) if len(rest) > 1 else (None, 0)
+        L.call("pg_out_conv_fwd_fused", L.ptr(a0.t), a0.C, *fold, L.ptr(op0), x1, c1, x2, c2,
+               L.ptr(A.p("decoder.net.%d.weight" % (i + 1))), L.ptr(A.p("decoder.net.%d.bias" % (i + 1))), N, H, W, L.OUT_TANH,
+               L.ptr(self.out), L.stream())
+        return True
 
     # -------------------------------------------------------------------------------- backward
     def _dsts_for(self, srcs, first_write):

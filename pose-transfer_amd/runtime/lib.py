@@ -149,6 +149,7 @@ _PROTOS = {
     "pg_stem_wgrad_bf16_ex": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
     "pg_stem_wgrad_bf16_v2": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp],
     "pg_bias_grad_bf16": [_vp, _i64, _i32, _vp, _vp],
+    "pg_out_conv_fwd_fused": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_tap_gather_pitch": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
     "pg_im2col_taps_bf16": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "pg_out_conv_wgrad_bf16": [_vp, _i32, _i32, _i32, _i32, C.POINTER(Dst), _i32, _vp, _vp, _i64, _vp],

@@ -351,3 +351,168 @@ def test_reducer_stream_order_one_bucket_per_layer(tmp_path, prec_env):
     broken = _run_dp_child(1, tmp_path, dict(base, PG_DP_DEBUG_NO_WAIT="1"))
     worst = max(float((broken[k] - ref[k]).abs().max()) / float(ref[k].abs().max()) for k in ("gen_grads", "disc_grads"))
     assert worst > 1e-2, "negative control: reducing without producer events went unnoticed (%.2e)" % worst
+
+
+# ------------------------------------------------------------------------------------------ output convolution forward, one pass
+@pytest.mark.parametrize("chans,fold", [((128, 64, 64), False), ((128, 64, 64), True), ((128, 64, 0), False), ((64, 64, 0), True)])
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 16, 32), (3, 19, 33)])
+def test_out_conv_fwd_fused_kernel(chans, fold, shape):
+    """pg_out_conv_fwd_fused (csrc/out_conv_fwd.hip; reference models/networks.py:228 ReLU -> Conv2d(cin, 3, k3, p1) -> Tanh):
+    the activated operand it stores equals pg_materialise_bf16_ex's bit for bit, out = tanh(bias + conv) of the bf16 operands and
+    bf16-rounded weights accumulated in fp32 (torch-CPU double reference), the folded finalize publishes the same affine; ragged
+    tiles (16 x 32 pixel tiles), one / two / three sources."""
+    import torch.nn.functional as F
+    N, H, W = shape
+    C0, C1, C2 = chans
+    cin = C0 + C1 + C2
+    g = lambda tag, sh: t(synth.normal(611, "ocf/%s/%s" % (tag, str(shape) + str(chans)), sh))
+    x0 = g("x0", (N, H, W, C0)).to(DEV).bfloat16()
+    x1 = F.relu(g("x1", (N, H, W, C1))).to(DEV).bfloat16()
+    x2 = F.relu(g("x2", (N, H, W, max(C2, 1)))).to(DEV).bfloat16() if C2 else None
+    Wf = (0.05 * g("w", (27, cin))).to(DEV)
+    bias = (0.1 * g("b", (3,))).to(DEV)
+    Lr = H * W * C0
+    gamma, beta = torch.tensor([1.3], device=DEV), torch.tensor([-0.2], device=DEV)
+    mean = torch.tensor([0.1 * (n + 1) for n in range(N)], dtype=torch.float64)
+    var = torch.tensor([0.5 + 0.25 * n for n in range(N)], dtype=torch.float64)
+    sums = torch.zeros(N, L.STAT_SLOTS, 2, dtype=torch.float64)
+    sums[:, 3, 0] = mean * Lr
+    sums[:, 3, 1] = (var + mean * mean) * Lr
+    sums = sums.to(DEV)
+    rstd = 1.0 / torch.sqrt(var + E.NORM_EPS)
+    aff_ref = torch.stack([1.3 * rstd, -0.2 - 1.3 * mean * rstd], 1).float().to(DEV)
+    # the unfused chain's operand: pg_materialise_bf16_ex with the same affine
+    op_ref = torch.empty(N * H * W * C0, dtype=torch.bfloat16, device=DEV)
+    L.call("pg_materialise_bf16_ex", L.ptr(x0), 1, L.ptr(aff_ref), None, L.ACT_RELU, N, H * W, C0, L.ptr(op_ref), None, 0, L.stream())
+    op0 = torch.full((N * H * W * C0,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out = torch.full((N, 3, H, W), float("nan"), device=DEV)
+    mr, aff_out = torch.zeros(N, 2, device=DEV), torch.zeros(N, 2, device=DEV)
+    fold_args = ((None, L.ptr(sums), L.ptr(gamma), L.ptr(beta), Lr, E.NORM_EPS, L.ptr(mr), L.ptr(aff_out)) if fold
+                 else (L.ptr(aff_ref), None, None, None, 0, E.NORM_EPS, None, None))
+    L.call("pg_out_conv_fwd_fused", L.ptr(x0), C0, *fold_args, L.ptr(op0), L.ptr(x1), C1, L.ptr(x2) if C2 else None, C2, L.ptr(Wf),
+           L.ptr(bias), N, H, W, L.OUT_TANH, L.ptr(out), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(op0.float(), op_ref.float())          # (value-equal: the materialise pass writes -0 where this one writes +0)
+    if fold:
+        assert maxdiff(aff_out, aff_ref) < 1e-6 and maxdiff(mr[:, 0], mean.float()) < 1e-6 and maxdiff(mr[:, 1], rstd.float()) < 1e-5
+    ops = [op_ref.view(N, H, W, C0), x1] + ([x2] if C2 else [])
+    xcat = torch.cat([o.float().cpu().double() for o in ops], 3).permute(0, 3, 1, 2)
+    w4 = Wf.bfloat16().float().cpu().double().view(3, 3, 3, cin).permute(2, 3, 0, 1)       # [tap r][tap s][co][ci] -> (co, ci, r, s)
+    ref = torch.tanh(F.conv2d(xcat, w4, bias.cpu().double(), padding=1))
+    assert maxdiff(out, ref) < 2e-5, maxdiff(out, ref)
+
+
+def test_out_conv_fwd_fused_in_the_engine(monkeypatch, deterministic):
+    """the generator with the one-pass output convolution against the materialise + contraction + tap-gather chain it replaces
+    (PG_NO_OUT_FWD_FUSED): out_gen within fp32 summation order; the backward pass from a fixed output gradient reads the same
+    stored operand bit for bit, so in deterministic mode every gradient is BIT-equal."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    size, n = (128, 128), 2
+    inp, tgt, wr, mk = dev(*[t(a) for a in synth.batch(509, "ocf", n, P, *size)])
+    drops = dev(*[t(m) for m in synth.dropout_masks(509, "ocf", n)])
+    gout = t(synth.normal(509, "ocf/g", (n, 3, *size))).to(DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, "OUT_FWD_FUSED", fused)
+        model = DeformablePose_GAN(_opt(size, n), device=DEV, init_seed=11)
+        eng = model.gen.engine(n)
+        assert eng.bfs
+        eng.set_dropout(drops)
+        names = []
+
+        def hook(name, a, launch):
+            names.append(name)
+            return launch()
+
+        model.gen.zero_grad()
+        monkeypatch.setattr(L, "CALL_HOOK", hook)
+        out = eng.forward(inp, wr, mk).clone()
+        monkeypatch.setattr(L, "CALL_HOOK", None)
+        eng.backward(gout)
+        torch.cuda.synchronize()
+        res[fused] = (out, {k: v.clone() for k, v in model.gen.arena.grad_dict().items()}, names)
+    assert "pg_out_conv_fwd_fused" in res[True][2] and "pg_tap_gather_pitch" not in res[True][2]
+    assert "pg_out_conv_fwd_fused" not in res[False][2] and "pg_tap_gather_pitch" in res[False][2]
+    assert maxdiff(res[True][0], res[False][0]) < 2e-5
+    for k, g0 in res[False][1].items():
+        assert torch.equal(res[True][1][k], g0), k
+
+
+# ------------------------------------------------------------------------------------------ x-phase merged transposed convolutions
+def _bf(tag, shape, scale=1.0):
+    x = (scale * t(synth.normal(613, "mg/" + tag, shape))).to(DEV).bfloat16().contiguous()
+    return E._reg_bf16(x)
+
+
+def _merged_vs_base(got, base, base_code):
+    """base_code 9 / 10: the tap-pair kernel (same K order: BIT-equal); 6: the 512 x 64 kernel without pairing (the 64-column launch
+    pairs only on grids >= 80 wide: (tap, chunk) order — equal up to fp32 summation order, i.e. one bf16 ulp of the stored value)"""
+    g, b = got.float(), base.float()
+    assert bool(torch.isfinite(g).all())
+    if base_code != 6:
+        assert torch.equal(g, b)
+    else:
+        assert float((g - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("cout,cins", [(128, (128, 64, 64)), (64, (128,)), (128, (64,))])
+@pytest.mark.parametrize("geom", [(2, 12, 48), (1, 9, 64), (3, 20, 43)])
+def test_x_phase_merged_forward(cout, cins, geom, monkeypatch):
+    """csrc/igemm_bf16_pair.hip, MG (round 5): the transposed k4 s2 convolution with 128 / 64 output channels as ONE 256 x 2 Cout
+    tile per phase PAIR (py, 0) + (py, 1) (reference models/networks.py:156 ConvTranspose2d + crop, the last decoder block).
+    The K loop visits (tap pair, channel chunk, tap) in the order of the tap-pair kernel it is derived from, so the stored tensor
+    is BIT-equal to that kernel's (itself checked against torch in test_conv_bf16_big_kernel[pair]); the fused statistics agree to
+    double rounding; partial last M tiles, tiles across image rows and samples, one and three sources."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    monkeypatch.setenv("PG_BIG_PAIR", "1")
+    N, H, W = geom
+    cin = sum(cins)
+    xs = [_bf("x%d/%s%s" % (j, geom, cins), (N, H, W, c)) for j, c in enumerate(cins)]
+    wp = (0.05 * t(synth.normal(613, "mg/w/%s%s%d" % (geom, cins, cout), (4, 4, cout, cin)))).to(DEV).contiguous()
+    res = {}
+    for mg in ("1", "0"):
+        monkeypatch.setenv("PG_BIG_MERGE", mg)
+        out = E._reg_bf16(torch.full((N, 2 * H, 2 * W, cout), float("nan"), dtype=torch.bfloat16, device=DEV))
+        stats = torch.zeros(N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
+        info = E._conv([E.Act(x, c).src() for x, c in zip(xs, cins)], N, H, W, L.ACT_NONE, 1, 4, 2, 1, 2 * H, 2 * W, wp, cout, cin,
+                       out=out, stats=stats, ksplit=1)
+        torch.cuda.synchronize()
+        res[mg] = (out, stats.sum(1).cpu(), info & 0xF)
+    assert res["1"][2] == (11 if cout == 128 else 12) and res["0"][2] in (6, 9, 10), (res["1"][2], res["0"][2])
+    _merged_vs_base(res["1"][0], res["0"][0], res["0"][2])
+    assert float(((res["1"][1] - res["0"][1]).abs() / res["0"][1].abs().clamp_min(1e-9)).max()) < (1e-5 if res["0"][2] != 6 else 1e-3)      # (fp32 wave partials over differently shaped tiles, then double)
+
+
+@pytest.mark.parametrize("cin,accumulate,sums", [(128, False, True), (128, True, False), (64, False, True), (64, True, False)])
+@pytest.mark.parametrize("geom", [(2, 12, 48), (3, 10, 43)])
+def test_x_phase_merged_data_gradient(cin, accumulate, sums, geom, monkeypatch):
+    """the same for the data gradient of a Conv2d(k4, s2, p1) with 128 / 64 INPUT channels (encoder levels 2 / 1; reference
+    models/networks.py:154, autograd of conv2d wrt its input): transposed geometry, bf16 gradient and forward tensors, LeakyReLU
+    derivative from the raw forward value + per-sample affine, fresh and accumulating destinations, the fused norm-backward sums.
+    BIT-equal gradients against the tap-pair kernel; sums to double rounding."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    monkeypatch.setenv("PG_BIG_PAIR", "1")
+    N, Hs, Ws = geom                      # the gradient arrives on the small grid, the destination is 2 Hs x 2 Ws
+    cout = 256
+    tag = "%s/%d" % (geom, cin)
+    gy = _bf("gy/" + tag, (N, Hs, Ws, cout))
+    fwd = _bf("fwd/" + tag, (N, 2 * Hs, 2 * Ws, cin))
+    aff = torch.stack([t(synth.uniform(613, "mg/a/" + tag, (N,), 0.5, 1.5)), t(synth.uniform(613, "mg/b/" + tag, (N,), -0.5, 0.5))], 1).float().to(DEV)
+    wp = (0.05 * t(synth.normal(613, "mg/wd/" + tag, (4, 4, cout, cin)))).to(DEV).contiguous()
+    prev = _bf("prev/" + tag, (N, 2 * Hs, 2 * Ws, cin), 0.3)
+    res = {}
+    for mg in ("1", "0"):
+        monkeypatch.setenv("PG_BIG_MERGE", mg)
+        grad = E._reg_bf16(prev.clone() if accumulate else torch.full_like(prev, float("nan")))
+        bs = torch.zeros(N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV) if sums else None
+        dst = L.make_dst(grad, cin, fwd=fwd, aff=aff, act=L.ACT_LEAKY, accumulate=accumulate, bsums=bs)
+        info = E._conv_dgrad(E.Act(gy, cout).src(), N, Hs, Ws, 1, 4, 2, 1, 2 * Hs, 2 * Ws, wp, cout, cin, [dst], ksplit=1)
+        torch.cuda.synchronize()
+        res[mg] = (grad, bs.sum(1).cpu() if sums else None, info & 0xF, bool(info & L.INFO_BSUMS))
+    assert res["1"][2] == (11 if cin == 128 else 12) and res["0"][2] in (6, 9, 10), (res["1"][2], res["0"][2])
+    _merged_vs_base(res["1"][0], res["0"][0], res["0"][2])
+    if sums:
+        assert res["1"][3] and res["0"][3]
+        assert float(((res["1"][1] - res["0"][1]).abs() / res["0"][1].abs().clamp_min(1e-9)).max()) < (1e-5 if res["0"][2] != 6 else 1e-3)      # (fp32 wave partials over differently shaped tiles, then double)
