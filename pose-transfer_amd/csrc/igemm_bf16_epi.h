@@ -464,14 +464,19 @@ __device__ __forceinline__ void big_scatter_tile8(const f32x16 (&acc)[TM_][TN_],
 // The whole epilogue of a 256-row kernel: partial tiles (split-K workspace), forward store (+ fused statistics), data-gradient
 // scatter (+ fused norm-backward sums).  sel_ok: rows outside the problem may hold non-zero accumulators (tap-pair kernel: their A
 // rows are shared with a neighbour) — the statistics then select on the row flag as they do with a bias.
-template <int TM, int TN, int STAT_OFF, int STAT_N, typename Stamp>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// Tw (round 5, persistent tap-pair kernel): this wave's transposition tile when it is not the default slot at the start of the
+// operand rings; after_sync: called by every thread right behind the barrier that ends the K loop (the rings are free: the
+// persistent kernel issues the next tile's prologue there).
+template <int TM, int TN, int STAT_OFF, int STAT_N, typename Stamp, typename Hook = NoHook>
 __device__ __forceinline__ void big_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], char* smem, const RowB* rows, int tid, int m0, int nb0,
                                              int wm0, int wn0, int bx, int by, int bz, int split, float* out_g, bool sel_ok, bool tl_on,
-                                             Stamp&& stamp) {
+                                             Stamp&& stamp, float* Tw = nullptr, Hook&& after_sync = Hook()) {
   const int lane = tid & 63, wave = tid >> 6;
   __syncthreads();
   stamp(3);
-  float* const T = reinterpret_cast<float*>(smem) + wave * (32 * (32 * TN + 4));
+  after_sync();
+  float* const T = Tw != nullptr ? Tw : reinterpret_cast<float*>(smem) + wave * (32 * (32 * TN + 4));
   const int ngc = nb0 + wn0 + (lane % (8 * TN)) * 4;            // first of this lane's 4 columns
   if (p.part != nullptr) {                                      // split-K through the workspace: plain partial tiles
     float* pp = p.part + (long)split * p.part_stride;
