@@ -477,7 +477,7 @@ def pmc_traffic(kernel):
     made by tools/pmc_bench.sh on the default workload — counters cannot be collected from inside this process):
     2*FETCH_SIZE + WRITE_SIZE, in bytes (MI355X_MICROARCH.md: FETCH_SIZE reads half of a wide coalesced stream on
     gfx950).  (None, None) when no PMC summary is available."""
-    for name in ("round4_pmc.json", "round3_pmc.json", "round2_pmc.json", "round1_pmc.json"):
+    for name in ("round5_pmc.json", "round4_pmc.json", "round3_pmc.json", "round2_pmc.json", "round1_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             k = d["kernels"].get(kernel)
@@ -488,27 +488,31 @@ def pmc_traffic(kernel):
     return None, None
 
 
-# family name of the launch table -> kernel symbol in profiles/round4_pmc_northstar.json (bf16 data path; that pass profiled the
+# family name of the launch table -> kernel symbol in profiles/round*_pmc_northstar.json (bf16 data path; that pass profiled the
 # generator's forward + backward at 256 x 256, batch 32 — the launches of these families in a batch-32 training step are the same)
 BF16_PMC_NAMES = {
-    "conv_igemm<256x256p,A0,B0>": "void pg::conv_bf16_pair_kernel<256>(pg::ConvK)",
-    "conv_igemm<256x128p,A0,B0>": "void pg::conv_bf16_pair_kernel<128>(pg::ConvK)",
-    "conv_igemm<512x64p,A0,B0>": "void pg::conv_bf16_pair_kernel<64>(pg::ConvK)",
+    "conv_igemm<256x256p,A0,B0>": "void pg::conv_bf16_pair_kernel<256, false>(pg::ConvK)",
+    "conv_igemm<256x128p,A0,B0>": "void pg::conv_bf16_pair_kernel<128, false>(pg::ConvK)",
+    "conv_igemm<512x64p,A0,B0>": "void pg::conv_bf16_pair_kernel<64, false>(pg::ConvK)",
+    "conv_igemm<256x256m,A0,B0>": "void pg::conv_bf16_pair_kernel<256, true>(pg::ConvK)",
+    "conv_igemm<256x128m,A0,B0>": "void pg::conv_bf16_pair_kernel<128, true>(pg::ConvK)",
     "conv_igemm<256x256,A0,B0>": "void pg::conv_bf16_big_kernel<256, 64>(pg::ConvK)",
 }
+BF16_PMC_NAMES_R4 = {k: v.replace(", false>", ">") for k, v in BF16_PMC_NAMES.items()}      # (round 4: one template parameter)
 
 
 def pmc_traffic_bf16(kernel, args):
     if not (args.batch == 32 and args.size == 256):
         return None, None
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "round4_pmc_northstar.json")))["kernels"]
-        k = d.get(BF16_PMC_NAMES.get(kernel, ""))
-        if k is not None:
-            return int((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), \
-                "profiles/round4_pmc_northstar.json (generator forward + backward, batch 32)"
-    except Exception:
-        pass
+    for name, names in (("round5_pmc_northstar.json", BF16_PMC_NAMES), ("round4_pmc_northstar.json", BF16_PMC_NAMES_R4)):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            k = d.get(names.get(kernel, ""))
+            if k is not None:
+                return int((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), \
+                    "profiles/%s (generator forward + backward, batch 32)" % name
+        except Exception:
+            continue
     return None, None
 
 
