@@ -435,8 +435,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
   RowB* rows = reinterpret_cast<RowB*>(smem + ROWS_OFF);
   const unsigned lds0 = (unsigned)(size_t)smem;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: wm0 / wn0 / the DMA slots / Tw live in SGPRs)
+  // Everything derived from the thread index is RE-derived per tile from an opaque zero (tile_begin): the compiler would otherwise
+  // keep ~20 loop-invariant lane constants alive across the tile loop, and at 256 VGPRs they end up in scratch — reloaded in the K
+  // loop's rare paths, where a scratch load's vmcnt wait also drains the operand DMA queue (first version: 17.05 -> 19.8 ms).
+  int tid = threadIdx.x;
+  int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int total = mt * nt * P, G = (int)gridDim.x;
   int L = (int)blockIdx.x;
   if (L >= total) return;
@@ -511,14 +514,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
     }
   };
 
-  const int wm0 = (wave / WGN) * (TM * 32);
-  const int wn0 = (wave % WGN) * (TN * 32);
-  const int l31 = lane & 31, lhi = lane >> 5;
+  int wm0 = (wave / WGN) * (TM * 32);
+  int wn0 = (wave % WGN) * (TN * 32);
+  int l31 = lane & 31, lhi = lane >> 5;
 
   // ---- DMA loader state (as conv_bf16_pair_kernel; the tile it works on is `lt`, its tables are in buffer `lbuf`)
-  const char* const zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
-  const char* const wp = uniform_ptr(reinterpret_cast<const char*>(p.W));
-  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const char* zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros));
+  const char* wp = uniform_ptr(reinterpret_cast<const char*>(p.W));
+  int chunk = (tid & 7) ^ ((tid >> 4) & 7);
   unsigned pa[A_PASS], pb[B_PASS];
   unsigned pa_ok = 0, pb_ok = 0;
   const char* a_src = zero_pg;
@@ -627,8 +630,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
   };
 
   constexpr bool BIGA = A_ST > 60000;
-  const int swr = (l31 >> 1) & 7;
-  const unsigned fb0 = lds0 + B_OFF + (unsigned)((wn0 + l31) * ROWB) + (unsigned)((lhi ^ swr) * 16);
+  int swr = (l31 >> 1) & 7;
+  unsigned fb0 = lds0 + B_OFF + (unsigned)((wn0 + l31) * ROWB) + (unsigned)((lhi ^ swr) * 16);
   unsigned abase[BIGA ? 2 : 1][2][TM];
   auto fetch = [&](auto asg, auto jt, auto bsg, auto ksc, f32x4 (&va)[TM], f32x4 (&vb)[TN]) __attribute__((always_inline)) {
     constexpr int AS = decltype(asg)::value, JT = decltype(jt)::value, BSG = decltype(bsg)::value, KS = decltype(ksc)::value;
@@ -665,10 +668,25 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
   typedef std::integral_constant<int, 3> I3;
 
   // this wave's transposition tile in the epilogue
-  float* const Tw = reinterpret_cast<float*>(smem + (!PF ? wave * TSZ
-                                                          : (wave < T_NA ? A_ST + wave * TSZ
-                                                                         : (wave < T_NA + T_NB ? B_OFF + B_ST + (wave - T_NA) * TSZ
-                                                                                               : TFREE_OFF + (wave - T_NA - T_NB) * TSZ))));
+  float* Tw = nullptr;
+  auto tile_begin = [&]() __attribute__((always_inline)) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    tid = (int)threadIdx.x + z;
+    lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    wm0 = (wave / WGN) * (TM * 32); wn0 = (wave % WGN) * (TN * 32);
+    l31 = lane & 31; lhi = lane >> 5;
+    chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    swr = (l31 >> 1) & 7;
+    fb0 = lds0 + B_OFF + (unsigned)((wn0 + l31) * ROWB) + (unsigned)((lhi ^ swr) * 16);
+    zero_pg = uniform_ptr(reinterpret_cast<const char*>(kZeros) + z);
+    wp = uniform_ptr(reinterpret_cast<const char*>(p.W) + z);
+    Tw = reinterpret_cast<float*>(smem + (!PF ? wave * TSZ
+                                              : (wave < T_NA ? A_ST + wave * TSZ
+                                                             : (wave < T_NA + T_NB ? B_OFF + B_ST + (wave - T_NA) * TSZ
+                                                                                   : TFREE_OFF + (wave - T_NA - T_NB) * TSZ))));
+  };
+  tile_begin();
 
   Tile cur = decode(L);
   int buf = 0;
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
       }
     }
     // the tile's first A / B tiles are in flight (issued by the prologue — for every tile but the first: under the previous epilogue)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     issue_b(1, 1);
@@ -766,18 +784,19 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
                                            [](int) {}, Tw, [&]() __attribute__((always_inline)) {
                                              if (PF && has_next) {
                                                build_dma_tables(nxt, buf ^ 1);
-                                               __syncthreads();
+                                               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);      // (LDS tables only: __syncthreads would wait for vmcnt(0) too)
                                                start_loader(nxt, buf ^ 1, true);
                                              }
                                            });
     if (!has_next) break;
-    __syncthreads();                       // every wave is done with rows[] and the statistics table
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);      // every wave is done with rows[] and the statistics table (no vmcnt wait: the epilogue's stores stay in flight)
+    tile_begin();
     L = Ln; cur = nxt;
     if (PF) {
       buf ^= 1;
       build_rows(cur);
       start_loader(cur, buf, false);       // the loader state the issued prologue left (its registers did not survive the epilogue)
-      __syncthreads();                     // (rows[] / statistics table visible; the K loop's first barrier follows anyway)
+      // (rows[] / statistics table: the K loop's first barrier, with its lgkmcnt(0), follows)
     } else {
       build_dma_tables(cur, 0);
       build_rows(cur);
@@ -787,15 +806,23 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
   }
 }
 
-void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
-  // (round 5) PG_PAIR_PERSIST=1: the persistent walk with the next tile's prologue under the epilogue (conv_bf16_pairp_kernel).
-  // Correct (tests/test_gpu_round5.py runs the tap-pair cases through it) and OFF: measured on one box, north-star pass 17.05 ->
-  // 19.79 ms, every launch slower (enc.2 forward 149 -> 200 us, dec.5 data gradient 1256 -> 1920 us).  The one-tile kernel sits at
-  // exactly 256 VGPRs; the values that now live across the tile loop push loop-invariant lane constants into scratch, the rare
-  // paths of the K loop (rebuild_a / rebuild_b at a tap or source change) reload them, and a scratch load's s_waitcnt vmcnt(0) also
-  // waits for every global->LDS DMA in flight (one in-order counter) — the K tile's prefetch distance is gone at each rebuild
-  // (every 2 - 8 steps).  Kept as the starting point for a version whose loader state lives in LDS.
-  static const bool persist = getenv("PG_PAIR_PERSIST") && getenv("PG_PAIR_PERSIST")[0] == '1';
+void launch_conv_bf16_pair(const ConvK& k_in, int bn, dim3 grid, hipStream_t st) {
+  // (round 5) the persistent walk with the next tile's prologue under the epilogue (conv_bf16_pairp_kernel): correct (the tap-pair
+  // and merged test cases pass through it with PG_PAIR_PERSIST=31) and OFF — slower in every variant on every layer measured
+  // (tools/layer_bench.py, batch 32, one box; one tile per workgroup -> persistent):
+  //   first version: lane constants alive across the tile loop spilled to scratch and were reloaded in the K loop's rare paths
+  //   (rebuild_a / rebuild_b), where a scratch load's vmcnt wait also drains the operand DMA queue: north-star 17.05 -> 19.8 ms;
+  //   second version (constants re-derived per tile from an opaque zero: no scratch in any K loop, none at all in the 128-wide
+  //   variants; raw barriers so that no wait covers the epilogue's stores): forward launches + 3 ... 7 % (enc.1 218 -> 229 us, dec.5
+  //   1027 -> 1083), data gradients + 11 ... 45 % (enc.1 287 -> 318, enc.2 182 -> 265, dec.4 985 -> 1134, dec.5 1106 -> 1405 us),
+  //   north-star 17.0 -> 17.3 (128-wide variants only) ... 18.1 ms (all).  The 3.3 - 4.5 us prologue it hides are paid back by the
+  //   second loader rebuild, three more barriers per tile and — in the 256-wide variants — by the scatter epilogue: with the next
+  //   tile's state alive its register budget overflows, and every compiler-inserted scratch reload carries a vmcnt(0) that breaks the
+  //   epilogue's counted waits (loads of the next half in flight behind the stores of this one).
+  // PG_PAIR_PERSIST = bit mask of the variants that take the persistent form: 1 <128>, 2 <128, merged>, 4 <256>, 8 <256, merged>, 16 <64>
+  static const int persist_mask = getenv("PG_PAIR_PERSIST") ? atoi(getenv("PG_PAIR_PERSIST")) : 0;
+  const int vbit = bn == 1256 ? 8 : (bn == 1128 ? 2 : (bn == 256 ? 4 : (bn == 64 ? 16 : 1)));
+  const bool persist = (persist_mask & vbit) != 0;
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0;
@@ -805,6 +832,7 @@ void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
     if (getenv("PG_PAIR_PERSIST_WGS")) ncu = atoi(getenv("PG_PAIR_PERSIST_WGS"));
   }
   if (persist) {
+    const ConvK& k = k_in;
     const int mt = (int)grid.x, nt = (int)grid.y, P = (int)grid.z;
     const long total = (long)mt * nt * P;
     const dim3 g((unsigned)(total < ncu ? total : ncu));
@@ -815,6 +843,7 @@ void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st) {
     else PG_KLAUNCH((conv_bf16_pairp_kernel<128>), g, dim3(512), 0, st, k, mt, nt, P);
     return;
   }
+  const ConvK& k = k_in;
   if (bn == 1256) PG_KLAUNCH((conv_bf16_pair_kernel<256, true>), grid, dim3(512), 0, st, k);       // x-phase merged: 256 x (2 x 128)
   else if (bn == 1128) PG_KLAUNCH((conv_bf16_pair_kernel<128, true>), grid, dim3(512), 0, st, k);  // 256 x (2 x 64)
   else if (bn == 256) PG_KLAUNCH((conv_bf16_pair_kernel<256>), grid, dim3(512), 0, st, k);
