@@ -53,11 +53,11 @@ prof() {  # tag, command...
   if [ -n "$TL" ]; then python tools/timeline_r4.py $(ls $O/prof_$tag/*results.db | head -1) $O/round4_timeline_$tag.txt $TL > /dev/null 2>&1 || true; fi
   rm -rf $O/prof_$tag
 }
-TL=7 prof default_f32 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-north-star --no-kernel-profile
+TL=7 prof default_f32 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-north-star --no-config-legs --no-kernel-profile
 TL=10 prof northstar_bf16 env PG_ONLY_BF16=1 PG_NS_ITERS=7 python tools/gen_fwd_bwd_bench.py 32
 TL=10 prof northstar_bf16_single_stream env PG_ONLY_BF16=1 PG_NO_SIDE_STREAM=1 PG_NS_ITERS=7 python tools/gen_fwd_bwd_bench.py 32
-TL=7 prof cfg1_b4_bf16 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-north-star --no-kernel-profile --precision bf16_data
-TL= prof cfg2_224_p32_bf16 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-north-star --no-kernel-profile --size 224 --pose_dim 32 --batch 8 --precision bf16_data
+TL=7 prof cfg1_b4_bf16 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-north-star --no-config-legs --no-kernel-profile --precision bf16_data
+TL= prof cfg2_224_p32_bf16 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-north-star --no-config-legs --no-kernel-profile --size 224 --pose_dim 32 --batch 8 --precision bf16_data
 # PMC passes
 bash tools/pmc_bench.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_bench.json $O/round4_pmc.json 2>/dev/null
 bash tools/pmc_northstar.sh > $O/pmc_ns.log 2>&1; cp gpurun_out/pmc_northstar.json $O/round4_pmc_northstar.json 2>/dev/null
