@@ -366,7 +366,8 @@ def test_side_stream_weight_gradients_match_single_stream(monkeypatch):
         assert np.all(np.isfinite(res[True][it][0])) and np.all(np.isfinite(res[True][it][1]))
         # (round 4: about one run in five lands at 0.056 after the third step — the same value every time, with and without
         #  the auxiliary stream and the fused norm sums: Adam turns a near-zero gradient whose sign the atomics order decides
-        #  into a +-lr step; the first iteration's arenas above are the stream-dependency check, this is a sanity band)
+        #  into a +-lr step; the first iteration's arenas above are the stream-dependency check, this is a sanity band.
+        #  Round 5: the strict form of this test is tests/test_gpu_round5.py::test_stream_schedules_are_bitwise_equal_in_deterministic_mode)
         assert maxdiff(res[True][it][2], res[False][it][2]) < (5e-3 if it == 1 else 0.15)
 
 

@@ -23,11 +23,12 @@ from types import SimpleNamespace
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 P, H, W, N, STRIDE = 18, 256, 256, 2, 5
 PREC = {"f32": 0, "bf16_data": 3}
-# (out_gen max-abs, out_gen mean-abs) vs the fp32 reference: fp32 keeps north_star's 1e-3; the bf16 data path its stated
-# tolerance (the deviation of the reference itself under bf16 autocast, SURVEY.md 8d: 0.026 mean / 0.28 max)
-TOL = {"f32": (1e-3, 1e-4), "bf16_data": (0.3, 2.6e-2)}
-# (loss rtol, out_gen max-abs, gradient samples / tensor max)
-STEP_TOL = {"f32": (1e-4, 1e-3, 5e-3), "bf16_data": (3e-2, 0.3, 0.2)}
+# (out_gen max-abs, out_gen mean-abs) vs the fp32 reference: fp32 keeps north_star's 1e-3; the bf16 data path 2 x what it was
+# OBSERVED to do over 3 seeds x 2 losses x 7 runs at this resolution (round 5, profiles/round5_bf16_tolerance.txt: 0.0216 max /
+# 0.00284 mean; round 4 stated 0.3 / 2.6e-2, the deviation of the reference itself under bf16 autocast)
+TOL = {"f32": (1e-3, 1e-4), "bf16_data": (0.045, 6e-3)}
+# (loss rtol, out_gen max-abs, gradient samples / tensor max); scalar norm gradients: tests/test_gpu_round5.py
+STEP_TOL = {"f32": (1e-4, 1e-3, 5e-3), "bf16_data": (5e-2, 0.045, 0.2)}
 
 
 def tp(d):
@@ -99,7 +100,7 @@ def test_step_256_vs_golden(name, prec, monkeypatch):
         bad = {}
         for k, g in grads.items():
             ref = fix[prefix + k]
-            if g.numel() == 1:          # scalar norm gamma / beta: cancelling sums over a whole activation (see test_oracle_golden)
+            if g.numel() == 1:          # scalar norm gamma / beta: compared in tests/test_gpu_round5.py (per scalar in fp32, as one vector per network in bf16)
                 continue
             ratio = float(np.abs(_summ(g)[2:] - ref[2:]).max() / max(ref[2], 1e-12))
             if ratio > gt_:
@@ -114,11 +115,14 @@ def test_step_256_vs_golden(name, prec, monkeypatch):
     d = (og[:, :, ::STRIDE, ::STRIDE].cpu() - t(fix[name + "_out_gen_strided"])).abs()
     assert float(d.max()) < ot, (name, prec, float(d.max()))
     if prec == "bf16_data":
-        assert float(d.mean()) < 2.6e-2
+        assert float(d.mean()) < 6e-3
     check_grads(model.gen.arena.grad_dict(), name + "_ggrad_")
 
 
 # ------------------------------------------------------------------------------------------ does the bf16 data path train?
+CORR_MIN = 0.45
+
+
 def _trajectory(prec, store, iters, monkeypatch, round_init=False, gan_w=1.0):
     """`iters` training iterations at 64 x 64 on a fixed 16-sample set (4 batches of 4, cycled), explicit dropout masks (the same
     sequence for every arm), identical initial weights.  The task is LEARNABLE (noise -> noise would leave nothing to compare at
@@ -190,8 +194,20 @@ def test_bf16_data_path_trains_like_fp32(gan_w, monkeypatch):
     the adversarial losses differ by factors.  A fixed '10 %, correlation 0.99' bar is therefore not met by fp32 against
     itself.  The test asserts what IS stable: the L1 term averaged over the whole run within 8 % of fp32's (observed <= 4.8 %),
     every window within max(25 %, 2 x the control's deviation), a final level no worse than 15 % / 2 x control above fp32's, no
-    divergence, and final outputs that still correlate with the fp32 run's (>= 0.3; the control ranges 0.73 - 0.92)."""
+    divergence, and final outputs that still correlate with the fp32 run's (>= CORR_MIN; the control ranges 0.67 - 0.92)."""
     iters = int(os.environ.get("PG_TRAJ_ITERS", "400"))
+    # Round 5: the arms run in PG_DETERMINISTIC mode (ordered split-K, un-split weight gradients, serial reductions: two runs of an arm
+    # are bit-equal, tests/test_gpu_round5.py) — the outcome of this test no longer depends on the order of float atomics, so an arm
+    # outside a band fails the test; round 4 gave a chaotic tail event a second trajectory.
+    lib = L.load()
+    lib.pg_set_deterministic(1)
+    try:
+        _trains_like_fp32(gan_w, iters, monkeypatch)
+    finally:
+        lib.pg_set_deterministic(0)
+
+
+def _trains_like_fp32(gan_w, iters, monkeypatch):
     ref_l, ref_o = _trajectory(0, True, iters, monkeypatch, gan_w=gan_w)
     a = _windows(ref_l)
     ctl_l, ctl_o = _trajectory(0, True, iters, monkeypatch, round_init=True, gan_w=gan_w)
@@ -212,20 +228,14 @@ def test_bf16_data_path_trains_like_fp32(gan_w, monkeypatch):
             return (tag, "final level", l[-WIN:, 4].mean(), ref_l[-WIN:, 4].mean())
         if not l[-WIN:, 4].mean() < 0.6 * l[:WIN, 4].mean():
             return (tag, "the L1 term did not go down")
-        if not corr >= 0.3:      # (the control's own correlation ranges 0.73 - 0.92 from run to run, an arm fell to 0.53 once)
+        if not corr >= CORR_MIN:      # (the control's own correlation: 0.67 - 0.92 over the runs of round 4; the bf16 arms 0.53 - 0.61)
             return (tag, "correlation", corr, ctl_corr)
         return None
 
     for tag, prec, store in arms:
         l, o = _trajectory(prec, store, iters, monkeypatch, gan_w=gan_w)
         bad = check(tag, l, o)
-        if bad is not None:
-            # The trajectories are chaotic (docstring): about one full-suite run in ten put ONE arm outside a band that nine
-            # runs meet.  A second trajectory of the same arm differs through the float atomics alone; the arm fails only if
-            # that one is outside too — a systematic deviation fails twice, a tail event does not.
-            l, o = _trajectory(prec, store, iters, monkeypatch, gan_w=gan_w)
-            bad2 = check(tag + " (second run)", l, o)
-            assert bad2 is None, (bad, bad2)
+        assert bad is None, bad
         if gan_w > 0:      # the game's losses over the WHOLE run: same order of magnitude as fp32's (window means of near-zero
             for col in (0, 5):      # quantities are not comparable; the control differs by factors per window)
                 r, rc = l[:, col].mean() / ref_l[:, col].mean(), ctl_l[:, col].mean() / ref_l[:, col].mean()
