@@ -667,9 +667,18 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
   // few pixels (deep layers at small batch): K cannot be split (>= 16 K tiles per workgroup), so 256-wide tiles leave most
   // of the chip idle (64 workgroups for a 512 x 512 filter) — halve the tile sides until ~128 workgroups exist
   static const bool small_tiles = getenv("PG_WGTR_NO_SMALL_TILES") == nullptr;
-  if (small_tiles && ksplit <= 0 && ktot < 32) {
-    if ((long)(Cout / bm) * (Cx / bn) * 16 < 128 && bn == 256) bn = 128;
-    if ((long)(Cout / bm) * (Cx / bn) * 16 < 128 && bm == 256) bm = 128;
+  // (round 5) with few pixels these launches are not contractions any more: 1 - 16 K tiles, then a 256 KB read-modify-write of the
+  // filter tile by ONE workgroup — 40 - 55 us per launch at batch 4 for 17 MB of dW (0.3 - 0.4 TB/s) with 64 - 128 workgroups.  The
+  // tile sides are halved (256 -> 128, then 64 columns) until ~1024 workgroups share the filter (PG_WGTR_SMALL_WGS; the rule stopped
+  // at 128 workgroups and 128-wide tiles until round 4).  bf16 batch 4, three A/B rounds on one box: 593 - 600 -> 620 - 625 img/s;
+  // configs[2] 919 -> 945; the batch-32 pass unchanged (its deep layers have >= 32 K tiles).
+  static const int small_wgs = getenv("PG_WGTR_SMALL_WGS") ? atoi(getenv("PG_WGTR_SMALL_WGS")) : 1024;
+  static const int small_kt = getenv("PG_WGTR_SMALL_KT") ? atoi(getenv("PG_WGTR_SMALL_KT")) : 32;
+  static const bool small_64 = getenv("PG_WGTR_NO_SMALL_64") == nullptr;
+  if (small_tiles && ksplit <= 0 && ktot < small_kt) {
+    if ((long)(Cout / bm) * (Cx / bn) * 16 < small_wgs && bn == 256) bn = 128;
+    if ((long)(Cout / bm) * (Cx / bn) * 16 < small_wgs && bm == 256) bm = 128;
+    if (small_64 && (long)(Cout / bm) * (Cx / bn) * 16 < small_wgs && bn == 128 && bm == 128) bn = 64;
   }
   const int mt = Cout / bm, nt = Cx / bn;
   int ks = ksplit;
