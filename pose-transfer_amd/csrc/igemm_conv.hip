@@ -1821,7 +1821,7 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
       int mtb = cdiv(k.M, bn == 64 ? 512 : 256);
       const int ntb = cdiv(k.n_cnt, bn);
       long wgs = (long)mtb * ntb * k.nphase;
-      static const long big_min = getenv("PG_BF16_BIG_MIN") ? atol(getenv("PG_BF16_BIG_MIN")) : 192;   // swept (tools/sweep_bf16_big_min.sh): 448 -> 523 / 814, 192 -> 529 / 832 img/s (256^2 batch 4 / 224^2 batch 8)
+      static const long big_min = getenv("PG_BF16_BIG_MIN") ? atol(getenv("PG_BF16_BIG_MIN")) : 96;   // swept (tools/sweep_bf16_big_min.sh): 448 -> 523 / 814, 192 -> 529 / 832 img/s (256^2 batch 4 / 224^2 batch 8); round 5, batch 4: 192 -> 643 / 647, 128 -> 621 (of 618), 96 -> 655.5 / 657.6, 64 -> 653; batch 32 unchanged
       // (round 4) 128-column tiles: 512 x 128 x 32 in three stages instead of 256 x 128 x 64 when the launch still fills the
       // chip with 512-row tiles (csrc/igemm_bf16.hip)
       int code = bn;

@@ -635,7 +635,11 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
       q.dW = dW; q.Cout = Cout; q.ldw = ldw; q.col_off = col_off;
       q.ktot = ktot;
       const int mt4 = Cout / tm, nt4 = Cx / tn;
-      static const int target4 = getenv("PG_WGTR4_TARGET") ? atoi(getenv("PG_WGTR4_TARGET")) : 256;
+      // workgroups per launch (x 4 taps each): 256 at batch 32 (north-star pass 17.05 ms; 128: 17.34, 384: 17.34), 128 at small
+      // batch — every split adds a full set of float atomics on dW next to main-stream launches that are latency-bound themselves
+      // (round 5, bf16 data path, 256 / 128 / 64: batch 4 608 / 634 / 591 img/s, batch 8 829 / 845 / 756, batch 16 1021 / 1016 / -)
+      static const int target4_env = getenv("PG_WGTR4_TARGET") ? atoi(getenv("PG_WGTR4_TARGET")) : 0;
+      const int target4 = target4_env > 0 ? target4_env : (N <= 12 ? 128 : 256);
       const long base4 = (long)mt4 * nt4 * 4;
       int ks4 = (int)((target4 + base4 - 1) / base4);
       if (ks4 > ktot / 8) ks4 = ktot / 8;                       // >= 8 K tiles per workgroup

@@ -1121,8 +1121,13 @@ class NormState:
 # Released ranges (the arena is laid out in backward-completion order: an advancing offset) are updated on the weight-gradient
 # side stream, which first waits for the releasing stream.  Same arithmetic per element as the single launch: bit-identical
 # parameters.  Single process only (a data-parallel run must all-reduce first), not in replay sessions, not for the stacked
-# generator (its stages accumulate into the shared arena).  PG_NO_EAGER_ADAM=1 switches it off.
-EAGER_ADAM = os.environ.get("PG_NO_EAGER_ADAM") is None
+# generator (its stages accumulate into the shared arena).
+# OFF by default since the end of round 5 (PG_EAGER_ADAM=1 switches it on, PG_NO_EAGER_ADAM=1 still forces it off): first measured
+# as a gain (bf16 batch 4 577 -> 592 img/s next to the second encoder stream), it became a loss once the small-pixel-count weight
+# gradients on the same stream got their smaller tiles and fewer splits — 17 range launches of 35 us queue up between them:
+# bf16 batch 4 635 / 643 -> 647 / 662 img/s without it (two boxes), configs[2] 947 -> 955, batch 32 1117 -> 1126, fp32 batch 4
+# 174.1 -> 174.8.  The single launch after the pass runs at the copy rate (0.39 ms at 6.3 TB/s).
+EAGER_ADAM = os.environ.get("PG_EAGER_ADAM") == "1" and os.environ.get("PG_NO_EAGER_ADAM") is None
 EAGER_ADAM_MIN = int(os.environ.get("PG_EAGER_ADAM_MIN", str(1 << 20)))      # elements per range launch (4 MB of parameters)
 
 
@@ -1284,6 +1289,11 @@ class GeneratorEngine:
         # measured (round 5, one box, generator forward + backward at batch 32 / bf16 batch-4 step / fp32 batch-4 step):
         # off 17.8 ms / 576 img/s / 173.6 img/s; from level 4 (the 16^2 ... 4^2 levels only) 17.8 / - / -; from level 3 17.5;
         # from level 1 17.3 / 592 / 175.5; from level 0 - / 590 / 175.2.  The first layers stay on the main stream.
+        # End of the round (after the weight-gradient retune), bf16 batch 4: from level 1 657.6, from level 2 668.4 img/s (level 1's
+        # 128^2 maps fill the chip on their own on the bf16 path even at batch 4); fp32 batch 4: level 1 175.0, level 2 173.3;
+        # batch 32: 17.05 / 17.08 ms.  So: level 2 on the bf16 data path at small batch, level 1 otherwise.
+        if PRECISION == 3 and self.N <= 12:
+            return min(2, self.nlev)
         return min(1, self.nlev)
 
     def _enc_in_src(self, e, inp):

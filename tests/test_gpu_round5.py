@@ -136,6 +136,7 @@ def test_eager_adam_issues_ranges_under_the_backward_pass(monkeypatch):
     pose_gan.py:111 `self.gen_opt.step()` is one call after it): several pg_adam launches per gen_update, together covering the
     arena exactly once, the first of them BEFORE the last weight gradient of the pass."""
     monkeypatch.setattr(E, "PRECISION", 0)
+    monkeypatch.setattr(E, "EAGER_ADAM", True)       # (off by default since the end of round 5: PG_EAGER_ADAM=1)
     size, n = (128, 128), 2
     opt = _opt(size, n)
     model = DeformablePose_GAN(opt, device=DEV, init_seed=7)
