@@ -1289,11 +1289,13 @@ class GeneratorEngine:
         # measured (round 5, one box, generator forward + backward at batch 32 / bf16 batch-4 step / fp32 batch-4 step):
         # off 17.8 ms / 576 img/s / 173.6 img/s; from level 4 (the 16^2 ... 4^2 levels only) 17.8 / - / -; from level 3 17.5;
         # from level 1 17.3 / 592 / 175.5; from level 0 - / 590 / 175.2.  The first layers stay on the main stream.
-        # End of the round (after the weight-gradient retune), bf16 batch 4: from level 1 657.6, from level 2 668.4 img/s (level 1's
-        # 128^2 maps fill the chip on their own on the bf16 path even at batch 4); fp32 batch 4: level 1 175.0, level 2 173.3;
-        # batch 32: 17.05 / 17.08 ms.  So: level 2 on the bf16 data path at small batch, level 1 otherwise.
-        if PRECISION == 3 and self.N <= 12:
-            return min(2, self.nlev)
+        # End of the round, after the weight-gradient retune and with Adam's range launches gone, the picture at SMALL batch turned:
+        # bf16 batch 4, level 1 / 2 / 3 / 4 / off: 657 / 675 / 682 / 687 / 699 img/s; configs[2] (batch 8) level 2 / 3 / 4: 973 / 987 /
+        # 993; fp32 batch 4, level 1 / 2 / 3 / 4 / off: 175.1 / 174.4 / 177.5 / 178.1 / 178.0; batch 32 (pass / step): level 1
+        # 17.01 ms, level 3 17.14 - 17.21, off 17.40; step 1143 - 1145 img/s at every level.  More streams only add contention between
+        # launches that are latency-bound anyway: the second encoder stream is for large batches.
+        if self.N <= 12:
+            return self.nlev
         return min(1, self.nlev)
 
     def _enc_in_src(self, e, inp):
