@@ -1666,9 +1666,16 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
   else bmode = (nvec_ok && d->wCin % 4 == 0) ? B_NN : B_SCALAR;
   if (d->epilogue == 1 && !k.dst_uniform) bmode = B_SCALAR;   // the vector kernels carry the uniform scatter only
   // ---- tile config
+  // bf16 STORAGE (output / destination tensors in bf16) is implemented by the row-major epilogues only, and those exist for wave
+  // tiles of 64 rows (TM == 2): the 64 x 64 workgroup tile (wave tile 32 x 32) would fall through to the MFMA-layout epilogue and
+  // address the bf16 tensors as fp32 (round 5: found when a split-K constant made the time model pick ks = 1 for the 4 x 4 layers at
+  // batch 4 — wrong results and a memory fault; the default constants always split those launches, which go through the fix-up pass)
+  bool io16 = d->epilogue == 0 && d->out_bf16 != 0;
+  if (d->epilogue == 1)
+    for (int j = 0; j < d->ndst; ++j) io16 = io16 || d->dst[j].flags != 0;
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
   if (k.n_cnt <= 32) cfg = 3;
-  else if (k.M <= 64) cfg = 2;
+  else if (k.M <= 64 && !io16) cfg = 2;
   else if (k.n_cnt % 128 == 0) cfg = 0;
   else cfg = 1;
   const int BMs[4] = {128, 128, 64, 128}, BNs[4] = {128, 64, 64, 32};

@@ -598,3 +598,42 @@ def test_step_512_vs_golden(prec, monkeypatch):
     if os.environ.get("PG_TOL_STUDY") == "1":
         print("TOLSTUDY5 512 %s: out_gen max %.5f | gradients %.4f | scalar gradients as one vector %.4f" % (prec, float(d.max()), worst, vec))
     assert worst <= gt_ and vec <= (0.08 if prec == "bf16_data" else 2e-2), (worst, vec)
+
+
+# ------------------------------------------------------------------------------------------ bf16 storage on the smallest maps, un-split
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_bf16_storage_on_4x4_maps_without_split_k(n, monkeypatch):
+    """The 4 x 4 / 8 x 8 layers at small batch have <= 64 GEMM rows.  Their launches are normally split along K and finished by the
+    fix-up pass; un-split (ksplit = 1 — which the split-K time model may also choose) they used to take the 64 x 64 workgroup tile,
+    whose MFMA-layout epilogue addresses bf16 tensors as fp32: wrong gradients and a memory fault (found in round 5 with a
+    non-default split-K constant).  conv_impl now keeps bf16-storage launches on tiles with the row-major epilogues.  Forward
+    (Conv2d k4 s2 p1, reference models/networks.py:154, bf16 output + statistics) and data gradient (bf16 gradient / forward
+    tensors, LeakyReLU derivative): the un-split launch against the split one, one bf16 ulp apart at most."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    C = 512
+    x = _bf("s44/x%d" % n, (n, 8, 8, C))
+    wp = (0.05 * t(synth.normal(613, "mg/s44/w%d" % n, (4, 4, C, C)))).to(DEV).contiguous()
+    outs = {}
+    for ks in (4, 1):
+        out = E._reg_bf16(torch.full((n, 4, 4, C), float("nan"), dtype=torch.bfloat16, device=DEV))
+        stats = torch.zeros(n, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
+        info = E._conv([E.Act(x, C).src()], n, 8, 8, L.ACT_NONE, 0, 4, 2, 1, 4, 4, wp, C, C, out=out, stats=stats, ksplit=ks)
+        torch.cuda.synchronize()
+        assert (info & 0xF) != 2, "64 x 64 tile on a bf16-storage launch"
+        outs[ks] = (out.float(), stats.sum(1).cpu())
+    assert bool(torch.isfinite(outs[1][0]).all())
+    assert float((outs[1][0] - outs[4][0]).abs().max()) <= 2.0 ** -7 * float(outs[4][0].abs().max())
+    assert float(((outs[1][1] - outs[4][1]).abs() / outs[4][1].abs().clamp_min(1e-9)).max()) < 1e-2
+    gy = _bf("s44/gy%d" % n, (n, 4, 4, C))
+    fwd = _bf("s44/f%d" % n, (n, 8, 8, C))
+    aff = torch.stack([t(synth.uniform(613, "mg/s44/a%d" % n, (n,), 0.5, 1.5)), t(synth.uniform(613, "mg/s44/b%d" % n, (n,), -0.5, 0.5))], 1).float().to(DEV)
+    grads = {}
+    for ks in (4, 1):
+        grad = E._reg_bf16(torch.full((n, 8, 8, C), float("nan"), dtype=torch.bfloat16, device=DEV))
+        dst = L.make_dst(grad, C, fwd=fwd, aff=aff, act=L.ACT_LEAKY, accumulate=False)
+        info = E._conv_dgrad(E.Act(gy, C).src(), n, 4, 4, 1, 4, 2, 1, 8, 8, wp, C, C, [dst], ksplit=ks)
+        torch.cuda.synchronize()
+        assert (info & 0xF) != 2
+        grads[ks] = grad.float()
+    assert bool(torch.isfinite(grads[1]).all())
+    assert float((grads[1] - grads[4]).abs().max()) <= 2.0 ** -6 * float(grads[4].abs().max())
