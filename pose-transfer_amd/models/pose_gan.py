@@ -21,6 +21,7 @@ from ..utils import pose_utils, synth
 from .networks import Deformable_Generator, Discriminator, Generator, Stacked_Generator, xavier_weights_init
 
 
+_PF_STREAMS = {}            # device index -> the prefetch stream (prefetch_gen_forward)
 GEN_PREFETCH = os.environ.get("PG_NO_GEN_PREFETCH") is None
 
 
@@ -158,7 +159,15 @@ class DeformablePose_GAN(nn.Module):
             return False
         input = input.contiguous()
         if getattr(self, "_pf_stream", None) is None:
-            self._pf_stream = torch.cuda.Stream(device=input.device)
+            # ONE prefetch stream per device, shared by every model of the process: torch hands out pool streams round-robin and HIP
+            # maps them onto a few hardware queues, so a fresh stream per model moved the (main, side, auxiliary, prefetch) set onto
+            # another queue combination with every model created — the third configuration leg of bench.py ran 5 % slower than the
+            # same leg in a fresh process (1013 -> 961 img/s) because two of its streams shared a hardware queue.
+            dev_i = input.device.index if input.device.index is not None else torch.cuda.current_device()
+            st = _PF_STREAMS.get(dev_i)
+            if st is None:
+                st = _PF_STREAMS[dev_i] = torch.cuda.Stream(device=input.device)
+            self._pf_stream = st
         if E.PRECISION == 3:
             self._core.arena.bf16_params()      # (first use after load_state_dict converts: on THIS stream, before the fork)
         L.call("pg_stream_wait", E._raw(self._pf_stream), L.stream())        # (the inputs were produced on this stream)
