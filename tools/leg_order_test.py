@@ -1,3 +1,5 @@
+"""bench.py configuration legs in a given order inside ONE process (hardware-queue mapping of the streams: models/pose_gan.py _PF_STREAMS).
+    gpurun -- python tools/leg_order_test.py cfg2,b4,cfg2"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import bench, torch
