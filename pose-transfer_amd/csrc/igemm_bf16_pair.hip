@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
 // stages 1 of the two rings and the LDS behind the tables; the DMA table and the tap tables are double-buffered.  The loader
 // state is rebuilt after the epilogue instead of being kept in registers across it.  BN = 64 (512-row tiles) has no LDS left for
 // this: it takes the persistent walk without the early prologue.
-template <int BN, bool MG = false>
+template <int BN, bool MG = false, bool EARLY = true>
 __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, const int mt, const int nt, const int P) {
   static_assert(!(MG && BN == 64), "x-phase merging: 256-row tiles");
   constexpr int XS = MG ? 2 : 1;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
   constexpr int A_ST = AROWS * ROWB, B_ST = BN * ROWB;
   constexpr int B_OFF = 2 * A_ST;
   constexpr int OPS = 2 * (A_ST + B_ST);
-  constexpr bool PF = BN != 64;                          // next tile's prologue under the epilogue
+  constexpr bool PF = BN != 64 && EARLY;                 // next tile's prologue under the epilogue (EARLY = false: the plain persistent walk)
   constexpr int NBUF = PF ? 2 : 1;
   constexpr int ARTAB = AROWS * (int)sizeof(ARow), TPTAB = MAXTAP * 8;
   constexpr int ROWS_OFF = OPS, AROW_OFF = ROWS_OFF + BM * (int)sizeof(RowB), TAPS_OFF = AROW_OFF + NBUF * ARTAB;
@@ -819,6 +819,12 @@ void launch_conv_bf16_pair(const ConvK& k_in, int bn, dim3 grid, hipStream_t st)
   //   second loader rebuild, three more barriers per tile and — in the 256-wide variants — by the scatter epilogue: with the next
   //   tile's state alive its register budget overflows, and every compiler-inserted scratch reload carries a vmcnt(0) that breaks the
   //   epilogue's counted waits (loads of the next half in flight behind the stores of this one).
+  //   third experiment (PG_PAIR_PERSIST_NOPF: the plain persistent walk, the next tile's prologue AFTER the epilogue as a fresh
+  //   workgroup would run it): still + 4 ... 45 % per launch (enc.2 data gradient 182 -> 263 us, dec.5 data gradient 1113 -> 1312),
+  //   north-star 17.2 -> 18.0 - 18.3 ms.  So it is persistence itself, and the reason is the memory counter: loads and stores share ONE
+  //   in-order vmcnt on gfx950, so the first wait for an operand tile of tile t + 1 also waits for the acknowledgement of every output
+  //   store of tile t (256 KB per CU: ~12 us at the HBM rate) — a workgroup that ENDS leaves its stores in flight and its successor
+  //   starts with fresh counters.  One tile per workgroup is the right shape on this part for store-heavy epilogues.
   // PG_PAIR_PERSIST = bit mask of the variants that take the persistent form: 1 <128>, 2 <128, merged>, 4 <256>, 8 <256, merged>, 16 <64>
   static const int persist_mask = getenv("PG_PAIR_PERSIST") ? atoi(getenv("PG_PAIR_PERSIST")) : 0;
   const int vbit = bn == 1256 ? 8 : (bn == 1128 ? 2 : (bn == 256 ? 4 : (bn == 64 ? 16 : 1)));
@@ -836,6 +842,15 @@ void launch_conv_bf16_pair(const ConvK& k_in, int bn, dim3 grid, hipStream_t st)
     const int mt = (int)grid.x, nt = (int)grid.y, P = (int)grid.z;
     const long total = (long)mt * nt * P;
     const dim3 g((unsigned)(total < ncu ? total : ncu));
+    static const bool nopf = getenv("PG_PAIR_PERSIST_NOPF") != nullptr;      // the persistent walk WITHOUT the early prologue
+    if (nopf) {
+      if (bn == 1256) PG_KLAUNCH((conv_bf16_pairp_kernel<256, true, false>), g, dim3(512), 0, st, k, mt, nt, P);
+      else if (bn == 1128) PG_KLAUNCH((conv_bf16_pairp_kernel<128, true, false>), g, dim3(512), 0, st, k, mt, nt, P);
+      else if (bn == 256) PG_KLAUNCH((conv_bf16_pairp_kernel<256, false, false>), g, dim3(512), 0, st, k, mt, nt, P);
+      else if (bn == 64) PG_KLAUNCH((conv_bf16_pairp_kernel<64>), g, dim3(512), 0, st, k, mt, nt, P);
+      else PG_KLAUNCH((conv_bf16_pairp_kernel<128, false, false>), g, dim3(512), 0, st, k, mt, nt, P);
+      return;
+    }
     if (bn == 1256) PG_KLAUNCH((conv_bf16_pairp_kernel<256, true>), g, dim3(512), 0, st, k, mt, nt, P);
     else if (bn == 1128) PG_KLAUNCH((conv_bf16_pairp_kernel<128, true>), g, dim3(512), 0, st, k, mt, nt, P);
     else if (bn == 256) PG_KLAUNCH((conv_bf16_pairp_kernel<256>), g, dim3(512), 0, st, k, mt, nt, P);
