@@ -1293,8 +1293,10 @@ class GeneratorEngine:
         # bf16 batch 4, level 1 / 2 / 3 / 4 / off: 657 / 675 / 682 / 687 / 699 img/s; configs[2] (batch 8) level 2 / 3 / 4: 973 / 987 /
         # 993; fp32 batch 4, level 1 / 2 / 3 / 4 / off: 175.1 / 174.4 / 177.5 / 178.1 / 178.0; batch 32 (pass / step): level 1
         # 17.01 ms, level 3 17.14 - 17.21, off 17.40; step 1143 - 1145 img/s at every level.  More streams only add contention between
-        # launches that are latency-bound anyway: the second encoder stream is for large batches.
-        if self.N <= 12:
+        # launches that are latency-bound anyway: the second encoder stream is for large batches.  Batch 8 / 12 / 16 steps, off against
+        # level 1: 890 / 851, 1008 / 962, 1060 / 1031 img/s; 512^2 batch 8: 291 / 280; batch 32: the step is the same at every level
+        # (1143 - 1145), the generator forward + backward alone gains 2 % from level 1 (17.01 against 17.40 ms).
+        if self.N <= 24:
             return self.nlev
         return min(1, self.nlev)
 
