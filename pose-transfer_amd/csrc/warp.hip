@@ -498,6 +498,204 @@ __global__ __launch_bounds__(256) void warp_fwd3_kernel(const void* feat, const 
   }
 }
 
+// Round-5 forward for bf16 STORAGE (8 channels per lane).  What bounds the kernel above (level 0, batch 32: 250 us = 2.7 TB/s over
+// the algorithmic bytes) — found by elimination: its stores and mask reads alone, in a plain streaming kernel, take
+// 80 - 95 us (tools/micro/store_patterns.hip); a first barrier-free version of this kernel with ~25 % more VALU work per pixel
+// ran in the SAME 250 us, and trimming that work by 15 % moved nothing — so neither bytes, nor barriers, nor instruction issue.
+// It is the chain of DEPENDENT memory round trips per wave and tile: mask values -> (taps ->) gathers of the first active
+// transform -> gathers of the second (95 % of the waves hold a pixel with two) -> stores, whose completion the NEXT tile's
+// first wait has to sit out as well, because gfx950 counts loads and stores in one in-order vmcnt.  At 5 waves per SIMD and
+// 1 - 2 us per round trip under load that is the measured time.  This version shortens the chain instead of widening it:
+//   * no LDS tap table and no per-tile barrier: the C/8 lanes of a pixel fetch one mask value each (one coalesced 4-byte load
+//     per lane and round; __ballot turns them into the pixel's set of active transforms), every lane walks ITS pixel's active
+//     set and evaluates the taps itself (~40 VALU instructions per active transform next to ~100 of sampling);
+//   * the next tile's mask values are fetched under this tile's gathers (- 11 % on their own);
+//   * the tile's results stay in registers and are stored AFTER the next tile's first gathers have been issued: the wait for
+//     those gathers is then vmcnt(<number of stores>), and no wait in the loop stands behind a fresh store.
+// Candidate order, arithmetic and the position of the "no transform" candidate are those of warp_fwd3_kernel: results are
+// BIT-equal to it (tests/test_gpu_round5.py::test_warp_forward_v5_equals_v3).
+// Host guarantees: C / 8 a power of two in 8 ... 64, T <= 2 C / 8, h w C / 8 a multiple of 64 (every lane of every wave owns a pixel).
+template <bool HAS_AMAX>
+__global__ __launch_bounds__(256) void warp_fwd5_kernel(const void* feat, const float* aff, const float* warps, const float* masks,
+                                                        int T, int C, int h, int w, int H0, int W0, int align, void* out,
+                                                        uint8_t* amax, int relu_out) {
+  constexpr int V = 8;
+  typedef float f2 __attribute__((ext_vector_type(2)));        // v_pk_fma_f32: two channels per instruction
+  __shared__ Theta th[MAXT];
+  extern __shared__ __attribute__((aligned(16))) char wsm[];
+  float* xs_t = reinterpret_cast<float*>(wsm);                 // [w] normalised column coordinate, [h] row coordinate: the two
+  float* ys_t = xs_t + w;                                      // IEEE divisions per pixel happen once per workgroup
+  const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  if (tid < T) th[tid] = make_theta(warps + ((long)n * T + tid) * 8, h, w, H0, W0);
+  const float fh = (float)h, fw = (float)w;
+  {
+#pragma clang fp contract(off)
+    for (int j = tid; j < w; j += 256)
+      xs_t[j] = align ? (w > 1 ? (((float)j * 2.0f) / (fw - 1.0f)) - 1.0f : 0.0f) : ((((float)j * 2.0f) + 1.0f) / fw) - 1.0f;
+    for (int i = tid; i < h; i += 256)
+      ys_t[i] = align ? (h > 1 ? (((float)i * 2.0f) / (fh - 1.0f)) - 1.0f : 0.0f) : ((((float)i * 2.0f) + 1.0f) / fh) - 1.0f;
+  }
+  __syncthreads();
+  const int wsh = (w & (w - 1)) == 0 ? 31 - __builtin_clz(w) : -1;
+  const int cpp = C / V;                                       // lanes per pixel
+  const int cshift = 31 - __builtin_clz(cpp);
+  const int npix = h * w;
+  const int items = npix * cpp;                                // host: < 2^31, a multiple of 64
+  const float a = aff ? aff[2 * n] : 1.f, b = aff ? aff[2 * n + 1] : 0.f;
+  const char* fb = reinterpret_cast<const char*>(feat) + (size_t)n * npix * C * 2;
+  char* ob = reinterpret_cast<char*>(out) + (size_t)n * npix * C * 2;
+  uint8_t* ab = HAS_AMAX ? amax + (size_t)n * npix * C : nullptr;
+  const int sub = lane & (cpp - 1), grp = lane - sub;          // my index in the pixel's lane group, the group's first lane
+  const unsigned long long gmask = cpp >= 64 ? ~0ull : ((1ull << cpp) - 1ull);
+  const unsigned tmask = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
+  const int cc = sub * V;
+  const float* mbase = masks + (long)n * npix * T;
+  const int stride = gridDim.x * 256;
+  // one mask value per lane and round (T <= 2 x lanes per pixel: two rounds, both loads issued before the first wait)
+  auto load_masks = [&](int base_, float (&mv_)[2]) {
+    const int pix_ = (base_ + lane) >> cshift;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int t = r * cpp + sub;
+      mv_[r] = (t < T) ? mbase[(long)pix_ * T + t] : 0.f;
+    }
+  };
+  // taps of transform t at normalised coordinates (xs, ys): four clamped byte offsets, four weights (zero outside the image)
+  auto make_taps4 = [&](int t, float xs, float ys, int (&o4)[4], float (&w4)[4]) {
+#pragma clang fp contract(off)
+    const Theta tt = th[t];
+    const float gx = ((tt.t00 * xs) + (tt.t01 * ys)) + tt.t02;
+    const float gy = ((tt.t10 * xs) + (tt.t11 * ys)) + tt.t12;
+    float ix, iy;
+    if (align) { ix = ((gx + 1.0f) / 2.0f) * (fw - 1.0f); iy = ((gy + 1.0f) / 2.0f) * (fh - 1.0f); }
+    else { ix = (((gx + 1.0f) * fw) - 1.0f) / 2.0f; iy = (((gy + 1.0f) * fh) - 1.0f) / 2.0f; }
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const int x0 = (int)fminf(fmaxf(x0f, -4.0f), (float)w + 4.0f);
+    const int y0 = (int)fminf(fmaxf(y0f, -4.0f), (float)h + 4.0f);
+    const float wg[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+      const bool ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h);
+      o4[k] = (min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)) * C * 2 + cc * 2;
+      w4[k] = ok ? wg[k] : 0.f;
+    }
+  };
+  float best[V];
+  unsigned bip[2];                                             // arg-max bytes, packed as they are stored
+  auto zero_candidate = [&]() {
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      if (0.f > best[e]) { best[e] = 0.f; bip[e >> 2] |= 0xffu << (8 * (e & 3)); }
+  };
+  auto consume = [&](const uint4 (&raw)[4], const float (&w4)[4], float m, int t) {
+    f2 s[V / 2];
+#pragma unroll
+    for (int e = 0; e < V / 2; ++e) s[e] = (f2){0.f, 0.f};
+    float wsum, am, bm;
+    {
+#pragma clang fp contract(off)
+      wsum = (w4[0] + w4[1]) + (w4[2] + w4[3]);
+      am = a * m;
+      bm = b * wsum * m;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned u[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+#pragma unroll
+      for (int e = 0; e < V / 2; ++e)
+        s[e] = __builtin_elementwise_fma((f2){__uint_as_float(u[e] << 16), __uint_as_float(u[e] & 0xffff0000u)}, (f2){w4[k], w4[k]}, s[e]);
+    }
+    const unsigned tsplat = (unsigned)t * 0x01010101u;
+#pragma unroll
+    for (int e = 0; e < V / 2; ++e) {
+      const f2 cand = __builtin_elementwise_fma(s[e], (f2){am, am}, (f2){bm, bm});
+      const float cv[2] = {cand.x, cand.y};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ch = 2 * e + q;
+        const bool gt = cv[q] > best[ch];
+        best[ch] = gt ? cv[q] : best[ch];
+        const unsigned sel = gt ? 0xffu << (8 * (ch & 3)) : 0u;
+        bip[ch >> 2] = (bip[ch >> 2] & ~sel) | (tsplat & sel);
+      }
+    }
+  };
+  // results of the previous tile, stored under this tile's first gathers.  Before the first tile: zeros to this lane's OWN first
+  // destination (its real values follow from the same lane in program order) — the stores stay unconditional, so the compiler's
+  // vmcnt for the gathers is a constant
+  uint4 pend_o = make_uint4(0u, 0u, 0u, 0u);
+  uint2 pend_a = make_uint2(0u, 0u);
+  const int base0 = blockIdx.x * 256 + (tid - lane);           // per WAVE: items is a multiple of 64, not of 256
+  int pend_off = ((base0 + lane) >> cshift) * C + cc;
+  float mv[2];
+  if (base0 < items) load_masks(base0, mv);
+  for (int base = base0; base < items; base += stride) {
+    const int pix = (base + lane) >> cshift;
+    const float* mrow = mbase + (long)pix * T;
+    // ---- the pixel's active transforms: bit t <=> mask != 0
+    unsigned act = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const unsigned long long bal = __ballot(mv[r] != 0.f);
+      if (r * cpp < 32) act |= (unsigned)((bal >> grp) & gmask) << (r * cpp);
+    }
+    act &= tmask;
+    const unsigned inact = ~act & tmask;
+    const int z = inact ? __builtin_ctz(inact) : 64;           // the first masked-out transform: where the candidate (0, none) enters
+    if (base + stride < items) load_masks(base + stride, mv);  // the NEXT tile's mask values, under this tile's gathers
+    const int i = wsh >= 0 ? pix >> wsh : pix / w, j = pix - i * w;
+    const float xs = xs_t[j], ys = ys_t[i];
+#pragma unroll
+    for (int e = 0; e < V; ++e) best[e] = -INFINITY;
+    bip[0] = bip[1] = 0xffffffffu;
+    bool zero_done = false;
+    unsigned bits = act;
+    // ---- first active transform: gathers issued, THEN the previous tile's stores, then the wait
+    const bool has = bits != 0;
+    uint4 raw[4];
+    float w4[4], m = 0.f;
+    int t = 0;
+    if (has) {
+      t = __builtin_ctz(bits);
+      bits &= bits - 1;
+      if (t > z) { zero_done = true; zero_candidate(); }
+      int o4[4];
+      make_taps4(t, xs, ys, o4, w4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) raw[k] = *reinterpret_cast<const uint4*>(fb + (unsigned)o4[k]);
+      m = mrow[t];
+    }
+    *reinterpret_cast<uint4*>(ob + (size_t)(unsigned)pend_off * 2) = pend_o;
+    if (HAS_AMAX) *reinterpret_cast<uint2*>(ab + (unsigned)pend_off) = pend_a;
+    if (has) consume(raw, w4, m, t);
+    while (bits) {
+      t = __builtin_ctz(bits);
+      bits &= bits - 1;
+      if (!zero_done && t > z) { zero_done = true; zero_candidate(); }
+      int o4[4];
+      make_taps4(t, xs, ys, o4, w4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) raw[k] = *reinterpret_cast<const uint4*>(fb + (unsigned)o4[k]);
+      m = mrow[t];
+      consume(raw, w4, m, t);
+    }
+    if (!zero_done && z < T) zero_candidate();
+    if (relu_out) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) best[e] = fmaxf(best[e], 0.f);
+    }
+    pend_o = make_uint4(wpack_bf16(best[0], best[1]), wpack_bf16(best[2], best[3]), wpack_bf16(best[4], best[5]), wpack_bf16(best[6], best[7]));
+    pend_a = make_uint2(bip[0], bip[1]);
+    pend_off = pix * C + cc;
+  }
+  if (base0 < items) {
+    *reinterpret_cast<uint4*>(ob + (size_t)(unsigned)pend_off * 2) = pend_o;
+    if (HAS_AMAX) *reinterpret_cast<uint2*>(ab + (unsigned)pend_off) = pend_a;
+  }
+}
+
 // LIST = false (the launch over all tiles): per-pixel candidate lists of GATHER_FLAT = 48 entries — 12 KB per workgroup instead of
 // the 40 KB of the worst case 10 x 16 (PMC: 2.4 waves per SIMD, 65 % of the wave cycles waiting; 1.06 -> 0.83 ms per pass at
 // batch 32).  A tile in which a pixel's list would overflow (several masks overlapping at a strongly minified spot) is not written
@@ -845,7 +1043,22 @@ extern "C" int pg_warp_mask_max_fwd_io(const void* feat, const float* aff, const
 #define PGW_FWD(IB_, OB_)                                                                                                     \
   PG_KLAUNCH((warp_fwd3_kernel<IB_, OB_>), grid, dim3(256), lds, st, feat, aff, warps, lvl_masks, T, C, h, w, H0, W0, \
                      align_corners, tp, out, argmax, relu)
-    if (v8)
+    const bool no_v5 = getenv("PG_WARP_FWD_V3") != nullptr;            // ablation switch (read per call: a test flips it): the LDS-tap-table kernel on bf16 storage too
+    const int cpp8 = C / 8;
+    if (v8 && !no_v5 && !(relu >> 8) && cpp8 >= 8 && cpp8 <= 64 && (cpp8 & (cpp8 - 1)) == 0 && T <= 2 * cpp8 && ((long)h * w * cpp8) % 64 == 0 &&
+        (double)h * w * C * 2.0 < 2147483648.0 && w + h <= 8192) {
+      const char* wenv = getenv("PG_WARP_FWD5_WGS");                    // workgroups per launch (read per call: the test walks several tiles per workgroup)
+      const long wcap5 = wenv ? atol(wenv) : 8192;
+      long wgs = ((long)h * w * cpp8 + 255) / 256;
+      const long cap5 = wcap5 / N > 32 ? wcap5 / N : 32;
+      if (wgs > cap5) wgs = cap5;
+      if (argmax)
+        PG_KLAUNCH(warp_fwd5_kernel<true>, dim3((unsigned)wgs, N), dim3(256), (size_t)(w + h) * 4, st, feat, aff, warps, lvl_masks, T, C, h, w, H0,
+                   W0, align_corners, out, argmax, relu);
+      else
+        PG_KLAUNCH(warp_fwd5_kernel<false>, dim3((unsigned)wgs, N), dim3(256), (size_t)(w + h) * 4, st, feat, aff, warps, lvl_masks, T, C, h, w, H0,
+                   W0, align_corners, out, argmax, relu);
+    } else if (v8)
       PG_KLAUNCH((warp_fwd3_kernel<true, true, 8>), grid, dim3(256), lds, st, feat, aff, warps, lvl_masks, T, C, h, w, H0, W0,
                  align_corners, tp, out, argmax, relu);
     else if (ib && ob) PGW_FWD(true, true);

@@ -637,3 +637,49 @@ def test_bf16_storage_on_4x4_maps_without_split_k(n, monkeypatch):
         grads[ks] = grad.float()
     assert bool(torch.isfinite(grads[1]).all())
     assert float((grads[1] - grads[4]).abs().max()) <= 2.0 ** -6 * float(grads[4].abs().max())
+
+
+@pytest.mark.parametrize("C,h,w,T,align,relu,use_aff", [(64, 64, 64, 10, 0, 1, True), (64, 128, 96, 10, 0, 1, True), (128, 24, 40, 10, 0, 0, False),
+                                                        (256, 16, 16, 3, 1, 1, True), (512, 9, 7, 10, 0, 1, True), (64, 40, 24, 16, 0, 1, False),
+                                                        (64, 33, 31, 17, 0, 1, False)])
+def test_warp_forward_v5_equals_v3(C, h, w, T, align, relu, use_aff):
+    """The barrier-free warp forward of bf16 STORAGE (`warp_fwd5_kernel`: ballot of the pixel's mask values, taps evaluated per lane)
+    against the LDS-tap-table kernel it replaces (`PG_WARP_FWD_V3=1`): output and arg-max planes BIT-equal — same candidate order,
+    same arithmetic, the "no transform" candidate at the first masked-out transform (reference utils/pose_transform.py:69-92).
+    Several tiles per workgroup (the results of a tile are stored under the next tile's gathers), T above and below the lanes per
+    pixel, align_corners; the last shape (pixel count x lanes per pixel not a multiple of 64, T > 16) stays on the old kernel."""
+    N, H0, W0 = 3, 4 * h, 4 * w
+    rng = np.random.RandomState(C + h + T)
+    sc = rng.uniform(0.7, 1.3, (N, T)); ph = rng.uniform(-0.5, 0.5, (N, T))
+    wr = np.zeros((N, T, 8), np.float32)
+    wr[..., 0] = sc * np.cos(ph); wr[..., 1] = -sc * np.sin(ph); wr[..., 3] = sc * np.sin(ph); wr[..., 4] = sc * np.cos(ph)
+    wr[..., 2] = rng.uniform(-0.6 * H0, 0.6 * H0, (N, T)); wr[..., 5] = rng.uniform(-0.6 * W0, 0.6 * W0, (N, T)); wr[..., 6:] = [0.0, 1.0]
+    lv = rng.uniform(0.05, 1.0, (N, h, w, T)).astype(np.float32)
+    lv[rng.uniform(size=lv.shape) < 0.7] = 0.0                          # most transforms masked out at a pixel, some pixels with none / all
+    lv[0, :2] = 0.0
+    lv[1, -2:] = rng.uniform(0.1, 1.0, (2, w, T))
+    feat = torch.from_numpy(rng.standard_normal((N, h, w, C)).astype(np.float32)).to(DEV).to(torch.bfloat16).contiguous()
+    feat[2, :, :, ::3] = 0.0                                            # exact-zero candidates: ties with the "no transform" candidate
+    aff = torch.from_numpy(rng.uniform(0.5, 1.5, (N, 2)).astype(np.float32)).to(DEV) if use_aff else None
+    wrd, lvd = torch.from_numpy(wr).to(DEV), torch.from_numpy(lv).to(DEV)
+    res = []
+    for v3 in (True, False, False):
+        if v3:
+            os.environ["PG_WARP_FWD_V3"] = "1"
+        elif len(res) == 2:
+            os.environ["PG_WARP_FWD5_WGS"] = "96"                       # 32 workgroups per sample: several tiles each (deferred stores, mask prefetch)
+        try:
+            out = torch.full((N, h, w, C), 7.0, device=DEV, dtype=torch.bfloat16)
+            arg = torch.full((N, h, w, C), 77, dtype=torch.uint8, device=DEV)
+            L.call("pg_warp_mask_max_fwd_io", L.ptr(feat), L.ptr(aff) if use_aff else None, L.ptr(wrd), L.ptr(lvd), N, T, C, h, w, H0, W0,
+                   align, L.ptr(out), L.ptr(arg), 3 | (4 if relu else 0), L.stream())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("PG_WARP_FWD_V3", None)
+            os.environ.pop("PG_WARP_FWD5_WGS", None)
+        res.append((out.view(torch.int16).cpu(), arg.cpu()))
+    for r in res[1:]:
+        assert torch.equal(res[0][1], r[1]), float((res[0][1] != r[1]).float().mean())
+        assert torch.equal(res[0][0], r[0])
+    used = set(res[1][1].unique().tolist())
+    assert 255 in used and len(used) >= min(T, 3), used
