@@ -683,3 +683,9 @@ def test_warp_forward_v5_equals_v3(C, h, w, T, align, relu, use_aff):
         assert torch.equal(res[0][0], r[0])
     used = set(res[1][1].unique().tolist())
     assert 255 in used and len(used) >= min(T, 3), used
+    # without an arg-max plane (inference through the C ABI): the same output
+    out = torch.full((N, h, w, C), 7.0, device=DEV, dtype=torch.bfloat16)
+    L.call("pg_warp_mask_max_fwd_io", L.ptr(feat), L.ptr(aff) if use_aff else None, L.ptr(wrd), L.ptr(lvd), N, T, C, h, w, H0, W0,
+           align, L.ptr(out), None, 3 | (4 if relu else 0), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16).cpu(), res[0][0])
