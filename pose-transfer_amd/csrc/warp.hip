@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
 #ifndef PG_GATHER_PB
 #define PG_GATHER_PB 4
 #endif
-  constexpr int PB = PG_GATHER_PB;          // list entries per batch of the gather phase (independent loads in flight; batch 32: 4 -> 642 us per pass, 2 -> 699, 1 -> 721)
+  constexpr int PB = PG_GATHER_PB;          // list entries per batch of the gather phase (independent loads in flight; batch 32: 4 -> 642 us per pass, 2 -> 699, 1 -> 721; 8 -> 155 VGPRs, 924 us against 712 on the round-5 box)
 #ifdef PG_TIMING_EXPERIMENTS
   const int wdbg = align >> 8;       // PG_DEBUG_WARP_BWD (timing build only; results are wrong): 1 = no phase 2, 2 = no phase 1
   align &= 0xff;
