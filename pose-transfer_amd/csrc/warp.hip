@@ -710,9 +710,13 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   constexpr int ESG = GB ? 2 : 4, ESD = DB ? 2 : 4;
   constexpr int FLAT = LIST ? GATHER_T * GATHER_CAP : GATHER_FLAT;
 #ifndef PG_GATHER_PB
-#define PG_GATHER_PB 4
+#define PG_GATHER_PB 2
 #endif
-  constexpr int PB = PG_GATHER_PB;          // list entries per batch of the gather phase (independent loads in flight; batch 32: 4 -> 642 us per pass, 2 -> 699, 1 -> 721; 8 -> 155 VGPRs, 924 us against 712 on the round-5 box)
+  constexpr int PB = PG_GATHER_PB;          // list entries per batch of the gather phase (independent loads in flight).
+                                            // Round 5, last day: what this kernel needs is RESIDENT WAVES, not loads per wave — it is bound by dependent memory round
+                                            // trips like the forward.  4 entries per batch = 100 VGPRs = 4 waves per SIMD: 712 us per pass at batch 32; 3 = 84 VGPRs = 5
+                                            // waves: 667; 2 with 32-bit offsets = 80 VGPRs and the coordinate tables in dynamic LDS (22 KB per workgroup): 6 waves, 597;
+                                            // + two candidate items per lane and round instead of four (68 VGPRs, 7 waves): 571.  (8 entries: 155 VGPRs, 924 us.)
 #ifdef PG_TIMING_EXPERIMENTS
   const int wdbg = align >> 8;       // PG_DEBUG_WARP_BWD (timing build only; results are wrong): 1 = no phase 2, 2 = no phase 1
   align &= 0xff;
@@ -728,7 +732,9 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   __shared__ int pr_n;                                    // accepted (pixel, transform) pairs of the tile:
   __shared__ int4 pr[GATHER_PIX * GATHER_T];              //   pixel | t << 8, i0, j0 | nj << 16, candidates (<= GATHER_CAP)
   __shared__ int px_x[GATHER_PIX], px_y[GATHER_PIX];
-  __shared__ float xs_t[GATHER_MAXDIM], ys_t[GATHER_MAXDIM];      // normalised grid coordinate per column / row (host: h, w <= 1024)
+  extern __shared__ __attribute__((aligned(16))) char gsm[];       // normalised grid coordinate per column / row: (w + h) floats
+  float* const xs_t = reinterpret_cast<float*>(gsm);               // (dynamic: 2 KB at 256^2 instead of 8 KB static — a sixth workgroup per CU)
+  float* const ys_t = xs_t + w;
   const int nent = LIST ? min(g_gather_ovf[0], GATHER_OVF_MAX) : 1;
   for (int ent = LIST ? (int)blockIdx.x : 0; ent < nent; ent += LIST ? (int)gridDim.x : 1) {
   const int n = LIST ? (g_gather_ovf[1 + ent] >> 20) : (int)blockIdx.y;
@@ -754,6 +760,8 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
   for (int k = threadIdx.x; k < w; k += 256) xs_t[k] = warp_norm_coord(k, w, align);
   for (int k = threadIdx.x; k < h; k += 256) ys_t[k] = warp_norm_coord(k, h, align);
   const long nb = (long)n * h * w;
+  const uint8_t* const amax_n = amax + nb * C;
+  const char* const gout_n = reinterpret_cast<const char*>(gout) + (size_t)(nb * C) * ESG;
   // persistent workgroups (round 3): the per-sample set-up above (ten inverted transforms, w + h table entries) cost more
   // than the 32 pixels of work behind it when every tile was its own workgroup (65536 workgroups at 256^2, batch 32)
   const int ntiles = LIST ? (g_gather_ovf[1 + ent] & 0xfffff) + 1 : (h * w + GATHER_PIX - 1) / GATHER_PIX;
@@ -799,7 +807,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
     // (tried: one word per candidate written by stage (a) so that stage (b) is dense — the divergent store loop costs more than
     //  the idle lanes: level 0 at batch 32 372 -> 408 us.  Timing build at that level: stage (a) 53 us, stage (b) 95, gather 178.)
     const int nitems = (wdbg & 4) ? 0 : pr_n * GATHER_CAP;      // (timing build: 4 = no candidate stage)
-    constexpr int U = 4;                                   // items per lane and round: the mask loads go out as one batch
+    constexpr int U = 2;                                   // items per lane and round: the mask loads go out as one batch
     for (int it0 = threadIdx.x; it0 < nitems; it0 += 256 * U) {
       float mv[U];
       int pp[U], tt[U], ci[U], cj[U];
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
     for (int e = 0; e < V; ++e) acc[e] = 0.f;
     const int cnt = e_cnt[p];
     for (int e0 = 0; e0 < cnt; e0 += PB) {
-      long o[PB]; float wt[PB]; int tt[PB]; unsigned am[PB][V / 4]; float g[PB][V];
+      unsigned o[PB]; float wt[PB]; int tt[PB]; unsigned am[PB][V / 4]; float g[PB][V];      // o: element offset inside the sample (host: h w C < 2^31)
 #pragma unroll
       for (int u = 0; u < PB; ++u) {
         const bool val = e0 + u < cnt;
@@ -870,10 +878,10 @@ __global__ __launch_bounds__(256) void warp_bwd_gather_kernel(const void* gout, 
         const int pk = e_pix[p][ee];
         tt[u] = val ? (pk >> 24) : 256;          // padding entries match no arg-max byte (255 = "no transform won" is a byte value)
         wt[u] = val ? e_w[p][ee] : 0.f;
-        o[u] = (nb + (pk & 0xffffff)) * C + c4;
+        o[u] = (unsigned)(pk & 0xffffff) * (unsigned)C + (unsigned)c4;
 #pragma unroll
-        for (int qd = 0; qd < V / 4; ++qd) am[u][qd] = *reinterpret_cast<const unsigned*>(amax + o[u] + 4 * qd);
-        wldv<GB, V>(reinterpret_cast<const char*>(gout), (size_t)o[u] * ESG, g[u]);
+        for (int qd = 0; qd < V / 4; ++qd) am[u][qd] = *reinterpret_cast<const unsigned*>(amax_n + o[u] + 4 * qd);
+        wldv<GB, V>(gout_n, (size_t)o[u] * ESG, g[u]);
       }
 #pragma unroll
       for (int u = 0; u < PB; ++u)
@@ -1107,7 +1115,7 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
     else PG_KLAUNCH((KERNEL<false, false>), GRID, dim3(256), 0, st, __VA_ARGS__);            \
   } while (0)
   const long all_tiles = (long)N * (((long)h * w + GATHER_PIX - 1) / GATHER_PIX);
-  if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM && all_tiles <= GATHER_OVF_MAX &&
+  if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && (double)h * w * C < 2147483648.0 && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM && all_tiles <= GATHER_OVF_MAX &&
       N < 2048) {
     // gather kernel OVERWRITES dfeat (narrow transforms), then the scatter kernel adds the wide ones
     static const int gcap = getenv("PG_WARP_BWD_TILES") ? atoi(getenv("PG_WARP_BWD_TILES")) : 256;     // workgroups per sample
@@ -1122,18 +1130,19 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
     static void* ovf_dev = nullptr;                      // g_gather_ovf: tiles whose 48-entry lists overflowed
     if (ovf_dev == nullptr) PG_REQUIRE(hipGetSymbolAddress(&ovf_dev, HIP_SYMBOL(g_gather_ovf)) == hipSuccess, "pg_warp_mask_max_bwd: symbol");
     PG_MEMSET_ASYNC(ovf_dev, 0, 4, st);
+    const size_t glds = (size_t)(w + h) * 4;
     const dim3 g1(gtiles, N), g2(64);                    // second launch: worst-case capacity over the overflow list (usually empty)
     if (gb && db && C % 8 == 0 && !no_v8b) {
-      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
+      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, false>), g1, dim3(256), glds, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
                  ac_g, dfeat, (const int*)bbox, det_g);
-      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
+      PG_KLAUNCH((warp_bwd_gather_kernel<true, true, 8, true>), g2, dim3(256), glds, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
                  ac_g, dfeat, (const int*)bbox, det_g);
     } else {
 #define PGW_GATHER(GBv, DBv)                                                                                                    \
   do {                                                                                                                          \
-    PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, false>), g1, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, \
+    PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, false>), g1, dim3(256), glds, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, \
                ac_g, dfeat, (const int*)bbox, det_g);                                                                         \
-    PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, true>), g2, dim3(256), 0, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,  \
+    PG_KLAUNCH((warp_bwd_gather_kernel<GBv, DBv, 4, true>), g2, dim3(256), glds, st, gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,  \
                ac_g, dfeat, (const int*)bbox, det_g);                                                                         \
   } while (0)
       if (gb && db) PGW_GATHER(true, true);
