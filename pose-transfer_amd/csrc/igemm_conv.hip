@@ -1553,6 +1553,7 @@ static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma,
 
 namespace pg { void launch_conv_bf16_big(const ConvK& k, int bn, dim3 grid, hipStream_t st); }   // igemm_bf16.hip
 namespace pg { void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st); }  // igemm_bf16_pair.hip
+namespace pg { void launch_conv_bf16_quad(const ConvK& k, bool merged, dim3 grid, hipStream_t st); }  // igemm_bf16_quad.hip
 
 using namespace pg;
 
@@ -1944,11 +1945,74 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
           }
         if (!(bs_any && bs_ok))
           for (int j = 0; j < PG_MAX_SRC; ++j) k.dst[j].bsums = nullptr;
-        if (merged) launch_conv_bf16_pair(k, 1000 + bn_l, dim3(mtb, 1, 2), st);
+        // (round 6) tap-QUAD sharing on 512 x 128 x 32 tiles (igemm_bf16_quad.hip) for the 128-column launches whose taps form
+        // 2 x 2 quads (k4 s2 p1 forward: 4 quads; a transposed phase / an x-merged phase pair: 1 quad): every input pixel of the tile's
+        // halo patch goes global -> LDS once, the weight tile once per 512 rows.  Conditions: the 512-row tile lies inside one sample,
+        // one image row of extra LDS rows fits (Gx <= ~128), enough tiles to fill the chip.
+        bool quad = false;
+        {
+          const char* qe = getenv("PG_BIG_QUAD");           // "0" / "1": read per launch (the test-suite flips it inside one process)
+          static const long quad_min = getenv("PG_QUAD_MIN") ? atol(getenv("PG_QUAD_MIN")) : 512;
+          const int xs = merged ? 2 : 1, gg_ = k.Gy * k.Gx;
+          bool want = (qe ? qe[0] != '0' : true) && (merged ? bn_l == 128 : (bn == 128 && ntb == 1 && k.n_cnt == 128)) &&
+                      gg_ % 512 == 0 && k.M % 512 == 0 && ctot % 32 == 0 && k.Wi < 32000 && k.Hi < 32000 &&
+                      ((long)(k.M / 512) * k.nphase >= quad_min || getenv("PG_FORCE_BF16_BIG") != nullptr);
+          if (want) {
+            const int max_rho = 511 + xs * ((k.Gx - 1 + 511) / k.Gx) + (merged ? 2 : 1) + k.Gx + xs;
+            want = max_rho <= 671;
+          }
+          for (int j = 0; j < d->nsrc && want; ++j)
+            if ((double)d->N * d->Hi * d->Wi * d->src[j].C * 2.0 >= 4294967296.0 || k.cstart[j] % 32 != 0) want = false;
+          if (want) {
+            ConvK kk = k;
+            bool ok = true;
+            for (int ph = 0; ph < (merged ? 4 : k.nphase) && ok; ++ph) {      // (merged: slots py and 2 + py hold the two column halves' taps)
+              const int nt_ = k.ntap[ph];
+              if (nt_ < 4 || (nt_ & 3)) { ok = false; break; }
+              int o[MAXTAP], used[MAXTAP];
+              for (int a = 0; a < nt_; ++a) { o[a] = a; used[a] = 0; }
+              for (int a = 1; a < nt_; ++a)           // insertion sort by (dy, dx)
+                for (int b = a; b > 0; --b) {
+                  const int x = o[b - 1], y = o[b];
+                  if (k.dy[ph][x] > k.dy[ph][y] || (k.dy[ph][x] == k.dy[ph][y] && k.dx[ph][x] > k.dx[ph][y])) { o[b - 1] = y; o[b] = x; }
+                }
+              auto find = [&](int dy_, int dx_) {
+                for (int b = 0; b < nt_; ++b)
+                  if (!used[b] && k.dy[ph][o[b]] == dy_ && k.dx[ph][o[b]] == dx_) return b;
+                return -1;
+              };
+              int w = 0;
+              for (int a = 0; a < nt_ && ok; ++a) {
+                if (used[a]) continue;
+                const int dy0 = k.dy[ph][o[a]], dx0 = k.dx[ph][o[a]];
+                int q4[4];
+                for (int e = 0; e < 4 && ok; ++e) {
+                  q4[e] = find(dy0 + (e >> 1) * k.si, dx0 + (e & 1) * k.si);
+                  if (q4[e] < 0) ok = false; else used[q4[e]] = 1;
+                }
+                for (int e = 0; e < 4 && ok; ++e) {
+                  kk.dy[ph][w] = k.dy[ph][o[q4[e]]]; kk.dx[ph][w] = k.dx[ph][o[q4[e]]]; kk.wtap[ph][w] = k.wtap[ph][o[q4[e]]];
+                  ++w;
+                }
+              }
+            }
+            if (ok && merged)       // the right half's quad = the left half's one slot to the right (the kernel shares the A tile)
+              for (int py = 0; py < 2; ++py)
+                for (int t = 0; t < 4; ++t)
+                  if (kk.dy[2 + py][t] != kk.dy[py][t] || kk.dx[2 + py][t] != kk.dx[py][t] + 1) ok = false;
+            if (ok) { k = kk; quad = true; }
+          }
+        }
+        if (quad) {
+          const int mtq = k.M / 512;
+          k.xcd_swizzle = ((mtq % 8 == 0 && k.nphase > 1 && !env().no_xcd_swizzle) ? 1 : 0);
+          launch_conv_bf16_quad(k, merged, dim3(mtq, 1, k.nphase), st);
+        }
+        else if (merged) launch_conv_bf16_pair(k, 1000 + bn_l, dim3(mtb, 1, 2), st);
         else if (pair) launch_conv_bf16_pair(k, bn, dim3(mtb, ntb, k.nphase), st);
         else launch_conv_bf16_big(k, code, dim3(mtb, ntb, k.nphase), st);
         PG_LAUNCH_OK("pg_conv (bf16 256-row kernel)");
-        last_info() = (merged ? (bn_l == 256 ? 11 : 12) : pair ? (bn == 256 ? 8 : (bn == 128 ? 9 : 10)) : (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6)))) |
+        last_info() = (quad ? (merged ? 14 : 13) : merged ? (bn_l == 256 ? 11 : 12) : pair ? (bn == 256 ? 8 : (bn == 128 ? 9 : 10)) : (code == 129 ? 7 : (bn == 256 ? 4 : (bn == 128 ? 5 : 6)))) |
                       (amode << 4) | (bmode << 8) | (1 << 16) | ((bs_any && bs_ok) ? PG_INFO_BSUMS : 0);
         return 0;
       }

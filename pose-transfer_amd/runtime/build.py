@@ -15,7 +15,7 @@ TIMING = os.environ.get("PG_TIMING_EXPERIMENTS") == "1"
 OBJDIR = os.path.join(LIBDIR, "obj_timing" if TIMING else "obj")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.environ.get("PG_LIB") or os.path.join(LIBDIR, "libposegan_hip_timing.so" if TIMING else "libposegan_hip.so")
-SOURCES = ["api.hip", "comm.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "pose_geom.hip", "edge.hip", "small_cin_wgrad.hip", "out_conv_dgrad.hip", "out_conv_fwd.hip", "igemm_conv.hip", "igemm_bf16.hip", "igemm_bf16_pair.hip", "wgrad_bf16.hip", "stem_bf16.hip", "igemm_wgrad.hip"]
+SOURCES = ["api.hip", "comm.hip", "optim.hip", "norm.hip", "losses.hip", "warp.hip", "pose_geom.hip", "edge.hip", "small_cin_wgrad.hip", "out_conv_dgrad.hip", "out_conv_fwd.hip", "igemm_conv.hip", "igemm_bf16.hip", "igemm_bf16_pair.hip", "igemm_bf16_quad.hip", "wgrad_bf16.hip", "stem_bf16.hip", "igemm_wgrad.hip"]
 # -pragma-unroll-threshold: the epilogue loops over a wave's MFMA tiles MUST be fully unrolled (a rolled loop indexes the
 # accumulator array at run time and the compiler moves it to scratch memory); the 4x2-tile bf16 kernel exceeds the default
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1000000",
@@ -45,7 +45,7 @@ def build_lib(force=False, verbose=True):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
-        if force or _newer(src, obj, conv_hdrs if s in ("igemm_conv.hip", "igemm_bf16.hip", "igemm_bf16_pair.hip", "wgrad_bf16.hip", "stem_bf16.hip") else hdrs):
+        if force or _newer(src, obj, conv_hdrs if s in ("igemm_conv.hip", "igemm_bf16.hip", "igemm_bf16_pair.hip", "igemm_bf16_quad.hip", "wgrad_bf16.hip", "stem_bf16.hip") else hdrs):
             jobs.append((src, obj))
 
     def cc(job):

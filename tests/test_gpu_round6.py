@@ -1,0 +1,172 @@
+"""Round-6 GPU tests (all through the C ABI):
+  * the tap-QUAD kernel (csrc/igemm_bf16_quad.hip: 512 x 128 x 32 tiles, one A tile per 2 x 2 quad of taps, x-phase merged form)
+    against torch on bf16-rounded operands and against the tap-pair / merged kernels it replaces on the short-K layers;
+  * the bf16-I/O warp kernels directly against the oracle;
+  * the bf16 data path's gradients against the oracle's FULL tensors: cosine and relative L2 per tensor (item 6b);
+  * PG_DETERMINISTIC and the wide / fall-back forms of the warp backward."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpu_util import DEV, E, L, ConvCase, act_fn, maxdiff, synth, t
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------ tap-quad kernel, fp32 tensors vs torch
+def quad_cases():
+    A, M = True, True
+    return [
+        # encoder level 1's shape class: Conv2d(k4, s2, p1) 64 -> 128; grid 32 x 32 (tiles of 16 image rows), 8 x 128 (4 rows,
+        # the real width), 64 x 48 x 2 samples (tiles that start inside an image row: 512 = 10 rows + 32)
+        ConvCase("quad_down_64_128_g32", "conv", [(64, A, False)], 128, 2, 64, 64, 4, 2, 1, L.ACT_LEAKY, seed=61),
+        ConvCase("quad_down_64_128_g128", "conv", [(64, A, False)], 128, 1, 16, 256, 4, 2, 1, L.ACT_LEAKY, seed=62),
+        ConvCase("quad_down_2src_g48", "conv", [(64, A, M), (64, False, False)], 128, 2, 128, 96, 4, 2, 1, L.ACT_LEAKY, seed=63),
+        # transposed, four phases of ONE quad each (un-merged): N = 128 columns, three sources
+        ConvCase("quad_up_128_3src", "convT", [(128, A, M), (64, False, False), (64, A, False)], 128, 2, 16, 32, 4, 2, 1,
+                 L.ACT_RELU, seed=64),
+    ]
+
+
+@pytest.mark.parametrize("case", quad_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
+def test_conv_bf16_quad_kernel(case, monkeypatch):
+    """conv_bf16_quad_kernel<false> forced on small problems: forward (fp32 output + fused statistics) and the data gradient of the
+    conv cases with 128 input channels (four transposed phases, one quad each, fp32 destinations, fresh and accumulating).  Exact up
+    to summation order against the fp32 contraction of the bf16-ROUNDED operands (1e-4 of the tensor max) and against the tap-pair
+    kernel on the same launch (reference models/networks.py:154-157: Conv2d / ConvTranspose2d k4 s2 p1 of a Block)."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    monkeypatch.setenv("PG_BIG_PAIR", "1")
+    monkeypatch.setenv("PG_BIG_MERGE", "0")
+    monkeypatch.setenv("PG_BIG_128_VARIANT", "256")
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    zs, xs = [], []
+    for j in range(len(case.srcs)):
+        z = case.raw[j]
+        if case.aff[j] is not None:
+            z = torch.addcmul(case.aff[j][:, 1].view(-1, 1, 1, 1), z, case.aff[j][:, 0].view(-1, 1, 1, 1))
+        zs.append(z.detach().clone().requires_grad_(True))
+    for j, z in enumerate(zs):
+        v = z if case.mask[j] is None else z * case.mask[j].view(case.N, -1, 1, 1)
+        xs.append(act_fn(v, case.act))
+    w = bf(case.w)
+    xq = torch.cat([bf(x.detach()) for x in xs], 1)
+    conv = (lambda x: F.conv2d(x, w, case.b, stride=case.stride, padding=case.pad)) if case.kind == "conv" else \
+           (lambda x: F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:-1, 1:-1])
+    ref = conv(xq)
+    res = {}
+    for q in ("1", "0"):
+        monkeypatch.setenv("PG_BIG_QUAD", q)
+        stats = torch.zeros(case.N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
+        got = case.run_forward(1, stats=stats)
+        res[q] = (got, stats.cpu().sum(1), L.load().pg_last_launch_info() & 0xF)
+    assert res["1"][2] == 13 and res["0"][2] in (5, 9), (res["1"][2], res["0"][2])
+    got, st = res["1"][0], res["1"][1]
+    assert rel(got, ref) < 1e-4, (case.name, rel(got, ref))
+    assert rel(got, res["0"][0]) < 2e-5, (case.name, rel(got, res["0"][0]))
+    o64 = got.double().reshape(case.N, -1)
+    assert float(((st[:, 0] - o64.sum(1)).abs() / o64.abs().sum(1)).max()) < 1e-6
+    assert float(((st[:, 1] - (o64 * o64).sum(1)).abs() / (o64 * o64).sum(1)).max()) < 1e-6
+    if case.kind == "conv" and case.cin == 128:
+        y = conv(torch.cat(xs, 1))
+        dref = torch.autograd.grad((y * bf(case.gout)).sum(), zs)
+        monkeypatch.setenv("PG_BIG_QUAD", "1")
+        for acc in (False, True):
+            dgot = case.run_dgrad(1, acc)
+            assert (L.load().pg_last_launch_info() & 0xF) == 13
+            for g, r in zip(dgot, dref):
+                assert rel(g, r) < 1e-4, (case.name, acc, rel(g, r))
+
+
+# ------------------------------------------------------------------------------------------ x-phase merged quad form, bf16 storage
+def _bf(tag, shape, scale=1.0):
+    x = (scale * t(synth.normal(661, "qd/" + tag, shape))).to(DEV).bfloat16().contiguous()
+    return E._reg_bf16(x)
+
+
+def _ulp_close(got, base):
+    """equal up to fp32 summation order: one bf16 ulp of the stored value (2^-8 relative to the element, 2^-7 of the tensor max as
+    the floor for cancelled elements)"""
+    g, b = got.float(), base.float()
+    assert bool(torch.isfinite(g).all())
+    tol = 2.0 ** -7 * b.abs() + 2.0 ** -9 * float(b.abs().max())
+    assert bool(((g - b).abs() <= tol).all()), float(((g - b).abs() - tol).max())
+
+
+QGEOM = [(2, 16, 64), (1, 8, 128), (3, 32, 48)]       # (N, H, W) of the small grid: H W % 512 == 0, W >= 43
+
+
+@pytest.mark.parametrize("cins", [(128,), (64, 64), (64,)])
+@pytest.mark.parametrize("geom", QGEOM)
+def test_quad_merged_forward(cins, geom, monkeypatch):
+    """conv_bf16_quad_kernel<true>: the transposed k4 s2 convolution with 64 output channels as 512 x (2 x 64) tiles per phase pair —
+    ONE A tile per channel chunk serves the 2 x 2 taps of both x-phases.  Against the x-phase merged tap-pair kernel (itself
+    bit-equal to the tap-pair kernel, which is checked against torch): equal up to fp32 summation order, i.e. one bf16 ulp of the
+    stored value; statistics to 1e-3 of their size."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    monkeypatch.setenv("PG_BIG_PAIR", "1")
+    monkeypatch.setenv("PG_BIG_MERGE", "1")
+    N, H, W = geom
+    cout, cin = 64, sum(cins)
+    xs = [_bf("x%d/%s%s" % (j, geom, cins), (N, H, W, c)) for j, c in enumerate(cins)]
+    wp = (0.05 * t(synth.normal(661, "qd/w/%s%s" % (geom, cins), (4, 4, cout, cin)))).to(DEV).contiguous()
+    res = {}
+    for q in ("1", "0"):
+        monkeypatch.setenv("PG_BIG_QUAD", q)
+        out = E._reg_bf16(torch.full((N, 2 * H, 2 * W, cout), float("nan"), dtype=torch.bfloat16, device=DEV))
+        stats = torch.zeros(N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV)
+        info = E._conv([E.Act(x, c).src() for x, c in zip(xs, cins)], N, H, W, L.ACT_NONE, 1, 4, 2, 1, 2 * H, 2 * W, wp, cout, cin,
+                       out=out, stats=stats, ksplit=1)
+        torch.cuda.synchronize()
+        res[q] = (out, stats.sum(1).cpu(), info & 0xF)
+    assert res["1"][2] == 14 and res["0"][2] == 12, (res["1"][2], res["0"][2])
+    _ulp_close(res["1"][0], res["0"][0])
+    assert float(((res["1"][1] - res["0"][1]).abs() / res["0"][1].abs().clamp_min(1e-9)).max()) < 1e-3
+
+
+@pytest.mark.parametrize("accumulate,sums", [(False, True), (True, False)])
+@pytest.mark.parametrize("geom", QGEOM)
+def test_quad_merged_data_gradient(accumulate, sums, geom, monkeypatch):
+    """the same for the data gradient of a Conv2d(k4, s2, p1) with 64 INPUT channels (encoder level 1; reference
+    models/networks.py:154, autograd of conv2d wrt its input): bf16 gradient and forward tensors, LeakyReLU derivative from the raw
+    forward value + per-sample affine, fresh and accumulating destinations, the fused norm-backward sums."""
+    monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
+    monkeypatch.setenv("PG_BIG_PAIR", "1")
+    monkeypatch.setenv("PG_BIG_MERGE", "1")
+    N, Hs, Ws = geom
+    cin, cout = 64, 128
+    tag = "%s/%d" % (geom, cin)
+    gy = _bf("gy/" + tag, (N, Hs, Ws, cout))
+    fwd = _bf("fwd/" + tag, (N, 2 * Hs, 2 * Ws, cin))
+    aff = torch.stack([t(synth.uniform(661, "qd/a/" + tag, (N,), 0.5, 1.5)), t(synth.uniform(661, "qd/b/" + tag, (N,), -0.5, 0.5))], 1).float().to(DEV)
+    wp = (0.05 * t(synth.normal(661, "qd/wd/" + tag, (4, 4, cout, cin)))).to(DEV).contiguous()
+    prev = _bf("prev/" + tag, (N, 2 * Hs, 2 * Ws, cin), 0.3)
+    res = {}
+    for q in ("1", "0"):
+        monkeypatch.setenv("PG_BIG_QUAD", q)
+        grad = E._reg_bf16(prev.clone() if accumulate else torch.full_like(prev, float("nan")))
+        bs = torch.zeros(N, L.STAT_SLOTS, 2, dtype=torch.float64, device=DEV) if sums else None
+        dst = L.make_dst(grad, cin, fwd=fwd, aff=aff, act=L.ACT_LEAKY, accumulate=accumulate, bsums=bs)
+        info = E._conv_dgrad(E.Act(gy, cout).src(), N, Hs, Ws, 1, 4, 2, 1, 2 * Hs, 2 * Ws, wp, cout, cin, [dst], ksplit=1)
+        torch.cuda.synchronize()
+        res[q] = (grad, bs.sum(1).cpu() if sums else None, info & 0xF, bool(info & L.INFO_BSUMS))
+    assert res["1"][2] == 14 and res["0"][2] == 12, (res["1"][2], res["0"][2])
+    _ulp_close(res["1"][0], res["0"][0])
+    if sums:
+        assert res["1"][3] and res["0"][3]
+        assert float(((res["1"][1] - res["0"][1]).abs() / res["0"][1].abs().clamp_min(1e-9)).max()) < 2e-3
