@@ -1553,7 +1553,7 @@ static void launch_cfg(const ConvK& k, int amode, int bmode, int prec, bool dma,
 
 namespace pg { void launch_conv_bf16_big(const ConvK& k, int bn, dim3 grid, hipStream_t st); }   // igemm_bf16.hip
 namespace pg { void launch_conv_bf16_pair(const ConvK& k, int bn, dim3 grid, hipStream_t st); }  // igemm_bf16_pair.hip
-namespace pg { void launch_conv_bf16_quad(const ConvK& k, bool merged, dim3 grid, hipStream_t st); }  // igemm_bf16_quad.hip
+namespace pg { void launch_conv_bf16_quad(const ConvK& k, bool merged, int waves, dim3 grid, hipStream_t st); }  // igemm_bf16_quad.hip
 
 using namespace pg;
 
@@ -1950,16 +1950,19 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
         // halo patch goes global -> LDS once, the weight tile once per 512 rows.  Conditions: the 512-row tile lies inside one sample,
         // one image row of extra LDS rows fits (Gx <= ~128), enough tiles to fill the chip.
         bool quad = false;
+        int quad_bm = 512;           // 512: 8 waves, one workgroup per CU; 256: 4 waves, two per CU (the default: its prologue / epilogue overlap)
         {
           const char* qe = getenv("PG_BIG_QUAD");           // "0" / "1": read per launch (the test-suite flips it inside one process)
+          const char* qw = getenv("PG_QUAD_WAVES");         // "8" / "4": likewise
           static const long quad_min = getenv("PG_QUAD_MIN") ? atol(getenv("PG_QUAD_MIN")) : 512;
+          quad_bm = (qw && qw[0] == '8') ? 512 : 256;
           const int xs = merged ? 2 : 1, gg_ = k.Gy * k.Gx;
           bool want = (qe ? qe[0] != '0' : true) && (merged ? bn_l == 128 : (bn == 128 && ntb == 1 && k.n_cnt == 128)) &&
-                      gg_ % 512 == 0 && k.M % 512 == 0 && ctot % 32 == 0 && k.Wi < 32000 && k.Hi < 32000 &&
+                      gg_ % quad_bm == 0 && k.M % quad_bm == 0 && ctot % 32 == 0 && k.Wi < 32000 && k.Hi < 32000 &&
                       ((long)(k.M / 512) * k.nphase >= quad_min || getenv("PG_FORCE_BF16_BIG") != nullptr);
           if (want) {
-            const int max_rho = 511 + xs * ((k.Gx - 1 + 511) / k.Gx) + (merged ? 2 : 1) + k.Gx + xs;
-            want = max_rho <= 671;
+            const int max_rho = quad_bm - 1 + xs * ((k.Gx - 1 + quad_bm - 1) / k.Gx) + (merged ? 2 : 1) + k.Gx + xs;
+            want = max_rho <= (quad_bm == 512 ? 671 : 399);
           }
           for (int j = 0; j < d->nsrc && want; ++j)
             if ((double)d->N * d->Hi * d->Wi * d->src[j].C * 2.0 >= 4294967296.0 || k.cstart[j] % 32 != 0) want = false;
@@ -2004,9 +2007,9 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
           }
         }
         if (quad) {
-          const int mtq = k.M / 512;
-          k.xcd_swizzle = ((mtq % 8 == 0 && k.nphase > 1 && !env().no_xcd_swizzle) ? 1 : 0);
-          launch_conv_bf16_quad(k, merged, dim3(mtq, 1, k.nphase), st);
+          const int mtq = k.M / quad_bm;
+          k.xcd_swizzle = ((mtq % 8 == 0 && k.nphase > 1 && !env().no_xcd_swizzle) ? 1 : 0) | (int)env().debug_bits;
+          launch_conv_bf16_quad(k, merged, quad_bm == 512 ? 8 : 4, dim3(mtq, 1, k.nphase), st);
         }
         else if (merged) launch_conv_bf16_pair(k, 1000 + bn_l, dim3(mtb, 1, 2), st);
         else if (pair) launch_conv_bf16_pair(k, bn, dim3(mtb, ntb, k.nphase), st);

@@ -1,6 +1,7 @@
 """Command-line options with the reference's flag names (reference src_deformable/opts.py:14-97).
 Only flags the hot path reads are acted upon; path/dir side effects of the reference's parse() are limited to
-the experiment directories.  New flags: --synthetic, --align_corners, --vgg_weights, --steps."""
+the experiment directories.  New flags: --synthetic, --align_corners, --vgg_weights, --steps, --lazy_losses,
+--synthetic_ring, --timing_skip."""
 import argparse
 import os
 
@@ -62,6 +63,13 @@ class opts():
         p.add_argument("--vgg_weights", default=None, help="torchvision vgg19 state_dict for the content loss")
         p.add_argument("--steps", default=0, type=int, help="stop after this many iterations (0 = full schedule)")
         p.add_argument("--seed", default=1234, type=int)
+        p.add_argument("--lazy_losses", default=1, type=int,
+                       help="1 = the six loss scalars stay on the device and are read back once per --display_ratio iterations (the "
+                            "reference only prints them then, main.py:117-127); 0 = a device->host read-back per update")
+        p.add_argument("--synthetic_ring", default=0, type=int,
+                       help="--synthetic 1: cycle through this many pre-generated device batches instead of generating one on the host per "
+                            "call (0 = fresh batch every call; bench.py's loop uses 3)")
+        p.add_argument("--timing_skip", default=10, type=int, help="iterations left out of the steady-state img/s main() reports")
         p.add_argument("--save_samples", default=0, type=int, help="write train / test image grids every display_ratio iterations")
         p.add_argument("--save_at_end", default=0, type=int, help="write a checkpoint when --steps stops the run")
         p.add_argument("--deterministic_test", default=0, type=int, help="test.py: gen.eval() (no Dropout2d) before generating")

@@ -41,13 +41,16 @@ def quad_cases():
     ]
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
 @pytest.mark.parametrize("case", quad_cases() if torch.cuda.is_available() else [], ids=lambda c: c.name)
-def test_conv_bf16_quad_kernel(case, monkeypatch):
+def test_conv_bf16_quad_kernel(case, waves, monkeypatch):
     """conv_bf16_quad_kernel<false> forced on small problems: forward (fp32 output + fused statistics) and the data gradient of the
     conv cases with 128 input channels (four transposed phases, one quad each, fp32 destinations, fresh and accumulating).  Exact up
     to summation order against the fp32 contraction of the bf16-ROUNDED operands (1e-4 of the tensor max) and against the tap-pair
-    kernel on the same launch (reference models/networks.py:154-157: Conv2d / ConvTranspose2d k4 s2 p1 of a Block)."""
+    kernel on the same launch (reference models/networks.py:154-157: Conv2d / ConvTranspose2d k4 s2 p1 of a Block).  waves: the
+    8-wave form (512-row tiles, one workgroup per CU) and the 4-wave form (256-row tiles, two per CU: the default)."""
     monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_QUAD_WAVES", waves)
     monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
     monkeypatch.setenv("PG_BIG_PAIR", "1")
     monkeypatch.setenv("PG_BIG_MERGE", "0")
@@ -109,14 +112,16 @@ def _ulp_close(got, base):
 QGEOM = [(2, 16, 64), (1, 8, 128), (3, 32, 48)]       # (N, H, W) of the small grid: H W % 512 == 0, W >= 43
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
 @pytest.mark.parametrize("cins", [(128,), (64, 64), (64,)])
 @pytest.mark.parametrize("geom", QGEOM)
-def test_quad_merged_forward(cins, geom, monkeypatch):
+def test_quad_merged_forward(cins, geom, waves, monkeypatch):
     """conv_bf16_quad_kernel<true>: the transposed k4 s2 convolution with 64 output channels as 512 x (2 x 64) tiles per phase pair —
     ONE A tile per channel chunk serves the 2 x 2 taps of both x-phases.  Against the x-phase merged tap-pair kernel (itself
     bit-equal to the tap-pair kernel, which is checked against torch): equal up to fp32 summation order, i.e. one bf16 ulp of the
     stored value; statistics to 1e-3 of their size."""
     monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_QUAD_WAVES", waves)
     monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
     monkeypatch.setenv("PG_BIG_PAIR", "1")
     monkeypatch.setenv("PG_BIG_MERGE", "1")
@@ -138,13 +143,15 @@ def test_quad_merged_forward(cins, geom, monkeypatch):
     assert float(((res["1"][1] - res["0"][1]).abs() / res["0"][1].abs().clamp_min(1e-9)).max()) < 1e-3
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
 @pytest.mark.parametrize("accumulate,sums", [(False, True), (True, False)])
 @pytest.mark.parametrize("geom", QGEOM)
-def test_quad_merged_data_gradient(accumulate, sums, geom, monkeypatch):
+def test_quad_merged_data_gradient(accumulate, sums, geom, waves, monkeypatch):
     """the same for the data gradient of a Conv2d(k4, s2, p1) with 64 INPUT channels (encoder level 1; reference
     models/networks.py:154, autograd of conv2d wrt its input): bf16 gradient and forward tensors, LeakyReLU derivative from the raw
     forward value + per-sample affine, fresh and accumulating destinations, the fused norm-backward sums."""
     monkeypatch.setattr(E, "PRECISION", 3)
+    monkeypatch.setenv("PG_QUAD_WAVES", waves)
     monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
     monkeypatch.setenv("PG_BIG_PAIR", "1")
     monkeypatch.setenv("PG_BIG_MERGE", "1")

@@ -63,7 +63,15 @@ def main():
     print("%s %s batch %d: call %.1f us (incl. operand materialisation), %.1f GFLOP, launch info %s" % (name, what, N, e0.elapsed_time(e1) * 1e3, flops / 1e9, hex(L.load().pg_last_conv_info()) if hasattr(L.load(), "pg_last_conv_info") else "-"))
     nw = 16384
     buf = np.zeros((nw, 16), dtype=np.uint64)
-    L.check(L.load().pg_debug_conv_timeline(buf.ctypes.data_as(ctypes.c_void_p), nw), "timeline")
+    code = L.load().pg_last_launch_info() & 0xF
+    if code in (13, 14):        # the tap-quad kernel (igemm_bf16_quad.hip) keeps its own stamps
+        fnq = L.load().pg_debug_conv_timeline_quad
+        fnq.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        fnq.restype = ctypes.c_int
+        L.check(fnq(buf.ctypes.data_as(ctypes.c_void_p), nw), "timeline (quad)")
+    else:
+        L.check(L.load().pg_debug_conv_timeline(buf.ctypes.data_as(ctypes.c_void_p), nw), "timeline")
+    print("kernel code", code)
     t = buf.astype(np.int64)
     live = t[:, 4] > t[:, 0]
     t = t[live]
