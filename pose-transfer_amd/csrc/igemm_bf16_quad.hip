@@ -67,6 +67,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_quad_kernel(const ConvK p) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         kTimelineQ[tl_id * QTL_SLOTS + 7] = xcc & 0xf;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        kTimelineQ[tl_id * QTL_SLOTS + 10] = hwid;
       }
       if (slot == 4) kTimelineQ[tl_id * QTL_SLOTS + 6] = wall_clock64();
     }
@@ -428,6 +431,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_quad2_kernel(const ConvK p) 
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         kTimelineQ[tl_id * QTL_SLOTS + 7] = xcc & 0xf;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        kTimelineQ[tl_id * QTL_SLOTS + 10] = hwid;
       }
       if (slot == 4) kTimelineQ[tl_id * QTL_SLOTS + 6] = wall_clock64();
     }

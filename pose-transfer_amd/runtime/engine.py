@@ -28,7 +28,7 @@ class KernelProfiler:
     (bench.py's `roofline` leg).  Not active inside the timed region."""
 
     CONV_TILES = {0: "128x128", 1: "128x64", 2: "64x64", 3: "128x32", 4: "256x256", 5: "256x128", 6: "512x64", 7: "512x128", 8: "256x256p", 9: "256x128p",
-                  10: "512x64p", 11: "256x256m", 12: "256x128m"}
+                  10: "512x64p", 11: "256x256m", 12: "256x128m", 13: "quad128", 14: "quad128m"}      # 13 / 14: igemm_bf16_quad.hip
     WGRAD_TILES = {0: "128x64", 1: "64x64", 2: "32x64", 3: "128x128", 4: "64x32", 5: "patch64xTapsCin", 6: "bf16-tr-256", 7: "bf16-stem"}
 
     def __init__(self):

@@ -93,6 +93,17 @@ def main():
             np.median(t[:, 8] - t[:, 3]) / mhz, np.median(t[:, 9] - t[:, 8]) / mhz, np.median(t[:, 4] - t[:, 9]) / mhz))
     if what == "fwd" and (t[:, 15] > t[:, 14]).all():
         print("  first 64-row call (stores + wave sums + LDS atomics): %.2f us" % (np.median(t[:, 15] - t[:, 14]) / mhz))
+    if code in (13, 14) and os.environ.get("PG_TL_DISPATCH"):
+        # dispatch pattern: which workgroups (linear launch index) shared a CU, in start order (HW_ID bits 8..15 + XCC id)
+        ids = np.nonzero(live)[0]
+        key = ((t[:, 10] >> 8) & 0xff) | (t[:, 7] << 8)
+        order = np.argsort(t[:, 5], kind="stable")
+        per = {}
+        for o in order:
+            per.setdefault(int(key[o]), []).append((int(ids[o]), float((t[o, 5] - t[:, 5].min()) / 100.0), float((t[o, 6] - t[:, 5].min()) / 100.0)))
+        print("  distinct CU keys:", len(per))
+        for kk in sorted(per)[:6]:
+            print("  cu %04x: %s" % (kk, " ".join("%d[%.0f-%.0f]" % e for e in per[kk][:10])))
     tot = (t[:, 4] - t[:, 0]) / mhz
     print("  %-10s median %7.2f us  mean %7.2f ; sum over WGs / 256 CUs = %.1f us" % ("total", np.median(tot), tot.mean(), tot.sum() / 256))
     # per-XCD workgroup counts and the idle tail
