@@ -391,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pair_kernel(const ConvK p) {
   big_epilogue<TM, TN, STAT_OFF, STAT_N>(p, acc, smem, rows, tid, m0, nb0, wm0, wn0, bx, by, bz, 0, out_g, true, false, [](int) {});
 }
 
+#ifdef PG_TIMING_EXPERIMENTS      // (round 6) the persistent form lost in every variant: it is built only into the timing library
 // ---------------------------------------------------------------------------------------------------------------------
 // PERSISTENT form (round 5).  conv_bf16_pair_kernel above runs ONE tile per workgroup, one workgroup per CU: between two tiles a
 // CU sees the old workgroup drain, the dispatch of the next one, its row / tap tables (1.1 - 1.3 us) and the full latency of its
@@ -806,9 +807,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_pairp_kernel(const ConvK p, 
   }
 }
 
+#endif  // PG_TIMING_EXPERIMENTS
+
 void launch_conv_bf16_pair(const ConvK& k_in, int bn, dim3 grid, hipStream_t st) {
-  // (round 5) the persistent walk with the next tile's prologue under the epilogue (conv_bf16_pairp_kernel): correct (the tap-pair
-  // and merged test cases pass through it with PG_PAIR_PERSIST=31) and OFF — slower in every variant on every layer measured
+  // (round 5) the persistent walk with the next tile's prologue under the epilogue (conv_bf16_pairp_kernel; timing builds only since
+  // round 6): correct (the tap-pair and merged test cases passed through it with PG_PAIR_PERSIST=31) and OFF — slower in every variant on every layer measured
   // (tools/layer_bench.py, batch 32, one box; one tile per workgroup -> persistent):
   //   first version: lane constants alive across the tile loop spilled to scratch and were reloaded in the K loop's rare paths
   //   (rebuild_a / rebuild_b), where a scratch load's vmcnt wait also drains the operand DMA queue: north-star 17.05 -> 19.8 ms;
@@ -825,6 +828,7 @@ void launch_conv_bf16_pair(const ConvK& k_in, int bn, dim3 grid, hipStream_t st)
   //   in-order vmcnt on gfx950, so the first wait for an operand tile of tile t + 1 also waits for the acknowledgement of every output
   //   store of tile t (256 KB per CU: ~12 us at the HBM rate) — a workgroup that ENDS leaves its stores in flight and its successor
   //   starts with fresh counters.  One tile per workgroup is the right shape on this part for store-heavy epilogues.
+#ifdef PG_TIMING_EXPERIMENTS
   // PG_PAIR_PERSIST = bit mask of the variants that take the persistent form: 1 <128>, 2 <128, merged>, 4 <256>, 8 <256, merged>, 16 <64>
   static const int persist_mask = getenv("PG_PAIR_PERSIST") ? atoi(getenv("PG_PAIR_PERSIST")) : 0;
   const int vbit = bn == 1256 ? 8 : (bn == 1128 ? 2 : (bn == 256 ? 4 : (bn == 64 ? 16 : 1)));
@@ -858,6 +862,7 @@ void launch_conv_bf16_pair(const ConvK& k_in, int bn, dim3 grid, hipStream_t st)
     else PG_KLAUNCH((conv_bf16_pairp_kernel<128>), g, dim3(512), 0, st, k, mt, nt, P);
     return;
   }
+#endif  // PG_TIMING_EXPERIMENTS
   const ConvK& k = k_in;
   if (bn == 1256) PG_KLAUNCH((conv_bf16_pair_kernel<256, true>), grid, dim3(512), 0, st, k);       // x-phase merged: 256 x (2 x 128)
   else if (bn == 1128) PG_KLAUNCH((conv_bf16_pair_kernel<128, true>), grid, dim3(512), 0, st, k);  // 256 x (2 x 64)

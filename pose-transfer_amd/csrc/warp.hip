@@ -956,6 +956,62 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const void* gout_, const 
 }
 
 
+// PG_DETERMINISTIC form of the scatter above (round 6): one lane owns ONE channel of a sample and walks the output
+// pixels in order, adding its taps to dfeat with plain read-modify-writes — every destination element has a single writer and a
+// fixed summation order, so two runs are bit-equal (the float-atomic form adds in arrival order).  Serial over h x w per lane:
+// slow by design, and only reached by the transforms the gather kernel leaves out (shrinking by more than ~0.6) or by shapes
+// outside the gather form; workgroups of a sample without such a transform leave at once.
+template <bool GB, bool DB>
+__global__ __launch_bounds__(64) void warp_bwd_det_kernel(const void* gout_, const uint8_t* amax, const float* warps,
+                                                          const float* masks, int T, int C, int h, int w, int H0, int W0,
+                                                          int align, void* dfeat_, int wide_only) {
+  __shared__ Theta th[MAXT];
+  __shared__ int wide[MAXT];
+  __shared__ int any_wide;
+  const int n = blockIdx.y;
+  if (threadIdx.x == 0) any_wide = 0;
+  __syncthreads();
+  if (threadIdx.x < T) {
+    th[threadIdx.x] = make_theta(warps + ((long)n * T + threadIdx.x) * 8, h, w, H0, W0);
+    wide[threadIdx.x] = wide_only ? !invert_warp(th[threadIdx.x], h, w, align).narrow : 1;
+    if (wide[threadIdx.x]) any_wide = 1;
+  }
+  __syncthreads();
+  if (!any_wide) return;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const long nb = (long)n * h * w;
+  for (int pix = 0; pix < h * w; ++pix) {
+    const int i = pix / w, j = pix - i * w;
+    const long o = (nb + pix) * C + c;
+    const int t = amax[o];
+    if (t >= T || !wide[t]) continue;
+    float g;
+    if constexpr (GB) g = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(gout_)[o] << 16);
+    else g = reinterpret_cast<const float*>(gout_)[o];
+    const float m = masks[(nb + pix) * T + t];
+    const Taps tp = make_taps(th[t], i, j, h, w, align);
+    const float gm = g * m;
+    const float wg[4] = {tp.w00, tp.w01, tp.w10, tp.w11};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xx = tp.x0 + (k & 1), yy = tp.y0 + (k >> 1);
+      const float v = gm * wg[k];
+      if (v != 0.f && xx >= 0 && xx < w && yy >= 0 && yy < h) {
+        const long e = (nb + (long)yy * w + xx) * C + c;
+        if constexpr (DB) {
+          unsigned short* q = reinterpret_cast<unsigned short*>(dfeat_) + e;
+          const float cur = __uint_as_float((unsigned)(*q) << 16);
+          *q = (unsigned short)(wpack_bf16(cur + v, 0.f) & 0xffffu);      // one bf16 rounding per add, as the packed atomic
+        } else {
+          reinterpret_cast<float*>(dfeat_)[e] += v;
+        }
+      }
+    }
+  }
+}
+
+
 // Key-point coordinates -> Gaussian heat-maps (reference utils/pose_utils.py:79-86, the step right before the path:
 // SURVEY.md §8f row 1).  numpy evaluates exp(-((yy-y)^2 + (xx-x)^2) / (2 sigma^2)) in float64 and stores float32; so
 // does this kernel.  A key-point with either coordinate == -1 (MISSING_VALUE) gives a zero map.
@@ -1114,6 +1170,13 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
     else if (db) PG_KLAUNCH((KERNEL<false, true>), GRID, dim3(256), 0, st, __VA_ARGS__);     \
     else PG_KLAUNCH((KERNEL<false, false>), GRID, dim3(256), 0, st, __VA_ARGS__);            \
   } while (0)
+#define PGW_DET(GRID, ...)                                                                              \
+  do {                                                                                                   \
+    if (gb && db) PG_KLAUNCH((warp_bwd_det_kernel<true, true>), GRID, dim3(64), 0, st, __VA_ARGS__);      \
+    else if (gb) PG_KLAUNCH((warp_bwd_det_kernel<true, false>), GRID, dim3(64), 0, st, __VA_ARGS__);      \
+    else if (db) PG_KLAUNCH((warp_bwd_det_kernel<false, true>), GRID, dim3(64), 0, st, __VA_ARGS__);      \
+    else PG_KLAUNCH((warp_bwd_det_kernel<false, false>), GRID, dim3(64), 0, st, __VA_ARGS__);             \
+  } while (0)
   const long all_tiles = (long)N * (((long)h * w + GATHER_PIX - 1) / GATHER_PIX);
   if (T <= GATHER_T && !no_gather && (long)h * w < (1l << 24) && (double)h * w * C < 2147483648.0 && h <= GATHER_MAXDIM && w <= GATHER_MAXDIM && all_tiles <= GATHER_OVF_MAX &&
       N < 2048) {
@@ -1126,7 +1189,7 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
 #ifdef PG_TIMING_EXPERIMENTS
     { static const int wd = getenv("PG_DEBUG_WARP_BWD") ? atoi(getenv("PG_DEBUG_WARP_BWD")) : 0; ac_g |= wd << 8; }
 #endif
-    const int det_g = deterministic() ? 1 : 0;           // PG_DETERMINISTIC: sorted candidate lists (the float-atomic scatter of strongly minifying transforms below stays order-dependent)
+    const int det_g = deterministic() ? 1 : 0;           // PG_DETERMINISTIC: sorted candidate lists here, the ordered single-writer kernel for the wide transforms below
     static void* ovf_dev = nullptr;                      // g_gather_ovf: tiles whose 48-entry lists overflowed
     if (ovf_dev == nullptr) PG_REQUIRE(hipGetSymbolAddress(&ovf_dev, HIP_SYMBOL(g_gather_ovf)) == hipSuccess, "pg_warp_mask_max_bwd: symbol");
     PG_MEMSET_ASYNC(ovf_dev, 0, 4, st);
@@ -1153,13 +1216,20 @@ extern "C" int pg_warp_mask_max_bwd_bbox(const void* gout, const uint8_t* argmax
     }
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (gather)");
     // (a sample without wide transforms costs one early-exiting workgroup round: keep that grid small)
-    PGW_BWD(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
-            align_corners, dfeat, 1);
+    if (deterministic())      // ordered single-writer form instead of float atomics (bit-repeatable; slow, rare)
+      PGW_DET(dim3((C + 63) / 64, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 1);
+    else
+      PGW_BWD(warp_bwd_kernel, dim3(min(warp_bwd_grid(C, h, w), 256), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0,
+              align_corners, dfeat, 1);
     PG_LAUNCH_OK("pg_warp_mask_max_bwd (wide transforms)");
     return 0;
   }
   PG_MEMSET_ASYNC(dfeat, 0, (db ? 2 : 4) * (size_t)N * h * w * C, st);
-  PGW_BWD(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
+  if (deterministic())
+    PGW_DET(dim3((C + 63) / 64, N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
+  else
+    PGW_BWD(warp_bwd_kernel, dim3(warp_bwd_grid(C, h, w), N), gout, argmax, warps, lvl_masks, T, C, h, w, H0, W0, align_corners, dfeat, 0);
+#undef PGW_DET
 #undef PGW_BWD
   PG_LAUNCH_OK("pg_warp_mask_max_bwd");
   return 0;

@@ -107,26 +107,29 @@ def test_deterministic_mode_repeats_bitwise(prec, monkeypatch, deterministic):
 def test_stream_schedules_are_bitwise_equal_in_deterministic_mode(prec, monkeypatch, deterministic):
     """ADVICE round 4 (the side-stream test's band had to be widened because run-to-run noise hid what it checks): with ordered
     sums the comparison is exact.  Single stream (no weight-gradient side stream, hence no auxiliary / second-encoder stream and
-    no optimiser ranges under the backward pass) == the default schedule (all four streams + EagerAdam), bit for bit, after three
-    iterations.  A missing stream dependency — a gradient read before it is written, a buffer reused too early, an Adam range
-    issued before the layer's data gradient has read the weights — changes bits here."""
+    no optimiser ranges under the backward pass) == every multi-stream schedule, bit for bit, after three iterations: the default
+    one (EagerAdam is OFF by default since the end of round 5), the one with the optimiser ranges under the backward pass
+    (EAGER_ADAM = True, set explicitly: ADVICE round 5) at every placement of the second encoder stream — the only legs in which
+    TWO streams release parameter ranges, i.e. EagerAdam.release's multi-stream wait logic — and the one without the second encoder
+    stream.  A missing stream dependency — a gradient read before it is written, a buffer reused too early, an Adam range issued
+    before the layer's data gradient has read the weights — changes bits here."""
     monkeypatch.setattr(E, "PRECISION", PREC[prec])
     monkeypatch.setattr(E, "SIDE_STREAM", False)
     ref = _run((128, 128), 4, 3)
     monkeypatch.setattr(E, "SIDE_STREAM", True)
-    got = _run((128, 128), 4, 3)
-    _assert_bitwise(ref, got, "single stream vs default schedule, " + prec)
-    # every placement of the second encoder stream, and the second stream alone without the optimiser ranges
+    monkeypatch.setattr(E, "EAGER_ADAM", False)
+    _assert_bitwise(ref, _run((128, 128), 4, 3), "single stream vs default schedule (no optimiser ranges), " + prec)
+    monkeypatch.setattr(E, "EAGER_ADAM", True)
+    _assert_bitwise(ref, _run((128, 128), 4, 3), "single stream vs all streams + optimiser ranges, " + prec)
+    # every placement of the second encoder stream WITH the optimiser ranges (two streams release parameters)
     for lvl in ("0", "3", "5"):
         monkeypatch.setenv("PG_ENC_PAR_LEVEL", lvl)
-        _assert_bitwise(ref, _run((128, 128), 4, 3), "PG_ENC_PAR_LEVEL=%s, %s" % (lvl, prec))
+        _assert_bitwise(ref, _run((128, 128), 4, 3), "PG_ENC_PAR_LEVEL=%s + optimiser ranges, %s" % (lvl, prec))
     monkeypatch.delenv("PG_ENC_PAR_LEVEL")
-    monkeypatch.setattr(E, "EAGER_ADAM", False)
-    _assert_bitwise(ref, _run((128, 128), 4, 3), "no optimiser ranges, " + prec)
-    monkeypatch.setattr(E, "EAGER_ADAM", True)
     monkeypatch.setattr(E, "ENC_PAR", False)
     _assert_bitwise(ref, _run((128, 128), 4, 3), "no second encoder stream, " + prec)
     monkeypatch.setattr(E, "ENC_PAR", True)
+    monkeypatch.setattr(E, "EAGER_ADAM", False)
     # the generator update's forward enqueued AHEAD of dis_update on its own stream and engine: same kernels, same dropout stream
     _assert_bitwise(ref, _run((128, 128), 4, 3, prefetch=True), "prefetched generator forward, " + prec)
 
@@ -177,6 +180,11 @@ def test_eager_adam_issues_ranges_under_the_backward_pass(monkeypatch):
 # profiles/round5_bf16_tolerance.txt: worst values over 3 seeds x 2 losses x 7 runs (float atomics: run-to-run spread) -> bars = 2 x worst,
 # rounded up.  out_max 0.0216, out_mean 0.00284, loss_rel 0.0250, grad 0.0999, grad_scalar_vec 0.0376.
 BF16_TOL = {"out_max": 0.045, "out_mean": 6e-3, "loss_rel": 5e-2, "grad": 0.2, "grad_scalar_vec": 0.08}
+# (round 6) direction / size error of every gradient TENSOR against the oracle's full tensors (seeds 93 / 94:
+# the oracle runs here anyway).  Observed (profiles/round6_bf16_gradient_cosine.txt, 2 seeds x 2 losses): worst cosine 0.9824, worst
+# relative L2 0.187 — both on the 8 x 8 -> 4 x 4 encoder weights (net.6), whose gradient is the smallest signal of the network; the review
+# proposed cosine >= 0.995, which this path does NOT meet on those tensors.  Bars = 2 x the observed deficit, as the other entries.
+BF16_FULL_TOL = {"grad_cos_min": 0.965, "grad_rel_l2_max": 0.38}
 # fp32, scalar gamma / beta gradients at 256 x 256: observed 0.0379 (l1) / 0.0654 (nn), the same in every run.  The 2e-2 of the 64 x 64
 # tests is below what the REFERENCE's own arithmetic determines at this size: the float32 oracle against the float64 oracle on the same
 # inputs differs by up to 0.040 / 0.069 on the same metric (tools/scalar_grad_noise.py; sums of ~1e7 signed terms that cancel to
@@ -254,6 +262,15 @@ def _step_256(name, seed, prec, monkeypatch):
         ggs = {k: _summ(v) for k, v in tr.last_gen_grads.items()}
         ref = {"dis": np.array(rdl), "gen": np.array(rgl), "out": rog[:, :, ::STRIDE, ::STRIDE],
                "dg": lambda k: dgs[k], "gg": lambda k: ggs[k]}
+        # (round 6) the oracle's FULL gradient tensors are here: direction and size error per tensor
+        full = {}
+        for pre, dev_g, ref_g in (("d/", dgr, tr.last_disc_grads), ("g/", ggr, tr.last_gen_grads)):
+            for k, v in dev_g.items():
+                if v.numel() > 1:
+                    a, b = v.detach().double().cpu().reshape(-1), ref_g[k].detach().double().reshape(-1)
+                    nb = float(b.norm())
+                    full[pre + k] = (float(a @ b) / max(float(a.norm()) * nb, 1e-300), float((a - b).norm()) / max(nb, 1e-300))
+        ref["full"] = full
     d = (og[:, :, ::STRIDE, ::STRIDE].cpu() - ref["out"]).abs()
     rel = lambda x, y: float(np.max(np.abs(np.array(x) - np.array(y)) / np.maximum(np.abs(np.array(y)), 5e-2)))
     obs = {"out_max": float(d.max()), "out_mean": float(d.mean()), "loss_rel": max(rel(dl, ref["dis"]), rel(gl, ref["gen"]))}
@@ -264,6 +281,13 @@ def _step_256(name, seed, prec, monkeypatch):
     obs["grad"] = max(v[1] for v in g.values() if v[0] == "tensor")
     obs["grad_scalar"] = max(v[1] for v in g.values() if v[0] == "scalar")
     obs["grad_scalar_vec"] = max(_scalar_vec(od_), _scalar_vec(og_))
+    if ref.get("full"):
+        obs["grad_cos_min"] = min(v[0] for v in ref["full"].values())
+        obs["grad_rel_l2_max"] = max(v[1] for v in ref["full"].values())
+        if os.environ.get("PG_TOL_STUDY") == "1":
+            wc = min((v[0], k) for k, v in ref["full"].items())
+            wl = max((v[1], k) for k, v in ref["full"].items())
+            print("TOLSTUDY6 %s seed %d %s: per-tensor cosine min %.5f (%s) | relative L2 max %.4f (%s)" % (name, seed, prec, wc[0], wc[1], wl[0], wl[1]))
     if os.environ.get("PG_TOL_STUDY") == "1":
         worst_t = max(((v[1], k) for k, v in g.items() if v[0] == "tensor"))
         worst_s = max(((v[1], k) for k, v in g.items() if v[0] == "scalar"))
@@ -282,6 +306,9 @@ def test_bf16_data_step_256_vs_reference(name, seed, monkeypatch):
     obs = _step_256(name, seed, "bf16_data", monkeypatch)
     bad = {k: (obs[k], tol) for k, tol in BF16_TOL.items() if not obs[k] <= tol}
     assert not bad, bad
+    if seed != 92:          # the oracle's full gradient tensors: per-tensor cosine and relative L2
+        assert obs["grad_cos_min"] >= BF16_FULL_TOL["grad_cos_min"], obs
+        assert obs["grad_rel_l2_max"] <= BF16_FULL_TOL["grad_rel_l2_max"], obs
 
 
 @pytest.mark.parametrize("name", ["l1", "nn"])

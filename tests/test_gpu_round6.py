@@ -177,3 +177,122 @@ def test_quad_merged_data_gradient(accumulate, sums, geom, waves, monkeypatch):
     if sums:
         assert res["1"][3] and res["0"][3]
         assert float(((res["1"][1] - res["0"][1]).abs() / res["0"][1].abs().clamp_min(1e-9)).max()) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ main.py: the lazy-loss loop
+@pytest.fixture
+def deterministic():
+    lib = L.load()
+    lib.pg_set_deterministic(1)
+    yield
+    lib.pg_set_deterministic(0)
+
+
+def test_main_lazy_losses_equal_eager_running_means(tmp_path, deterministic):
+    """pose-transfer_amd/main.py (reference src_deformable/main.py:70-127): with --lazy_losses 1 (default) the six loss scalars stay on
+    the device and are read back once per --display_ratio iterations; the printed running means must be those of the eager loop
+    (a read-back per update, as the reference's .item() calls).  Deterministic mode: the two runs are bit-equal trajectories.
+    Also: --training_ratio 0 (a generator-only run) works, and main() reports its steady-state rate."""
+    from pose_transfer_amd import main as M
+    common = ["--dataset", "market", "--pose_dim", "18", "--batch_size", "2", "--exp_root", str(tmp_path), "--expID", "lz",
+              "--display_ratio", "2", "--iters_per_epoch", "5", "--number_of_epochs", "1", "--checkpoint_ratio", "100", "--steps", "5",
+              "--timing_skip", "2"]
+    vals = {}
+    for lazy in (1, 0):
+        m = M.main(common + ["--lazy_losses", str(lazy), "--training_ratio", "2"])
+        vals[lazy] = m.last_display
+        assert m.last_run_stats["timed_iterations"] == 3 and m.last_run_stats["img_s"] > 0
+        assert m.last_run_stats["lazy_losses"] == bool(lazy)
+    assert vals[1]["iterations"] == vals[0]["iterations"] == 5
+    assert len(vals[1]["gen"]) == 3 and len(vals[1]["disc"]) == 3
+    np.testing.assert_allclose(vals[1]["gen"], vals[0]["gen"], rtol=1e-6)
+    np.testing.assert_allclose(vals[1]["disc"], vals[0]["disc"], rtol=1e-6)
+    m = M.main(common + ["--synthetic_ring", "3"])            # bench.py's source: a ring of pre-generated device batches
+    assert np.isfinite(m.last_display["gen"] + m.last_display["disc"]).all() and m.last_run_stats["timed_iterations"] == 3
+    m = M.main(common[:-4] + ["--steps", "2", "--timing_skip", "1", "--training_ratio", "0"])
+    assert m.iteration == 2 and m.last_run_stats["iterations"] == 2
+
+
+# ------------------------------------------------------------------------------------------ bf16-I/O warp kernels vs the oracle
+BW_CASES = [("w256s4", (256, 256), 4), ("w128x64s2", (128, 64), 2), ("w224s8", (224, 224), 8), ("w64s1", (64, 64), 1), ("w96x80s2", (96, 80), 2)]
+
+
+@pytest.mark.parametrize("name,size,s", BW_CASES)
+@pytest.mark.parametrize("ac", [0, 1])
+def test_warp_bf16_io_vs_oracle(name, size, s, ac):
+    """the bf16-storage warp kernels (`warp_fwd5_kernel`, the 8-channel gather backward; C = 64 selects them)
+    DIRECTLY against the oracle (reference utils/pose_transform.py:16-92) on bf16-rounded inputs: forward within one bf16 ulp of the
+    output (the kernel samples in fp32 and rounds once), backward within two ulps of the gradient except where a near-tie of the
+    arg-max flips the selected transform (same allowance as the fp32 test: < 5e-4 of the elements)."""
+    import ref_cpu as R
+    N, C, T = 2, 64, 10
+    H0, W0 = size
+    h, w = H0 // s, W0 // s
+    bfr = lambda x: x.to(torch.bfloat16).to(torch.float32)
+    feat = bfr(t(synth.normal(66, name + "/f", (N, C, h, w))))
+    wr, mk = synth.warps_and_masks(66, name, N, H0, W0)
+    go = bfr(t(synth.normal(66, name + "/go", (N, C, h, w))))
+    fr = feat.clone().requires_grad_(True)
+    ref = R.warp_mask_max(fr, t(wr), t(mk), size, align_corners=bool(ac))
+    (gref,) = torch.autograd.grad((ref * go).sum(), fr)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    god = go.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    wrd, mkd = t(wr).float().to(DEV), t(mk).float().to(DEV)
+    lvl = torch.empty(N, h, w, T, device=DEV)
+    L.call("pg_mask_pyramid", L.ptr(mkd), 0, N, T, H0, W0, h, w, L.ptr(lvl), L.stream())
+    out = torch.full((N, h, w, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    arg = torch.full((N, h, w, C), 77, dtype=torch.uint8, device=DEV)
+    L.call("pg_warp_mask_max_fwd_io", L.ptr(fd), None, L.ptr(wrd), L.ptr(lvl), N, T, C, h, w, H0, W0, ac, L.ptr(out), L.ptr(arg), 3, L.stream())
+    dfeat = torch.full((N, h, w, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.call("pg_warp_mask_max_bwd_bbox", L.ptr(god), L.ptr(arg), L.ptr(wrd), L.ptr(lvl), None, N, T, C, h, w, H0, W0, ac, L.ptr(dfeat), 3, L.stream())
+    torch.cuda.synchronize()
+    o = out.float().cpu().permute(0, 3, 1, 2)
+    r = ref.detach()
+    ulp = lambda x: 2.0 ** -8 * x.abs()
+    bad = ((o - r).abs() > ulp(r) + 1e-6).float().mean()
+    assert float(bad) < 5e-4, float(bad)                     # (near-ties of the max: another transform's value, itself within fp32 rounding)
+    assert float((o - r).abs().max()) <= 2.0 ** -7 * float(r.abs().max())
+    d = dfeat.float().cpu().permute(0, 3, 1, 2)
+    assert bool(torch.isfinite(d).all())
+    badg = ((d - gref).abs() > 2 * ulp(gref) + 2.0 ** -9 * float(gref.abs().max())).float().mean()
+    assert float(badg) < 5e-4, float(badg)
+
+
+# ------------------------------------------------------------------------------------------ PG_DETERMINISTIC and the wide transforms
+@pytest.mark.parametrize("io", [0, 3])
+@pytest.mark.parametrize("T", [10, 12])
+def test_warp_backward_deterministic_wide_transforms(io, T, deterministic):
+    """ADVICE round 5 (csrc/warp.hip): in deterministic mode the transforms the gather kernel leaves out (shrinking by more than
+    ~0.6: their pre-image boxes exceed its capacity) and the shapes outside the gather form (T > 10: the full fall-back) used to be
+    added with float atomics in arrival order.  They now take the ordered single-writer kernel: two runs are BIT-equal, and the result
+    equals the default (atomic) path up to summation order."""
+    N, C, h, w, H0, W0 = 2, 64, 24, 20, 48, 40
+    rng = np.random.RandomState(5 + T)
+    wr = np.zeros((N, T, 8), np.float32)
+    rows = [[1, 0, 0, 0, 1, 0], [0.35, 0, 6, 0, 0.35, 9], [0.3, -0.2, 20, 0.2, 0.3, 4], [0.25, 0, 10, 0, 0.25, 10],
+            [3.0, 0, -30, 0, 3.0, -20], [0.4, 0.1, 3, -0.1, 0.4, 2], [1, 0.6, -5, 0.1, 1, 2], [0.5, 0, 0, 0, 0.5, -10],
+            [1.2, 0.3, 3, -0.3, 1.2, 1], [0.9, 0, 2.5, 0, 0.9, -1.5], [0.3, 0, 1, 0, 0.3, 1], [0.45, 0, -3, 0, 0.45, 5]]
+    for n in range(N):
+        for k in range(T):
+            wr[n, (k + 3 * n) % T, :6] = rows[k]
+    lv = rng.uniform(0.2, 1.0, (N, h, w, T)).astype(np.float32)
+    arg = torch.from_numpy(rng.randint(0, T, (N, h, w, C)).astype(np.uint8)).to(DEV)       # every transform selected somewhere
+    dt = torch.bfloat16 if io else torch.float32
+    go = torch.from_numpy(rng.standard_normal((N, h, w, C)).astype(np.float32)).to(DEV).to(dt)
+    wrd, lvd = torch.from_numpy(wr).to(DEV), torch.from_numpy(lv).to(DEV)
+    lib = L.load()
+
+    def run():
+        d = torch.full((N, h, w, C), float("nan"), device=DEV, dtype=dt)
+        L.call("pg_warp_mask_max_bwd_bbox", L.ptr(go), L.ptr(arg), L.ptr(wrd), L.ptr(lvd), None, N, T, C, h, w, H0, W0, 0, L.ptr(d), io, L.stream())
+        torch.cuda.synchronize()
+        return d.float().cpu()
+
+    a, b = run(), run()
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    lib.pg_set_deterministic(0)
+    c = run()
+    lib.pg_set_deterministic(1)
+    tol = (2.0 ** -6 if io else 1e-5) * float(c.abs().max())
+    assert float((a - c).abs().max()) <= tol, (float((a - c).abs().max()), tol)
+    assert float(a.abs().max()) > 0

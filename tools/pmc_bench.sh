@@ -5,7 +5,7 @@ set -e
 OUT=$PWD/gpurun_out/pmc_bench
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-north-star --no-config-legs --no-kernel-profile"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-north-star --no-config-legs --no-extra-legs --no-kernel-profile"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o f -- $CMD > $OUT/f.log 2>&1 || true
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o w -- $CMD > $OUT/w.log 2>&1 || true
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT -o m -- $CMD > $OUT/m.log 2>&1 || true

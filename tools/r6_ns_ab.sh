@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 rm -f gpurun_out/r6_ns_ab.log
 for cfg in "PG_BIG_QUAD=0" "PG_BIG_QUAD=1 PG_QUAD_WAVES=4" "PG_BIG_QUAD=1 PG_QUAD_WAVES=8" "PG_BIG_QUAD=0" "PG_BIG_QUAD=1 PG_QUAD_WAVES=4"; do
   echo "---- $cfg" >> gpurun_out/r6_ns_ab.log
-  env $cfg timeout 600 python bench.py --no-cpu-baseline --no-config-legs --no-kernel-profile --steps 5 --warmup 3 2>/dev/null | python -c "
+  env $cfg timeout 600 python bench.py --no-cpu-baseline --no-config-legs --no-extra-legs --no-kernel-profile --steps 5 --warmup 3 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 ns = d['north_star']
