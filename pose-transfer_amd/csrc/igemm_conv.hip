@@ -1950,12 +1950,16 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
         // halo patch goes global -> LDS once, the weight tile once per 512 rows.  Conditions: the 512-row tile lies inside one sample,
         // one image row of extra LDS rows fits (Gx <= ~128), enough tiles to fill the chip.
         bool quad = false;
-        int quad_bm = 512;           // 512: 8 waves, one workgroup per CU; 256: 4 waves, two per CU (the default: its prologue / epilogue overlap)
+        // 512: 8 waves, one workgroup per CU (the default); 256: 4 waves, two per CU.  Alone on the chip the 4-wave form is the faster one
+        // (enc.1 forward 172 against 181 us: one workgroup's prologue / epilogue beside the other's K loop), but inside the training pass,
+        // next to the weight-gradient / encoder streams' one-workgroup-per-CU kernels, it LOSES: north-star pass + 0.10 ms against - 0.07 ms
+        // for the 8-wave form, alternating arms in one process (tools/quad_inproc_ab.py, profiles/round6_quad_inproc_ab.txt).
+        int quad_bm = 512;
         {
           const char* qe = getenv("PG_BIG_QUAD");           // "0" / "1": read per launch (the test-suite flips it inside one process)
           const char* qw = getenv("PG_QUAD_WAVES");         // "8" / "4": likewise
           static const long quad_min = getenv("PG_QUAD_MIN") ? atol(getenv("PG_QUAD_MIN")) : 512;
-          quad_bm = (qw && qw[0] == '8') ? 512 : 256;
+          quad_bm = (qw && qw[0] == '4') ? 256 : 512;
           const int xs = merged ? 2 : 1, gg_ = k.Gy * k.Gx;
           bool want = (qe ? qe[0] != '0' : true) && (merged ? bn_l == 128 : (bn == 128 && ntb == 1 && k.n_cnt == 128)) &&
                       gg_ % quad_bm == 0 && k.M % quad_bm == 0 && ctot % 32 == 0 && k.Wi < 32000 && k.Hi < 32000 &&

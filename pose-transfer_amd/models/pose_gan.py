@@ -23,6 +23,10 @@ from .networks import Deformable_Generator, Discriminator, Generator, Stacked_Ge
 
 _PF_STREAMS = {}            # device index -> the prefetch stream (prefetch_gen_forward)
 GEN_PREFETCH = os.environ.get("PG_NO_GEN_PREFETCH") is None
+# (round 6) the prefetched forward keeps a second GeneratorEngine (a full set of activation / operand buffers)
+# resident; it pays where launches leave CUs idle — small per-GPU batches (256^2 batch 4: 632 -> 707 img/s) — and buys nothing at
+# batch 32 or 512^2.  On only up to this many input pixels per batch (default: 12 images of 256 x 256).
+GEN_PREFETCH_MAX_PIX = int(os.environ.get("PG_GEN_PREFETCH_MAX_PIX", str(12 * 256 * 256)))
 
 
 class FusedAdam:
@@ -151,11 +155,13 @@ class DeformablePose_GAN(nn.Module):
     # own stream and into its own engine (activation buffers), that forward runs NEXT TO dis_update's work instead of
     # after it.  Same kernels, same dropout stream (`call="g"` of this iteration), same results — gen_update recognises the
     # prefetched pass by its input tensors and the arena's weight version and otherwise computes the forward as before.
-    # Single-stage generators only, not in replay sessions.  PG_NO_GEN_PREFETCH=1 switches it off.
+    # Single-stage generators only, not in replay sessions, small per-GPU batches only (GEN_PREFETCH_MAX_PIX).  PG_NO_GEN_PREFETCH=1
+    # switches it off.
     def prefetch_gen_forward(self, input, other_inputs):
         self._pf = None
         if not (GEN_PREFETCH and self.gen_type != "stacked" and self.deformable and E.REPLAY_CTR is None and E.SIDE_STREAM
-                and torch.is_tensor(input) and input.is_cuda):
+                and torch.is_tensor(input) and input.is_cuda
+                and input.shape[0] * input.shape[2] * input.shape[3] <= GEN_PREFETCH_MAX_PIX):
             return False
         input = input.contiguous()
         if getattr(self, "_pf_stream", None) is None:

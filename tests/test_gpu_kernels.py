@@ -841,6 +841,7 @@ def test_conv_bf16_big_kernel(case, variant, monkeypatch):
     # step along x (every k4 s2 launch; k3 and 1x1 launches cannot pair and take the plain kernel)
     monkeypatch.setenv("PG_BIG_PAIR", "1" if variant == "pair" else "0")
     monkeypatch.setenv("PG_BIG_MERGE", "0")          # (round 5: the x-phase merged form has its own tests, tests/test_gpu_round5.py)
+    monkeypatch.setenv("PG_BIG_QUAD", "0")           # (round 6: the tap-quad kernels have their own tests, tests/test_gpu_round6.py)
     monkeypatch.setenv("PG_BIG_128_VARIANT", "256" if variant == "pair" else variant)
     if variant == "512" and case.cout != 128 and case.cin != 128:
         pytest.skip("no 128-column launch in this case")

@@ -73,7 +73,7 @@ def test_bf16_data_path_contractions_at_north_star_shapes(case, monkeypatch):
     got = case.run_forward(ks, stats=stats)
     info = L.load().pg_last_launch_info()
     if case.name.startswith("xcd"):
-        assert (info & 0xF) in (4, 5, 7, 8, 9), "the 256-row kernel did not run (tile id %d)" % (info & 0xF)
+        assert (info & 0xF) in (4, 5, 7, 8, 9, 13), "the 256-row kernel did not run (tile id %d)" % (info & 0xF)      # (13: the round-6 tap-quad kernel)
     assert rel(got, ref) < 1e-4, (case.name, float(rel(got, ref)))
     o64 = got.double().reshape(case.N, -1)
     st = stats.cpu().sum(1)
@@ -84,7 +84,7 @@ def test_bf16_data_path_contractions_at_north_star_shapes(case, monkeypatch):
     for acc in (False, True):
         dgot = case.run_dgrad(ks, acc)
         if case.name.startswith("xcd"):
-            assert (L.load().pg_last_launch_info() & 0xF) in (4, 5, 7, 8, 9)
+            assert (L.load().pg_last_launch_info() & 0xF) in (4, 5, 7, 8, 9, 13)
         for g, r in zip(dgot, dref):
             assert rel(g, r) < 1e-4, (case.name, acc, float(rel(g, r)))
     dw = case.run_wgrad(0)

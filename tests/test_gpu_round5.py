@@ -511,6 +511,7 @@ def test_x_phase_merged_forward(cout, cins, geom, monkeypatch):
     monkeypatch.setattr(E, "PRECISION", 3)
     monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
     monkeypatch.setenv("PG_BIG_PAIR", "1")
+    monkeypatch.setenv("PG_BIG_QUAD", "0")           # (round 6: the quad forms are compared with these kernels in tests/test_gpu_round6.py)
     N, H, W = geom
     cin = sum(cins)
     xs = [_bf("x%d/%s%s" % (j, geom, cins), (N, H, W, c)) for j, c in enumerate(cins)]
@@ -539,6 +540,7 @@ def test_x_phase_merged_data_gradient(cin, accumulate, sums, geom, monkeypatch):
     monkeypatch.setattr(E, "PRECISION", 3)
     monkeypatch.setenv("PG_FORCE_BF16_BIG", "1")
     monkeypatch.setenv("PG_BIG_PAIR", "1")
+    monkeypatch.setenv("PG_BIG_QUAD", "0")
     N, Hs, Ws = geom                      # the gradient arrives on the small grid, the destination is 2 Hs x 2 Ws
     cout = 256
     tag = "%s/%d" % (geom, cin)
