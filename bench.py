@@ -550,8 +550,8 @@ BF16_PMC_NAMES = {
     "conv_igemm<256x256m,A0,B0>": "void pg::conv_bf16_pair_kernel<256, true>(pg::ConvK)",
     "conv_igemm<256x128m,A0,B0>": "void pg::conv_bf16_pair_kernel<128, true>(pg::ConvK)",
     "conv_igemm<256x256,A0,B0>": "void pg::conv_bf16_big_kernel<256, 64>(pg::ConvK)",
-    "conv_igemm<quad128,A0,B0>": "void pg::conv_bf16_quad2_kernel<false>(pg::ConvK)",
-    "conv_igemm<quad128m,A0,B0>": "void pg::conv_bf16_quad2_kernel<true>(pg::ConvK)",
+    "conv_igemm<quad128,A0,B0>": "void pg::conv_bf16_quad_kernel<false>(pg::ConvK)",
+    "conv_igemm<quad128m,A0,B0>": "void pg::conv_bf16_quad_kernel<true>(pg::ConvK)",
 }
 BF16_PMC_NAMES_R4 = {k: v.replace(", false>", ">") for k, v in BF16_PMC_NAMES.items()}      # (round 4: one template parameter)
 

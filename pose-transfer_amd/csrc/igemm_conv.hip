@@ -1958,7 +1958,9 @@ static int conv_impl(const pg_conv_t* d, const TapBatch* tb, void* stream) {
         {
           const char* qe = getenv("PG_BIG_QUAD");           // "0" / "1": read per launch (the test-suite flips it inside one process)
           const char* qw = getenv("PG_QUAD_WAVES");         // "8" / "4": likewise
-          static const long quad_min = getenv("PG_QUAD_MIN") ? atol(getenv("PG_QUAD_MIN")) : 512;
+          // >= 4 rounds of 512-row workgroups: with 512 tiles (two rounds) the discriminator's 128 -> 256 data gradient at batch 64 ran
+          // 154 us here against 134 us on the tap-pair kernel's 1024 tiles (profiles/round6_launch_table_b32_bf16_data.txt, first version)
+          static const long quad_min = getenv("PG_QUAD_MIN") ? atol(getenv("PG_QUAD_MIN")) : 1024;
           quad_bm = (qw && qw[0] == '4') ? 256 : 512;
           const int xs = merged ? 2 : 1, gg_ = k.Gy * k.Gx;
           bool want = (qe ? qe[0] != '0' : true) && (merged ? bn_l == 128 : (bn == 128 && ntb == 1 && k.n_cnt == 128)) &&
