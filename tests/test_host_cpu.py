@@ -102,6 +102,32 @@ def test_synthetic_source_shapes():
             assert tuple(b[2].shape) == (2, T, 8)
 
 
+def test_synthetic_ring_and_loss_log():
+    """main.py (round 6): --synthetic_ring K hands out K pre-generated batches round-robin (the fresh source's first K batches); LossLog
+    keeps lazily returned loss triples as tensors and moves them to the host in one copy when the means are asked for (where the
+    reference prints them, main.py:117-127) — the running means equal those of eagerly read-back floats."""
+    from pose_transfer_amd import main as M
+    base = ["--dataset", "market", "--pose_dim", "18", "--batch_size", "2"]
+    fresh = M.SyntheticSource(opts().parse(base), "cpu")
+    ring = M.SyntheticSource(opts().parse(base + ["--synthetic_ring", "2"]), "cpu")
+    f = [fresh.next() for _ in range(2)]
+    r = [ring.next() for _ in range(5)]
+    for i in range(5):
+        for a, b in zip(r[i], f[i % 2]):
+            assert torch.equal(a.float(), b.float())
+    assert r[2][0] is r[0][0]                                   # the ring re-uses its tensors
+    lazy, eager = M.LossLog(), M.LossLog()
+    rng = np.random.RandomState(3)
+    for i in range(7):
+        v = rng.uniform(0, 3, 3).astype(np.float32)
+        lazy.append(torch.from_numpy(v.copy()))
+        eager.append([float(x) for x in v])
+        if i in (2, 6):
+            assert len(lazy.pending) > 0
+            np.testing.assert_allclose(lazy.means(), eager.means(), rtol=1e-7)
+            assert not lazy.pending and len(lazy.host) == i + 1
+
+
 # ---------------------------------------------------------------------------------------------- pipeline helpers
 def test_peak_cords_equals_render_and_read_back():
     """peak_cords == map_to_cord(cords_to_map(.)) — what the reference does for the interpolated poses."""
