@@ -104,6 +104,24 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_quad_kernel(const ConvK p) {
     const int q = tid - 64;
     taps_l[MAXTAP + q] = (p.dy[2 + phase][q] & 0xff) | ((p.dx[2 + phase][q] & 0xff) << 8) | ((int)p.wtap[2 + phase][q] << 16);
   }
+  {
+    RowB ri;
+    const int m = m0 + tid;
+    ri.n = -1; ri.opix = 0; ri.iy = 0; ri.ix = 0; ri.oy = 0; ri.ox = 0;
+    if (m < p.M) {
+      const int rem = rem0 + tid;
+      const int qy = rem / gx;
+      const int qx = rem - qy * gx;
+      const int oy = qy * p.so + p.phy[phase];
+      const int ox = qx * p.so + p.phx[phase];
+      if (oy < p.Ho && ox < p.Wo) {
+        ri.n = n_s; ri.iy = (short)(qy * p.si); ri.ix = (short)(qx * p.si); ri.oy = (short)oy; ri.ox = (short)ox;
+        ri.opix = (n_s * p.Ho + oy) * p.Wo + ox;
+        if (MG) ri.opix >>= 1;                            // pixel PAIR (ox = 2 qx, Wo even): the epilogues' rows are 2 Cout wide
+      }
+    }
+    rows[tid] = ri;
+  }
   for (int rho = tid; rho < AROWS; rho += 512) {          // LDS row -> (local image row j, slot k): rho + qx0 = j (Gx + XS) + k
     const int t = rho + qx0;
     const int j = t / IR, k = t - j * IR;
@@ -111,7 +129,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_quad_kernel(const ConvK p) {
     a.iy = (short)((qy0 + j) * p.si); a.ix = (short)(k * p.si);
     reinterpret_cast<QRow*>(smem + AROW_OFF)[rho] = a;
   }
-  __syncthreads();                                  // (the loaders' tables; the epilogue's row table is built behind the first DMAs)
+  __syncthreads();
+  stamp(1);
 
   const int cpt = p.Ctot / 32;                      // channel chunks per quad
   const int nsteps = PG_DBG(p, 8) ? 1 : (ntap >> 2) * cpt;      // (quad, chunk) steps; four tiles each  (bit 3: PG_DEBUG_ONE_KTILE, fixed-cost experiment)
@@ -281,26 +300,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_quad_kernel(const ConvK p) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) issue_b(t);
   advance_b();
-  {
-    RowB ri;
-    const int m = m0 + tid;
-    ri.n = -1; ri.opix = 0; ri.iy = 0; ri.ix = 0; ri.oy = 0; ri.ox = 0;
-    if (m < p.M) {
-      const int rem = rem0 + tid;
-      const int qy = rem / gx;
-      const int qx = rem - qy * gx;
-      const int oy = qy * p.so + p.phy[phase];
-      const int ox = qx * p.so + p.phx[phase];
-      if (oy < p.Ho && ox < p.Wo) {
-        ri.n = n_s; ri.iy = (short)(qy * p.si); ri.ix = (short)(qx * p.si); ri.oy = (short)oy; ri.ox = (short)ox;
-        ri.opix = (n_s * p.Ho + oy) * p.Wo + ox;
-        if (MG) ri.opix >>= 1;                            // pixel PAIR (ox = 2 qx, Wo even): the epilogues' rows are 2 Cout wide
-      }
-    }
-    rows[tid] = ri;
-  }
-  stamp(1);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
