@@ -21,6 +21,13 @@ from pose_transfer_amd.utils import synth  # noqa: E402
 
 ARMS = [("quad off", {"PG_BIG_QUAD": "0"}), ("quad 4-wave", {"PG_BIG_QUAD": "1", "PG_QUAD_WAVES": "4"}),
         ("quad 8-wave", {"PG_BIG_QUAD": "1", "PG_QUAD_WAVES": "8"})]
+# PG_AB_ARMS="name:K=V,K=V;name2:K=V" replaces the arms (the first one is the reference); only PER-LAUNCH switches make sense here
+if os.environ.get("PG_AB_ARMS"):
+    ARMS = []
+    for a in os.environ["PG_AB_ARMS"].split(";"):
+        nm, _, kv = a.partition(":")
+        ARMS.append((nm, dict(x.split("=", 1) for x in kv.split(",") if x)))
+KEYS = sorted({k for _, e in ARMS for k in e})
 
 
 def main():
@@ -44,7 +51,7 @@ def main():
         eng.backward(gout)
 
     def setenv(env):
-        for k in ("PG_BIG_QUAD", "PG_QUAD_WAVES"):
+        for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(env)
 
@@ -69,11 +76,11 @@ def main():
             res[nm].append(e0.elapsed_time(e1) / passes)
     for nm, _ in ARMS:
         a = np.array(res[nm])
-        print("%-12s mean %.3f ms  median %.3f  min %.3f  max %.3f  (%d rounds x %d passes)" % (nm, a.mean(), np.median(a), a.min(), a.max(), rounds, passes))
+        print("%-16s mean %.3f ms  median %.3f  min %.3f  max %.3f  (%d rounds x %d passes)" % (nm, a.mean(), np.median(a), a.min(), a.max(), rounds, passes))
     base = np.array(res[ARMS[0][0]])
     for nm, _ in ARMS[1:]:
         d = np.array(res[nm]) - base
-        print("%-12s - off: mean %+.3f ms, per-round %s" % (nm, d.mean(), " ".join("%+.2f" % x for x in d)))
+        print("%-16s - ref: mean %+.3f ms, per-round %s" % (nm, d.mean(), " ".join("%+.2f" % x for x in d)))
 
 
 if __name__ == "__main__":
