@@ -65,6 +65,14 @@ struct Env {
   }
 };
 inline const Env& env() { static const Env e; return e; }
+// Integer tuning knob: read from the environment ONCE (the caller keeps the value in a function-local static) — unless the process was
+// started with PG_DYN_ENV=1, in which case every launch re-reads it, so that tools/quad_inproc_ab.py can alternate the arms of an A/B
+// inside one process (box-to-box and process-to-process drift cancel).  Every value selects a correct path.
+inline bool dyn_env() { static const bool d = getenv("PG_DYN_ENV") != nullptr; return d; }
+inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#define PG_ENV_INT(var, name, dflt)              \
+  static const int var##_static = pg::env_int(name, dflt); \
+  const int var = pg::dyn_env() ? pg::env_int(name, dflt) : var##_static
 
 // PG_DETERMINISTIC (round 5; pg_set_deterministic / the environment variable at load time): every launch path whose result
 // depends on an arrival order is replaced by an ordered one — split-K contractions only through the workspace + fix-up pass (or

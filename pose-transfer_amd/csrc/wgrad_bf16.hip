@@ -638,7 +638,7 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
       // workgroups per launch (x 4 taps each): 256 at batch 32 (north-star pass 17.05 ms; 128: 17.34, 384: 17.34), 128 at small
       // batch — every split adds a full set of float atomics on dW next to main-stream launches that are latency-bound themselves
       // (round 5, bf16 data path, 256 / 128 / 64: batch 4 608 / 634 / 591 img/s, batch 8 829 / 845 / 756, batch 16 1021 / 1016 / -)
-      static const int target4_env = getenv("PG_WGTR4_TARGET") ? atoi(getenv("PG_WGTR4_TARGET")) : 0;
+      PG_ENV_INT(target4_env, "PG_WGTR4_TARGET", 0);
       const int target4 = target4_env > 0 ? target4_env : (N <= 12 ? 128 : 256);
       const long base4 = (long)mt4 * nt4 * 4;
       int ks4 = (int)((target4 + base4 - 1) / base4);
@@ -695,7 +695,7 @@ extern "C" int pg_wgrad_bf16_ex(const void* x_bf16, int32_t Cx, const void* dy_b
     // with >= 128 K tiles: dec.2 418 -> 349 us, enc.4 135 -> 117 us; in the pass, next to the main stream's kernels, the same rule
     // LOSES: north-star 18.22 -> 18.33 ms, batch-32 step 1110 -> 1100 img/s.  Kept at 128.)
     const long base = (long)mt * nt * 16;
-    static const int target = getenv("PG_WGTR_TARGET") ? atoi(getenv("PG_WGTR_TARGET")) : 128;
+    PG_ENV_INT(target, "PG_WGTR_TARGET", 128);
     // thin tiles with a long K (the discriminator's 64 -> 128 layer on 63 x 63 maps: one 128 x 64 tile per tap, 1985 K tiles — 0.59 ms
     // per launch at batch 32 with 8 splits): these are latency-bound per workgroup, so they take 512 workgroups
     static const int thin_target = getenv("PG_WGTR_THIN_TARGET") ? atoi(getenv("PG_WGTR_THIN_TARGET")) : 512;

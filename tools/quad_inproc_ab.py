@@ -33,7 +33,7 @@ KEYS = sorted({k for _, e in ARMS for k in e})
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     passes = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-    N, size, kp = 32, 256, 18
+    N, size, kp = int(os.environ.get("PG_AB_BATCH", "32")), 256, 18
     E.PRECISION = 3
     o = SimpleNamespace(image_size=(size, size), use_input_pose=True, pose_dim=kp, batch_size=N, num_stacks=4, gen_type="baseline",
                         dataset="fasion", warp_skip="mask", learning_rate=2e-4, content_loss_layer="none", nn_loss_area_size=1,
@@ -49,6 +49,14 @@ def main():
         model.gen.zero_grad()
         eng.forward(inp, wr, mk)
         eng.backward(gout)
+
+    if os.environ.get("PG_AB_MODE") == "step":        # the full training iteration (dis_update + gen_update, 3 batches) instead of the pass
+        import bench
+        batches = [dev(synth.batch(1234, "ns/%s" % s_, N, kp, size, size)) for s_ in "ABC"]
+        od = dict(vars(o), lazy_losses=True)
+
+        def one_pass():  # noqa: F811
+            bench.iteration(model, batches, od)
 
     def setenv(env):
         for k in KEYS:
