@@ -233,6 +233,11 @@ int pg_stem_wgrad_bf16(const pg_src_t* src, int32_t nsrc, int32_t N, int32_t Hi,
 int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t stride,
                        int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out,
                        int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream);
+/* (round 6) the same with dY in bf16 STORAGE (io_flags bit 0): the stage-to-stage chain of the stacked generator on the bf16 data path
+ * (reference models/networks.py:306-327: stage i's image input is stage i-1's output; autograd of the first Conv2d, networks.py:186). */
+int pg_small_cin_dgrad_io(const void* dY, const float* W, int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t stride,
+                          int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out, int64_t oN,
+                          int64_t oC, int64_t oH, int64_t oW, int32_t io_flags, void* stream);
 
 /* db[c] += sum over rows of a strided [rows][C] view (bias gradient; torch autograd of conv bias). */
 int pg_bias_grad(const float* dY, int64_t rows_outer, int64_t rows_inner, int32_t C, int64_t s_outer,

@@ -496,7 +496,7 @@ extern "C" int pg_small_cin_conv(const pg_src_t* src, int32_t nsrc, int32_t N, i
 namespace pg {
 
 struct SmallCinDgradK {
-  const float* dY;     // NHWC [N][Ho][Wo][64]
+  const void* dY;      // NHWC [N][Ho][Wo][64], fp32 or (DYB) bf16
   const float* W;      // packed [K*K][64][Cin]
   float* out;
   long oN, oC, oH, oW;
@@ -505,7 +505,8 @@ struct SmallCinDgradK {
 
 // K, S compile-time: the tap loops unroll, and for S = 2 only the K/2 x K/2 taps of the pixel's parity class are visited
 // (the generic form spent most of its instructions on runtime divisions and parity tests: 73 us for 4 images).
-template <int K, int S>
+// DYB (round 6): dY is a bf16 tensor (bf16 STORAGE of the generator: the stage-to-stage chain of the stacked generator).
+template <int K, int S, bool DYB = false>
 __global__ __launch_bounds__(256) void small_cin_dgrad_kernel(const SmallCinDgradK p) {
   __shared__ __attribute__((aligned(16))) float wl[K * K * 4 * 64];          // [tap][c (4)][co]
   for (int i = threadIdx.x; i < K * K * 4 * 64; i += 256) {
@@ -534,7 +535,13 @@ __global__ __launch_bounds__(256) void small_cin_dgrad_kernel(const SmallCinDgra
         const int oy = (S == 1) ? ty : (ty >> 1), ox = (S == 1) ? tx : (tx >> 1);
         const bool ok = (ty >= 0) & (tx >= 0) & (oy < p.Ho) & (ox < p.Wo);
         const long off = ok ? (((long)n * p.Ho + oy) * p.Wo + ox) * 64 + l16 * 4 : 0;
-        g[a * NR + b] = *reinterpret_cast<const float4*>(p.dY + off);
+        if constexpr (DYB) {
+          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.dY) + off);
+          g[a * NR + b] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                      __uint_as_float(u.y & 0xffff0000u));
+        } else {
+          g[a * NR + b] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dY) + off);
+        }
         if (!ok) g[a * NR + b] = make_float4(0.f, 0.f, 0.f, 0.f);
         wt[a * NR + b] = wl + (r * K + s2) * 256 + l16 * 4;
       }
@@ -558,9 +565,10 @@ __global__ __launch_bounds__(256) void small_cin_dgrad_kernel(const SmallCinDgra
 
 }  // namespace pg
 
-extern "C" int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t stride,
-                                  int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out,
-                                  int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream) {
+// io_flags: bit 0 = dY is bf16
+extern "C" int pg_small_cin_dgrad_io(const void* dY, const float* W, int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t stride,
+                                     int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out,
+                                     int64_t oN, int64_t oC, int64_t oH, int64_t oW, int32_t io_flags, void* stream) {
   PG_REQUIRE(dY && W && out && N > 0 && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0, "pg_small_cin_dgrad: bad arguments");
   PG_REQUIRE(((K == 3 && stride == 1) || (K == 4 && stride == 2)) && nc >= 1 && nc <= 4 && c_off >= 0 && c_off + nc <= Cin,
              "pg_small_cin_dgrad: k3 s1 or k4 s2, 1..4 channels (got k%d s%d nc=%d c_off=%d Cin=%d)", K, stride, nc, c_off, Cin);
@@ -569,8 +577,21 @@ extern "C" int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, in
   k.N = N; k.Ho = Ho; k.Wo = Wo; k.Hi = Hi; k.Wi = Wi; k.K = K; k.S = stride; k.pad = pad; k.Cin = Cin; k.c_off = c_off; k.nc = nc;
   long blocks = ((long)N * Hi * Wi + 15) / 16;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (K == 3) PG_KLAUNCH((pg::small_cin_dgrad_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
-  else PG_KLAUNCH((pg::small_cin_dgrad_kernel<4, 2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  const bool dyb = (io_flags & 1) != 0;
+  const dim3 grid((unsigned)blocks);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 3) {
+    if (dyb) PG_KLAUNCH((pg::small_cin_dgrad_kernel<3, 1, true>), grid, dim3(256), 0, st, k);
+    else PG_KLAUNCH((pg::small_cin_dgrad_kernel<3, 1, false>), grid, dim3(256), 0, st, k);
+  } else {
+    if (dyb) PG_KLAUNCH((pg::small_cin_dgrad_kernel<4, 2, true>), grid, dim3(256), 0, st, k);
+    else PG_KLAUNCH((pg::small_cin_dgrad_kernel<4, 2, false>), grid, dim3(256), 0, st, k);
+  }
   PG_LAUNCH_OK("pg_small_cin_dgrad");
   return 0;
+}
+extern "C" int pg_small_cin_dgrad(const float* dY, const float* W, int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t stride,
+                                  int32_t pad, int32_t Hi, int32_t Wi, int32_t Cin, int32_t c_off, int32_t nc, float* out,
+                                  int64_t oN, int64_t oC, int64_t oH, int64_t oW, void* stream) {
+  return pg_small_cin_dgrad_io(dY, W, N, Ho, Wo, K, stride, pad, Hi, Wi, Cin, c_off, nc, out, oN, oC, oH, oW, 0, stream);
 }

@@ -8,6 +8,8 @@ return NCHW fp32 tensors like the reference; parameters live in a flat packed ar
 so ``loss.backward(); optimizer.step()`` works, while the trainer (models/pose_gan.py) drives the
 engines directly without an autograd tape.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -115,8 +117,7 @@ class Deformable_Generator(_ArenaModule):
     def engine(self, n, stage=0):
         """Engine (activation buffers + schedules) of one forward at batch n; `stage` separates the chained forwards
         of the stacked generator, which must all stay alive until the backward pass."""
-        # engines are built for ONE storage mode (bf16 STORAGE on the bf16 data path, runtime/engine.py); the chained stages of
-        # the stacked generator back-propagate an image gradient through the first layer and keep fp32 storage
+        # engines are built for ONE storage mode (bf16 STORAGE on the bf16 data path, runtime/engine.py)
         key = (n, stage, E.bf16_store() and getattr(self, "bf16_store_ok", True))
         if key not in self._engines:
             self._engines[key] = E.GeneratorEngine(
@@ -146,7 +147,9 @@ class Stacked_Generator(nn.Module):
         self.nfilters_enc, self.nfilters_dec, self.use_input_pose = tuple(nfilters_enc), tuple(nfilters_dec), use_input_pose
         self.generator = Deformable_Generator(input_nc, pose_dim, image_size, nfilters_enc, nfilters_dec, warp_skip,
                                               use_input_pose, align_corners, device)
-        self.generator.bf16_store_ok = False      # the chained backward needs the image gradient of the first layer (fp32 path)
+        # (round 6) the chained backward's image gradient of the first layer reads the bf16 gradient tensor (pg_small_cin_dgrad_io):
+        # the stages run in bf16 STORAGE on the bf16 data path like the single-stage generator; PG_STACKED_F32_STORE=1 = the round-5 mode
+        self.generator.bf16_store_ok = os.environ.get("PG_STACKED_F32_STORE") is None
 
     @property
     def arena(self):

@@ -1736,8 +1736,6 @@ class GeneratorEngine:
         for e in self.encs:
             dz = self.e_dz[e][0]
             s0 = self._enc_in_src(e, self.input)
-            if self.bfs:
-                assert image_grad is None, "bf16 storage: the chained (stacked) generator keeps fp32 storage"
             # (round 4) the first layer's weight-gradient pass delivers the bias gradient as well where it can; where it cannot,
             # the bias-gradient kernel goes FIRST (main stream, before the weight-gradient call: the reducer's ordering invariant)
             fuse = self.enc[0] == 64 and _stem_bias_fusable(3, 1, 1, s0.C)
@@ -1755,9 +1753,11 @@ class GeneratorEngine:
             if image_grad is not None and e in ("encoder_app", "encoder"):
                 # data-gradient of the k3/s1/p1 first convolution restricted to its 3 image channels, written NCHW
                 assert image_grad.is_contiguous() and tuple(image_grad.shape) == (N, 3, H, W)
-                if self.enc[0] == 64 and SMALL_CIN_DGRAD:
-                    L.call("pg_small_cin_dgrad", L.ptr(dz), L.ptr(A.p(e + ".net.0.weight")), N, H, W, 3, 1, 1, H, W, s0.C, 0, 3,
-                           L.ptr(image_grad), 3 * H * W, H * W, W, 1, L.stream())
+                if self.enc[0] == 64 and (SMALL_CIN_DGRAD or self.bfs):
+                    # (round 6) bf16 STORAGE: dz is a bf16 tensor — the streaming kernel reads it as such (io_flags bit 0), so the
+                    # chained stages of the stacked generator run in the storage mode of the single-stage generator
+                    L.call("pg_small_cin_dgrad_io", L.ptr(dz), L.ptr(A.p(e + ".net.0.weight")), N, H, W, 3, 1, 1, H, W, s0.C, 0, 3,
+                           L.ptr(image_grad), 3 * H * W, H * W, W, 1, 1 if self.bfs else 0, L.stream())
                 else:
                     _conv([Act(dz, self.enc[0]).src()], N, H, W, L.ACT_NONE, 1, 3, 1, 1, H, W, A.p(e + ".net.0.weight"),
                           self.enc[0], s0.C, transposed=True, out=image_grad, out_strides=(3 * H * W, H * W, W, 1),

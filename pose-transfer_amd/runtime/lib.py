@@ -75,6 +75,7 @@ _PROTOS = {
     "pg_dropout_mask_ctr": [_vp, _i64, _u64, _f32, _vp, _vp],
     "pg_adam_ctr": [_vp, _vp, _vp, _vp, _vp, _i64, C.c_double, C.c_double, _f32, _f32, _i64, _vp, _f32, _vp, _vp],
     "pg_small_cin_dgrad": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _vp],
+    "pg_small_cin_dgrad_io": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pg_stem_pack_elems": [_i32, _i32],
     "pg_stem_pack_bf16": [_vp, _i32, _i32, _vp, _vp],
     "pg_stem_conv_bf16": [C.POINTER(Src), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],

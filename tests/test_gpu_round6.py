@@ -296,3 +296,69 @@ def test_warp_backward_deterministic_wide_transforms(io, T, deterministic):
     tol = (2.0 ** -6 if io else 1e-5) * float(c.abs().max())
     assert float((a - c).abs().max()) <= tol, (float((a - c).abs().max()), tol)
     assert float(a.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------ stacked generator in bf16 STORAGE
+@pytest.mark.parametrize("K,S,pad,cin,c_off,nc", [(3, 1, 1, 21, 0, 3), (4, 2, 0, 42, 21, 3)])
+def test_small_cin_dgrad_bf16_gradient_tensor(K, S, pad, cin, c_off, nc):
+    """pg_small_cin_dgrad_io (csrc/edge.hip): the image gradient of a first-layer convolution from a bf16 gradient tensor equals the
+    fp32 kernel on the bf16-rounded values (same arithmetic after the load) and torch's conv_transpose2d (reference: autograd of
+    nn.Conv2d, models/networks.py:186,341)."""
+    N, Ho, Wo = 2, 24, 20
+    Hi, Wi = (Ho, Wo) if S == 1 else (2 * Ho + 2, 2 * Wo + 2)
+    dy = t(synth.normal(67, "scd/dy%d" % K, (N, Ho, Wo, 64))).to(torch.bfloat16)
+    w = t(synth.normal(67, "scd/w%d" % K, (K, K, 64, cin))).float()
+    outs = []
+    for bf in (True, False):
+        src = dy.to(DEV) if bf else dy.float().to(DEV)
+        out = torch.full((N, nc, Hi, Wi), float("nan"), device=DEV)
+        L.call("pg_small_cin_dgrad_io", L.ptr(src), L.ptr(w.to(DEV)), N, Ho, Wo, K, S, pad, Hi, Wi, cin, c_off, nc, L.ptr(out),
+               nc * Hi * Wi, Hi * Wi, Wi, 1, 1 if bf else 0, L.stream())
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    wt = w.permute(2, 3, 0, 1)[:, c_off:c_off + nc].contiguous()                  # (Cout = 64, nc, K, K): conv weight restricted to the image channels
+    ref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wt, None, stride=S, padding=pad)
+    ref = F.pad(ref, (0, Wi - ref.shape[3], 0, Hi - ref.shape[2]))
+    assert rel(outs[0], ref) < 1e-5
+
+
+def test_stacked_generator_bf16_storage_step_vs_golden(monkeypatch):
+    """gen_type='stacked' on the bf16 data path in bf16 STORAGE (round 6; reference networks.py:290-327, pose_gan.py:72-77,120-125):
+    until round 5 the chained stages kept fp32 storage because the stage-to-stage image gradient was an fp32-only kernel.  One
+    dis_update + gen_update against the REAL reference's capture (tests/golden/stacked.npz) within the bf16 envelope of the 64 x 64
+    fixtures (out_gen 6e-2 max-abs, losses 5e-2, gradient summaries 0.2 of the tensor max: tests/test_gpu_round3.py BF16_GRAD_TOL),
+    and every stage's engine must be in the storage mode."""
+    from pose_transfer_amd.models.pose_gan import DeformablePose_GAN
+    from types import SimpleNamespace
+    from test_gpu_round2 import stacked_inputs, _summ
+    monkeypatch.setattr(E, "PRECISION", 3)
+    fix = np.load(os.path.join(GOLDEN, "stacked.npz"))
+    P, H, W, N, S = 18, 64, 64, 2, 2
+    enc, dec = synth.nfilters((H, W))
+    opt = SimpleNamespace(image_size=(H, W), use_input_pose=True, pose_dim=P, batch_size=N, num_stacks=S, gen_type="stacked",
+                          dataset="fasion", warp_skip="mask", learning_rate=2e-4, content_loss_layer="none", nn_loss_area_size=1,
+                          gan_penalty_weight=1.0, l1_penalty_weight=100.0)
+    model = DeformablePose_GAN(opt, device=DEV)
+    tpd = lambda d: {k: t(v) for k, v in d.items()}
+    model.gen.generator.load_state_dict(tpd(synth.init_params(73, "stk/step/gen", synth.generator_spec(P, enc, dec), 0.1)))
+    model.disc.load_state_dict(tpd(synth.init_params(73, "stk/step/disc", synth.discriminator_spec(42), 0.1)))
+    od = vars(opt)
+    devs = lambda xs: [x.to(DEV) for x in xs]
+    bA, bB, bC = [devs(stacked_inputs(73, "stk/step/%s" % s, N, P, H, W, S)) for s in "ABC"]
+    dA = [devs([t(m) for m in synth.dropout_masks(73, "stk/step/dA%d" % s, N)]) for s in range(S)]
+    dC = [devs([t(m) for m in synth.dropout_masks(73, "stk/step/dC%d" % s, N)]) for s in range(S)]
+    oi = lambda b, d: {"interpol_pose": b[2], "interpol_warps": b[3], "interpol_masks": b[4], "drop_masks": d}
+    dl = model.dis_update(bA[0], bA[1], oi(bA, dA), bB[0], bB[1], od)
+    og, outputs, gl = model.gen_update(bC[0], bC[1], oi(bC, dC), od)
+    engs = [model._core.engine(N, i) for i in range(S)]
+    assert all(e.bfs for e in engs), "the stacked stages did not take bf16 storage"
+    np.testing.assert_allclose(dl, fix["step_dis_losses"], rtol=5e-2, atol=5e-3)
+    np.testing.assert_allclose(gl, fix["step_gen_losses"], rtol=5e-2, atol=5e-3)
+    assert len(outputs) == S and maxdiff(og, t(fix["step_out_gen"])) < 6e-2 and maxdiff(outputs[0], t(fix["step_out0"])) < 6e-2
+    worst = 0.0
+    for k, g in model._core.arena.grad_dict().items():
+        ref = fix["step_ggrad_generator." + k]
+        if g.numel() > 1 and not np.all(ref[3:] == ref[3]):
+            worst = max(worst, float(np.abs(_summ(g)[2:] - ref[2:]).max() / max(ref[2], 1e-12)))
+    assert worst <= 0.2, worst
