@@ -259,10 +259,11 @@ class Discriminator(_ArenaModule):
         self._anchor = nn.Parameter(torch.zeros(1, device=device))
 
     def engine(self, m):
-        if m not in self._engines:
-            self._engines[m] = E.DiscriminatorEngine(self.arena, m, self.image_size[0], self.image_size[1],
-                                                     self.pose_dim, self.device)
-        return self._engines[m]
+        key = (m, E.bf16_store() and E.DISC_BF16_STORE)          # engines are built for ONE storage mode (runtime/engine.py)
+        if key not in self._engines:
+            self._engines[key] = E.DiscriminatorEngine(self.arena, m, self.image_size[0], self.image_size[1],
+                                                       self.pose_dim, self.device)
+        return self._engines[key]
 
     def forward(self, x):
         return _DiscFn.apply(x, self, self._anchor)

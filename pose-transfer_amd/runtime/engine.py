@@ -591,6 +591,7 @@ NORM_BWD_BF16 = os.environ.get("PG_NO_NORM_BWD_BF16") is None    # ablation swit
 FUSE_NORM_SUMS = os.environ.get("PG_NO_FUSED_NORM_SUMS") is None   # ablation switch: norm backward's reduce pass always runs
 STEM_EMIT_BF16 = os.environ.get("PG_NO_STEM_EMIT_BF16") is None  # ablation switch: separate materialisation of the level-0 output
 STEM_BF16 = os.environ.get("PG_NO_STEM_BF16") is None     # ablation switch: fp32 first-layer kernels on the bf16 data path
+DISC_BF16_STORE = os.environ.get("PG_DISC_F32_STORE") is None   # (round 6) bf16 STORAGE for the discriminator; the switch = round 5's fp32 storage
 
 
 def stem_pack_floats(K, cin):
@@ -1793,8 +1794,20 @@ class DiscriminatorEngine:
             ws.append((ws[-1] + 2 - 4) // 2 + 1)
         assert hs[-1] >= 1 and ws[-1] >= 1
         self.hs, self.ws = hs, ws
-        self.raw = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
-        self.dz = [torch.empty(M, hs[j], ws[j], self.chans[j], **f32) for j in range(self.nblk)]
+        # bf16 STORAGE (round 6; the generator's since round 3): the stem's and the first blocks' raw outputs and the gradients that
+        # flow through them are bf16 tensors — everything up to the LAST normalised block, whose output (15 x 15 x 512 at 256^2: 6 %
+        # of the network's activation elements) and gradient stay fp32 because the three kernels of the one-output-channel last
+        # block (forward, weight gradient, data gradient: csrc/edge.hip, pg_conv_wgrad) read fp32 tensors.  No new kernel is needed
+        # below that: the stem writes bf16 (pg_stem_conv_bf16_v3), the 256-row / generic bf16 kernels store and scatter bf16, norm
+        # forward / backward and the weight gradients take either dtype, the stem's weight / image gradients read bf16
+        # (pg_stem_wgrad_bf16_v2, pg_small_cin_dgrad_io).  PG_DISC_F32_STORE=1 = the round-5 mode.
+        self.bfs = bool(bf16_store() and STEM_BF16 and STEM_EMIT_BF16 and DISC_BF16_STORE and 3 + 2 * pose_dim + 3 <= 80 and self.nblk >= 4
+                        and all(c % 128 == 0 for c in self.chans[1:-1]) and torch.cuda.is_available())
+        nbf = self.nblk - 2 if self.bfs else 0          # blocks 0 .. nbf - 1 in bf16
+        dt = lambda j: dict(dtype=torch.bfloat16 if j < nbf else torch.float32, device=device)
+        self.raw = [_reg_bf16(torch.empty(M, hs[j], ws[j], self.chans[j], **dt(j))) for j in range(self.nblk)]
+        self.dz = [_reg_bf16(torch.empty(M, hs[j], ws[j], self.chans[j], **dt(j))) for j in range(self.nblk)]
+        self._dz0_views = {}
         self.nscr = NormScratch(self.nblk, M, device)
         self.norm = [NormState(M, device, self.nscr) if 0 < j < self.nblk - 1 else None for j in range(self.nblk)]
         self.wt0 = torch.empty(stem_pack_floats(4, 3 + 2 * pose_dim + 3), **f32)          # [Cin][16][64] repack of the stem
@@ -1849,14 +1862,24 @@ class DiscriminatorEngine:
         if PRECISION == 3 and STEM_BF16 and STEM_EMIT_BF16 and _BF_CTX is not None and 3 + 2 * self.P + 3 <= 80:
             bf0 = _BF_CTX.reserve(L.ptr(self.raw[0]), 64, L.ACT_LEAKY, None, None, self.M * self.hs[0] * self.ws[0] * 64,
                                   self.raw[0].device)
+        assert self.bfs == (bf16_store() and self.bfs), "the engine was built for another storage mode (PRECISION changed?)"
         for pair in pairs:
             n = pair[0].shape[0]
             assert all(t.is_contiguous() and t.dtype == torch.float32 for t in pair)
             srcs = self._stem_srcs(pair)
-            out_ptr = self.raw[0].data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
-            _small_cin_conv(srcs, n, H, W, 4, 2, 0, A.p("net.0.weight"), A.p("net.0.bias"), self.wt0, out_ptr,
-                            next_act=L.ACT_LEAKY,
-                            bf_ptr=None if bf0 is None else bf0.data_ptr() + 2 * off * self.hs[0] * self.ws[0] * 64)
+            esz = 2 if self.bfs else 4
+            out_ptr = self.raw[0].data_ptr() + esz * off * self.hs[0] * self.ws[0] * 64
+            bfp = None if bf0 is None else bf0.data_ptr() + 2 * off * self.hs[0] * self.ws[0] * 64
+            if self.bfs:
+                # bf16 STORAGE: the raw output as bf16 and the next block's LeakyReLU operand in the same pass
+                assert bfp is not None
+                L.call("pg_stem_pack_bf16", L.ptr(A.p("net.0.weight")), 4, sum(a.C for a in srcs), L.ptr(self.wt0), L.stream())
+                arr = (L.Src * len(srcs))(*[a.src() for a in srcs])
+                L.call("pg_stem_conv_bf16_v3", arr, len(srcs), n, H, W, 4, 2, 0, L.ptr(self.wt0), L.ptr(A.p("net.0.bias")), None,
+                       out_ptr, L.ACT_NONE, bfp, L.ACT_LEAKY, None, L.ACT_NONE, L.stream())
+            else:
+                _small_cin_conv(srcs, n, H, W, 4, 2, 0, A.p("net.0.weight"), A.p("net.0.bias"), self.wt0, out_ptr,
+                                next_act=L.ACT_LEAKY, bf_ptr=bfp)
             off += n
         assert off == self.M
         for j in range(1, self.nblk):
@@ -1926,14 +1949,24 @@ class DiscriminatorEngine:
         off = 0
         for pi, pair in enumerate(self.inputs):
             n = pair[0].shape[0]
-            dptr = dz0.data_ptr() + 4 * off * self.hs[0] * self.ws[0] * 64
+            dptr = dz0.data_ptr() + (2 if self.bfs else 4) * off * self.hs[0] * self.ws[0] * 64
+            if self.bfs:
+                # this pair's slice of the bf16 gradient as a registered tensor: the weight-gradient dispatch recognises bf16 STORAGE
+                # by the tensor behind the pointer
+                v = self._dz0_views.get((off, n))
+                if v is None:
+                    v = self._dz0_views[(off, n)] = _reg_bf16(dz0[off:off + n])
+                assert v.data_ptr() == dptr
             if need_wgrad:
                 # (round 4) the stem's weight-gradient pass delivers this pair's share of the bias gradient where it can; where it
                 # cannot, the bias-gradient kernel goes first (see GeneratorEngine._backward_stems)
                 fuse = _stem_bias_fusable(4, 2, 0, cin)
                 if not fuse:
                     _debug_delay()
-                    L.call("pg_bias_grad", dptr, n * self.hs[0] * self.ws[0], 1, 64, 64, 0, 1, L.ptr(A.g("net.0.bias")), L.stream())
+                    if self.bfs:
+                        L.call("pg_bias_grad_bf16", dptr, n * self.hs[0] * self.ws[0], 64, L.ptr(A.g("net.0.bias")), L.stream())
+                    else:
+                        L.call("pg_bias_grad", dptr, n * self.hs[0] * self.ws[0], 1, 64, 64, 0, 1, L.ptr(A.g("net.0.bias")), L.stream())
                 done = _wgrad([a.src() for a in self._stem_srcs(pair)], n, L.ACT_NONE, dptr, 64, cin, True, self.hs[0],
                               self.ws[0], H, W, 4, 2, 0, A.g("net.0.weight"), scalar_x=True, dbias=A.g("net.0.bias") if fuse else None)
                 assert bool(done) == bool(fuse), "stem bias gradient: the launch code and _stem_bias_fusable disagree"
@@ -1941,9 +1974,9 @@ class DiscriminatorEngine:
                 g = image_grad[pi]
                 s = L.Src()
                 s.ptr, s.C = dptr, 64
-                if SMALL_CIN_DGRAD:       # streaming kernel: 16 lanes per image pixel (GEMM-N = 3 wastes a 32-wide MFMA tile)
-                    L.call("pg_small_cin_dgrad", dptr, L.ptr(A.p("net.0.weight")), n, self.hs[0], self.ws[0], 4, 2, 0, H, W, cin,
-                           3 + self.P, 3, L.ptr(g), 3 * H * W, H * W, W, 1, L.stream())
+                if SMALL_CIN_DGRAD or self.bfs:       # streaming kernel: 16 lanes per image pixel (GEMM-N = 3 wastes a 32-wide MFMA tile)
+                    L.call("pg_small_cin_dgrad_io", dptr, L.ptr(A.p("net.0.weight")), n, self.hs[0], self.ws[0], 4, 2, 0, H, W, cin,
+                           3 + self.P, 3, L.ptr(g), 3 * H * W, H * W, W, 1, 1 if self.bfs else 0, L.stream())
                 else:
                     _conv([s], n, self.hs[0], self.ws[0], L.ACT_NONE, 1, 4, 2, 0, H, W, A.p("net.0.weight"), 64, cin,
                           transposed=True, out=g, out_strides=(3 * H * W, H * W, W, 1), n_off=3 + self.P, n_cnt=3)
