@@ -38,8 +38,8 @@ CLASSES = {
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     passes = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-    N, size, kp = 32, 256, 18
-    E.PRECISION = 3
+    N, size, kp = int(os.environ.get("PG_AB_BATCH", "32")), 256, 18
+    E.PRECISION = {"f32": 0, "bf16_data": 3}[os.environ.get("PG_AB_PRECISION", "bf16_data")]
     o = SimpleNamespace(image_size=(size, size), use_input_pose=True, pose_dim=kp, batch_size=N, num_stacks=4, gen_type="baseline",
                         dataset="fasion", warp_skip="mask", learning_rate=2e-4, content_loss_layer="none", nn_loss_area_size=1,
                         gan_penalty_weight=1.0, l1_penalty_weight=100.0)
@@ -74,6 +74,40 @@ def main():
         eng.forward(inp, wr, mk)
         eng.backward(gout)
 
+    if os.environ.get("PG_AB_MODE") == "step":        # the full training iteration (dis_update + gen_update, 3 batches) instead of the pass
+        import bench
+        batches = [dev(synth.batch(1234, "ns/%s" % s_, N, kp, size, size)) for s_ in "ABC"]
+        od = dict(vars(o), lazy_losses=True)
+        raw_wg = lib.pg_conv_wgrad
+
+        def wg_wrapper(d, st):
+            rc = raw_wg(d, st)
+            if state["pred"] is not None and state["pred"]("pg_conv_wgrad", None):
+                raw_wg(d, st)
+            return rc
+
+        lib.pg_conv_wgrad = wg_wrapper
+        CLASSES.pop("weight gradients (pg_wgrad_bf16_ex)")
+        CLASSES["weight gradients (pg_wgrad_bf16_ex / pg_conv_wgrad)"] = lambda n, d: n in ("pg_wgrad_bf16_ex", "pg_conv_wgrad")
+        CLASSES["first-layer weight gradients"] = lambda n, d: n.startswith("pg_stem_wgrad") or n == "pg_small_cin_wgrad"
+        CLASSES["first-layer forward"] = lambda n, d: n.startswith("pg_stem_conv") or n in ("pg_small_cin_conv", "pg_repack_small_cin")
+        CLASSES["norm finalize / stats"] = lambda n, d: n in ("pg_norm_finalize", "pg_norm_stats")
+        CLASSES["norm backward (reduce + apply)"] = lambda n, d: n.startswith("pg_norm_bwd")
+        CLASSES.pop("norm backward apply")
+        CLASSES["Adam"] = lambda n, d: n.startswith("pg_adam")
+        CLASSES["losses, tanh, edge layers of D"] = lambda n, d: n in ("pg_gan_logloss", "pg_l1_loss", "pg_tanh_bwd", "pg_add2", "pg_small_cout_dgrad",
+                                                                        "pg_small_cin_dgrad", "pg_small_cin_dgrad_io", "pg_bias_grad", "pg_bias_grad_bf16")
+        CLASSES["dropout masks, zero fills, stream waits"] = lambda n, d: n in ("pg_dropout_mask", "pg_zero", "pg_stream_wait", "pg_copy")
+        if os.environ.get("PG_AB_GLUE"):               # the glue calls one by one
+            for k in list(CLASSES):
+                CLASSES.pop(k)
+            for nm in ("pg_stream_wait", "pg_zero", "pg_dropout_mask", "pg_copy", "pg_norm_finalize", "pg_add2", "pg_tanh_bwd", "pg_gan_logloss",
+                       "pg_l1_loss", "pg_mask_pyramid", "pg_mask_bbox", "pg_stem_pack_bf16", "pg_repack_small_cin", "pg_bias_grad"):
+                CLASSES[nm] = (lambda want: (lambda n, d: n == want))(nm)
+
+        def one_pass():  # noqa: F811
+            bench.iteration(model, batches, od)
+
     def timed(pred):
         state["pred"] = pred
         one_pass()
@@ -104,7 +138,7 @@ def main():
             dbl[nm].append(timed(pred))
         base.append(timed(None))
     b = float(np.mean(base))
-    print("pass %.3f ms (multi-stream), %.3f ms single-stream; %d rounds x %d passes" % (b, ss_base, rounds, passes))
+    print("%s, batch %d, %s: %.3f ms (multi-stream), %.3f ms single-stream; %d rounds x %d passes" % (os.environ.get("PG_AB_MODE", "pass"), N, os.environ.get("PG_AB_PRECISION", "bf16_data"), b, ss_base, rounds, passes))
     print("%-44s %10s %12s %9s" % ("class (every launch issued twice)", "alone ms", "pass + ms", "exposure"))
     tot_a = tot_d = 0.0
     for nm in CLASSES:
