@@ -27,6 +27,7 @@ GEN_PREFETCH = os.environ.get("PG_NO_GEN_PREFETCH") is None
 # resident; it pays where launches leave CUs idle — small per-GPU batches (256^2 batch 4: 632 -> 707 img/s) — and buys nothing at
 # batch 32 or 512^2.  On only up to this many input pixels per batch (default: 12 images of 256 x 256).
 GEN_PREFETCH_MAX_PIX = int(os.environ.get("PG_GEN_PREFETCH_MAX_PIX", str(12 * 256 * 256)))
+ZERO_ON_PREFETCH = os.environ.get("PG_NO_ZERO_ON_PREFETCH") is None      # (round 6) gen.zero_grad() on the prefetch stream
 
 
 class FusedAdam:
@@ -178,8 +179,15 @@ class DeformablePose_GAN(nn.Module):
             self._core.arena.bf16_params()      # (first use after load_state_dict converts: on THIS stream, before the fork)
         L.call("pg_stream_wait", E._raw(self._pf_stream), L.stream())        # (the inputs were produced on this stream)
         with torch.cuda.stream(self._pf_stream):
+            # (round 6) the generator's gradient arena (328 MB at 256^2) is zeroed here, next to dis_update's work, instead of at the
+            # start of gen_update: dis_update never touches it, the last reader (the previous gen_update's Adam) is behind the fork, and
+            # gen_update joins this stream before its first gradient write.  tools/pass_sensitivity.py: the zero fills cost 0.09 - 0.14 ms
+            # of a batch-4 iteration on the main stream.
+            zeroed = ZERO_ON_PREFETCH
+            if zeroed:
+                self.gen.zero_grad()
             engs, out = self._gen_forward(input, other_inputs, (other_inputs or {}).get("drop_masks"), engine_stage=1)
-        self._pf = {"key": self._pf_key(input, other_inputs), "engs": engs, "out": out, "input": input}
+        self._pf = {"key": self._pf_key(input, other_inputs), "engs": engs, "out": out, "input": input, "zeroed": zeroed}
         return True
 
     def _pf_key(self, input, other_inputs):
@@ -200,6 +208,7 @@ class DeformablePose_GAN(nn.Module):
                 self._drop_n.pop(("g", 0), None)
             return None
         L.call("pg_stream_wait", L.stream(), E._raw(self._pf_stream))        # this stream continues behind the prefetched pass
+        self._pf_zeroed = bool(pf.get("zeroed"))
         return pf["engs"], pf["out"]
 
     def _gen_forward(self, input, other_inputs, drop_masks, call="g", engine_stage=0):
@@ -233,9 +242,11 @@ class DeformablePose_GAN(nn.Module):
         """reference pose_gan.py:69-115."""
         n, (H, W) = input.shape[0], self.image_size
         input, target = input.contiguous(), target.contiguous()
-        self.gen.zero_grad()
         E.dev_zero(self._loss[0:3])
+        self._pf_zeroed = False
         pre = self._take_prefetched(input, other_inputs)
+        if not self._pf_zeroed:          # (the prefetched pass zeroed the gradient arena on its stream, behind which this one continues)
+            self.gen.zero_grad()
         if pre is not None:
             engs, out_gen = pre
         else:
